@@ -1,0 +1,169 @@
+/* mpiflow_hip.h - C ABI of libmpiflow_hip.so: the MI355X (gfx950) implementation of MPI-Flow's per-image hot path.
+ *
+ * The reference (Sharpiless/MPI-Flow) has no plugin/operator registry.  Its boundary for this path is
+ *   (1) one real FFI symbol: `forward_warping` in external/forward_warping/warping.c:6, loaded with ctypes at
+ *       moving_obj.py:12-13 and called with host pointers at moving_obj.py:127-129; and
+ *   (2) plain Python call signatures (utils/utils.py, utils/mpi/ modules, geometry.py, moving_obj.py), whose arithmetic
+ *       is carried out by PyTorch ATen kernels.
+ * This library therefore exports (1) under its exact name and semantics, and for (2) one device-pointer entry point
+ * per reference function on the path (the comment on each cites the reference lines it replaces).  The Python
+ * package mpiflow_amd/ mirrors the reference's signatures and binds these symbols with ctypes; INTEGRATION.md shows
+ * the same binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every mpf_* function returns 0 on success, otherwise a hipError_t value (or MPF_ERR_*); mpf_last_error()
+ *     returns a description for the calling thread.  Nothing is thrown, nothing aborts.
+ *   - pointers named d_* are DEVICE pointers (fp32 unless stated), row-major, contiguous; the caller owns them.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All calls are asynchronous on that
+ *     stream and graph-capturable: no allocation, no synchronisation, no host<->device copies inside, except the
+ *     two host-pointer conveniences at the bottom which say so.
+ *   - small per-call matrices (K^-1, G, per-plane homographies, plane depths) arrive in ONE device buffer
+ *     `d_params` of MPF_PARAMS_FLOATS(records) floats laid out as below; the host computes them with the
+ *     reference's own batched torch-CPU expressions (bit-identical homographies are a parity requirement).
+ *   - B == 1 (as in the reference's entry point); S planes ordered near -> far; N = H*W; S < 4096.
+ */
+#ifndef MPIFLOW_HIP_H
+#define MPIFLOW_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPF_VERSION 100
+
+/* d_params layout (floats):
+ *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)
+ *   [21..31] reserved (zero)
+ *   then one 16-float record per plane (per plane and pose for mpf_src_blend_flow: record = s*P + p):
+ *     [0..8] 3x3 homography (H_src_tgt for warps, H_tgt_src for flows)   [9] plane depth d_s = 1/disparity_s
+ *     [10..15] reserved (zero)                                                                                  */
+#define MPF_PARAMS_HEADER 32
+#define MPF_PLANE_RECORD 16
+#define MPF_PARAMS_FLOATS(records) (MPF_PARAMS_HEADER + MPF_PLANE_RECORD * (records))
+
+#define MPF_ERR_BAD_ARGUMENT 10001
+#define MPF_ERR_UNSUPPORTED  10002
+
+int mpf_version(void);
+const char *mpf_last_error(void);
+/* fills CU count, HBM bytes, gfx arch name (e.g. "gfx950"); any pointer may be NULL */
+int mpf_device_info(int device, int *cu_count, size_t *hbm_bytes, char *arch, size_t arch_len);
+
+/* bench/tuning knobs (never change results): "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 4) */
+int mpf_tune(const char *key, int value);
+
+/* ================= fused hot path =============================================================================== */
+
+/* Stage A + C.  Replaces utils/utils.py:190-204 (get_src_xyz_from_plane_disparity + render() in the source frame +
+ * the blend of the source image into every plane) fused with HomographySample.sample_inverse
+ * (utils/mpi/homography_sampler.py:160-220) + plane_volume_rendering_flow (utils/mpi/mpi_rendering.py:102-139) for
+ * P = 0, 1 or 2 poses sharing the same source-frame weights.
+ *   d_mpi [S,4,H,W] planar (rgb, sigma);  d_img [3,H,W];  d_params with S*P records (S records if P == 0; only the
+ *   depth is read then).  Outputs, each optional (NULL to skip):
+ *   d_out_rgba [S,H,W,4] interleaved blended rgb + sigma (the layout mpf_warp_composite streams fastest);
+ *   d_out_rgb_planar [S,3,H,W];  d_out_tacc [S,H,W] (= "blend_weights");  d_flows [P,2,H,W], clipped to
+ *   +-flow_clip when flow_clip > 0 (utils/utils.py:348). */
+int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const float *d_params, int P, int S, int H, int W,
+                       float flow_clip, float *d_out_rgba, float *d_out_rgb_planar, float *d_out_tacc,
+                       float *d_flows, void *stream);
+
+/* obj_mask [H,W] -> per-texel quads (m[y,x], m[y,x+1], m[y+1,x], m[y+1,x+1]) as float4 [H,W,4], out-of-range
+ * neighbours 0, of (complement ? 1 - m : m): the four bilinear taps of the mask channel in one 16-byte load.
+ * (utils/utils.py:328 repeats the same [H,W] mask over all S planes; :225 passes 1 - obj_mask.) */
+int mpf_build_mask_quads(const float *d_obj_mask, int complement, int H, int W, float *d_quads, void *stream);
+
+/* Stage B - the north-star kernel.  Replaces HomographySample.sample (utils/mpi/homography_sampler.py:80-158) on the
+ * 8-channel stack + render_tgt_rgb_depth's composite (utils/mpi/mpi_rendering.py:336-347 -> plane_volume_rendering
+ * :62-99 -> weighted_sum_mpi :142-154), streamed per target pixel; xyz_tgt is evaluated analytically at the clamped
+ * source coordinate instead of being warped as 3 extra channels.
+ *   d_rgba: [S,H,W,4] if interleaved else planar [S,4,H,W];  d_mask_quads from mpf_build_mask_quads or NULL;
+ *   d_params with S records holding H_src_tgt.  Outputs: d_rgb [3,H,W], d_depth [H,W] (NULL ok),
+ *   d_objmask [H,W] (NULL iff d_mask_quads NULL), d_tgt_mask [H,W] = number of planes whose source coordinate is in
+ *   range (NULL ok). */
+int mpf_warp_composite(const float *d_rgba, int interleaved, const float *d_mask_quads, const float *d_params,
+                       int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask, float *d_tgt_mask,
+                       void *stream);
+
+/* Stage D.  Replaces utils/utils.py:237-283 (uint8 BGR conversion, threshold, layer select, fill mask).
+ * frames [3,H,W] RGB float, masks [H,W], flows [2,H,W], obj_mask [H,W] ->
+ * d_flow_mix [H,W,2] f32, d_frame_mix [H,W,3] u8 BGR, d_fill_mask [H,W] u8 (1 = hole to inpaint). */
+int mpf_merge(const float *d_frame, const float *d_frame_dyn, const float *d_mask, const float *d_mask_dyn,
+              const float *d_flow, const float *d_flow_dyn, const float *d_obj_mask, float thresh, int H, int W,
+              float *d_flow_mix, uint8_t *d_frame_mix, uint8_t *d_fill_mask, void *stream);
+
+/* One onion-peel pass of the built-in hole fill used when OpenCV is absent (NOT cv2.inpaint's Navier-Stokes; row A13 is
+ * parity-unpinned): hole pixels touching a known pixel become the rounded mean of their known
+ * 8-neighbours.  img u8 [H,W,3], hole u8 [H,W] (1 = hole); *d_remaining is incremented by the holes still open. */
+int mpf_fill_holes_step(const uint8_t *d_img_in, const uint8_t *d_hole_in, int H, int W, uint8_t *d_img_out,
+                        uint8_t *d_hole_out, unsigned *d_remaining, void *stream);
+
+/* [3,H,W] float RGB -> [H,W,3] u8 BGR, clip(rint(x*255))  (utils/utils.py:174-177) */
+int mpf_to_u8_bgr(const float *d_img, int H, int W, uint8_t *d_out, void *stream);
+
+/* ================= generic (materialised-tensor) ops behind the utils/mpi function signatures ==================== */
+
+/* get_src_xyz_from_plane_disparity (utils/mpi/mpi_rendering.py:213-239): params header K^-1 + S records (depth) */
+int mpf_src_xyz(const float *d_params, int S, int H, int W, float *d_xyz_S3HW, void *stream);
+/* transform_G_xyz (utils/mpi/rendering_utils.py:4-23): params header G; xyz [S,3,N] -> [S,3,N] */
+int mpf_transform_xyz(const float *d_params, const float *d_xyz, int S, int64_t N, float *d_out, void *stream);
+/* HomographySample.sample after H_src_tgt is known (utils/mpi/homography_sampler.py:124-158):
+ * src [S,C,H,W] -> tgt [S,C,H,W], valid u8 [S,H,W] (NULL ok), flowB2A [S,H,W,2] (NULL ok) */
+int mpf_homography_sample(const float *d_src, const float *d_params, int S, int C, int H, int W, float *d_tgt,
+                          uint8_t *d_valid, float *d_flowB2A, void *stream);
+/* HomographySample.sample_inverse after H_tgt_src is known (utils/mpi/homography_sampler.py:197-218): [S,H,W,2] */
+int mpf_homography_flow(const float *d_params, int S, int H, int W, float *d_flow, void *stream);
+/* plane_volume_rendering / plane_volume_rendering_flow / weighted_sum_mpi (utils/mpi/mpi_rendering.py:62-154) on
+ * materialised rgb [S,3,N] (NULL ok), sigma [S,N], xyz [S,3,N]; extra_in [S,E,N] (E <= 4) is summed with the same
+ * weights into extra_out [E,N] (flow and/or obj-mask).  hard != 0: extra is taken from the arg-max-weight plane only
+ * (hard_flow, :126-130). */
+int mpf_volume_render(const float *d_rgb, const float *d_sigma, const float *d_xyz, int S, int64_t N,
+                      float *d_rgb_out, float *d_depth_out, float *d_tacc_out, float *d_weights_out,
+                      const float *d_extra_in, int E, float *d_extra_out, int hard, void *stream);
+
+/* weighted_sum_mpi's sums with caller-supplied weights (utils/mpi/mpi_rendering.py:143-152):
+ * out[c,n] = cascade-sum_s weights[s,n] * values[s,c,n]   (values NULL: plain sum of the weights, C must be 1) */
+int mpf_weighted_sum(const float *d_weights, const float *d_values, int S, int C, int64_t N, float *d_out, void *stream);
+
+/* ================= depth -> flow projection and forward warp (geometry.py, moving_obj.py, warping.c) ============= */
+
+/* moving_obj.py:29-30: depth = 1 / (disp + 0.005), values above 100 clamped to 100 */
+int mpf_disp_to_depth(const float *d_disp, int64_t N, float *d_depth, void *stream);
+/* BackprojectDepth + Project3D (geometry.py:41-49, :63-76): depth [H,W]; inv_K 3x3 and P = (K.T)[:3,:] 3x4 passed BY
+ * VALUE from host pointers; outputs pix [H,W,2] (normalised as the reference returns them) and z [H,W]. */
+int mpf_backproject_project(const float *d_depth, const float *h_inv_k9, const float *h_P12, int H, int W,
+                            float *d_pix, float *d_z, void *stream);
+/* The two halves on their own, for the class-level drop-ins: BackprojectDepth.forward -> cam points [4,N] (rows X,Y,Z,1)
+ * and Project3D.forward on arbitrary homogeneous points [4,N] with eps (geometry.py:55, :70). */
+int mpf_backproject(const float *d_depth, const float *h_inv_k9, int H, int W, float *d_cam_points, void *stream);
+int mpf_project3d(const float *d_points_4N, const float *h_P12, float eps, int H, int W, float *d_pix, float *d_z,
+                  void *stream);
+/* moving_obj.py:108-124, :153: select object/static projection by instance mask, to pixel units, truncate + clamp.
+ * outputs p1 [H,W,2], z1 [H,W], safe_x/safe_y int64 [H,W], flow01 [H,W,2] */
+int mpf_select_truncate(const float *d_p_static, const float *d_z_static, const float *d_p_obj, const float *d_z_obj,
+                        const float *d_inst, int H, int W, float *d_p1, float *d_z1, int64_t *d_safe_x,
+                        int64_t *d_safe_y, float *d_flow01, void *stream);
+/* Order-preserving parallel equivalent of warping.c:6-33 on device buffers.  d_warped u8 [h,w,5] is fully written
+ * (no need to zero it).  d_workspace: mpf_forward_warp_workspace(h,w) bytes of scratch. */
+size_t mpf_forward_warp_workspace(int h, int w);
+int mpf_forward_warp(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_idy, const float *d_z,
+                     uint8_t *d_warped, int h, int w, void *d_workspace, size_t workspace_bytes, void *stream);
+/* moving_obj.py:133-150: masks H, M, M' = dilate3x3(M), P = (M' == M), H' = H*P, each u8 [H,W] */
+int mpf_warp_masks(const uint8_t *d_warped, int H, int W, uint8_t *d_Hm, uint8_t *d_M, uint8_t *d_Md, uint8_t *d_P,
+                   uint8_t *d_Hp, void *stream);
+
+/* THE REFERENCE'S FFI SYMBOL (external/forward_warping/warping.c:6; bound at moving_obj.py:12-13, called at :127-129).
+ * Same name, same argument meaning, HOST pointers: src u8 [h*w*3], idx/idy int64 [h*w] (pre-clamped by the caller, as
+ * in the reference), z f32 [h*w], warped u8 [h*w*5] (caller-owned).  Synchronous.  Runs the HIP kernels above on the
+ * current device (copies in, warps, copies out); there is no CPU implementation behind it - without a GPU it prints
+ * the HIP error to stderr and leaves `warped` untouched (the reference signature has no error channel). */
+void forward_warping(const void *src, const void *idx, const void *idy, const void *z, void *warped, int h, int w);
+/* same, with an error code */
+int mpf_forward_warping_host(const void *src, const void *idx, const void *idy, const void *z, void *warped, int h,
+                             int w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""ctypes binding of libmpiflow_hip.so (C ABI: include/mpiflow_hip.h).
+
+The shared library is built in-tree by `python __graft_entry__.py` / `make -C mpiflow_amd/csrc` with
+`hipcc --offload-arch=gfx950`.  There is NO fallback: if the library is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpiflow_hip.so")
+
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_i64 = ctypes.c_int64
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/mpiflow_hip.h declares (tests/test_capi.py checks)
+SIGNATURES = {
+    "mpf_version": (c_i, []),
+    "mpf_last_error": (ctypes.c_char_p, []),
+    "mpf_device_info": (c_i, [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_sz), ctypes.c_char_p, c_sz]),
+    "mpf_src_blend_flow": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "mpf_build_mask_quads": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "mpf_warp_composite": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "mpf_merge": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "mpf_fill_holes_step": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "mpf_to_u8_bgr": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    "mpf_src_xyz": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "mpf_transform_xyz": (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p]),
+    "mpf_homography_sample": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "mpf_homography_flow": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "mpf_volume_render": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "mpf_weighted_sum": (c_i, [c_p, c_p, c_i, c_i, c_i64, c_p, c_p]),
+    "mpf_disp_to_depth": (c_i, [c_p, c_i64, c_p, c_p]),
+    "mpf_backproject_project": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "mpf_backproject": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+    "mpf_project3d": (c_i, [c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p]),
+    "mpf_select_truncate": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "mpf_forward_warp_workspace": (c_sz, [c_i, c_i]),
+    "mpf_forward_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_sz, c_p]),
+    "mpf_warp_masks": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "forward_warping": (None, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
+    "mpf_forward_warping_host": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
+    "mpf_tune": (c_i, [ctypes.c_char_p, c_i]),
+}
+
+
+class MpiFlowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MpiFlowHipError(
+            "libmpiflow_hip.so not found at %s - build it with `python __graft_entry__.py` or "
+            "`make -C mpiflow_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mpf_last_error()
+        raise MpiFlowHipError("%s failed with code %d: %s" % (what or "libmpiflow_hip call", rc,
+                                                              msg.decode() if msg else "?"))
+
+
+def device_info(device=0):
+    lib = load()
+    cu, mem = c_i(0), c_sz(0)
+    arch = ctypes.create_string_buffer(64)
+    check(lib.mpf_device_info(device, ctypes.byref(cu), ctypes.byref(mem), arch, 64), "mpf_device_info")
+    return dict(cu_count=cu.value, hbm_bytes=mem.value, arch=arch.value.decode())

@@ -1,0 +1,356 @@
+// mpf_fwarp.hip - order-preserving parallel forward splat for MI355X (gfx950) + the glue kernels of moving_obj.py.
+//
+// The reference's external/forward_warping/warping.c:6-33 is a serial raster scan whose result depends on visit
+// order: at a target pixel the colour that survives is NOT the z-minimum but that of the LAST source (in raster order)
+// whose z is smaller than the z of the source that visited the target immediately before it (1000 for the first);
+// the collision byte records whether the last visitor found the target untouched (or left at the 1000 sentinel).
+// A z-buffer with atomics therefore gives different images (SURVEY.md §7 hard part 3).  Parallel restatement used here:
+//
+//   1. key[i] = target(i) = idy[i]*w + idx[i] for every source pixel i (raster index)
+//   2. stable LSD radix sort of (key, i) by key          -> each target's visitors, contiguous, in raster order
+//   3. per sorted slot j: pred = slot j-1 if same target;  cond(j) = z[j] < (pred ? z[pred] : 1000)
+//      winner(target) = max j with cond(j)                (atomicMax on a per-target word)
+//   4. the last slot of each segment writes the 5 output bytes of its target
+//
+// Integer/byte work, bandwidth-trivial (N = h*w <= a few million 4-byte keys, 3 radix passes): the design goal is
+// bit-exact equality with the serial C, with bounded cost for pathological pile-ups (thousands of sources clamped onto
+// one border pixel), which is what the global sort buys over per-target lists.
+#include <string.h>
+#include "mpf_common.h"
+#include "mpf_math.h"
+
+#define RADIX_BITS 8
+#define RADIX 256
+#define SORT_THREADS 256
+#define SORT_ITEMS 8
+#define SORT_TILE (SORT_THREADS * SORT_ITEMS)
+
+// ---- moving_obj.py:29-30 : depth = 1/(disp + 0.005), clamped to 100 --------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_disp_to_depth(const float *__restrict__ disp, int64_t N, float *__restrict__ depth)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float d = 1.0f / (disp[n] + 0.005f);
+    depth[n] = (d > 100.0f) ? 100.0f : d;
+}
+
+extern "C" int mpf_disp_to_depth(const float *d_disp, int64_t N, float *d_depth, void *stream)
+{
+    MPF_REQUIRE(d_disp && d_depth && N >= 1, "mpf_disp_to_depth: bad argument");
+    hipLaunchKernelGGL(k_disp_to_depth, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_disp, N, d_depth);
+    return mpf_launch_status("k_disp_to_depth");
+}
+
+// ---- moving_obj.py:108-124, :153 --------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_select_truncate(const float *__restrict__ p_static, const float *__restrict__ z_static, const float *__restrict__ p_obj,
+                  const float *__restrict__ z_obj, const float *__restrict__ inst, int H, int W, float *__restrict__ p1,
+                  float *__restrict__ z1, int64_t *__restrict__ safe_x, int64_t *__restrict__ safe_y, float *__restrict__ flow01)
+{
+    const int64_t N = (int64_t)H * W;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const bool sel = inst[n] > 0.0f;                                    // :108-112
+    const float nx = sel ? p_obj[2 * n] : p_static[2 * n];
+    const float ny = sel ? p_obj[2 * n + 1] : p_static[2 * n + 1];
+    z1[n] = sel ? z_obj[n] : z_static[n];
+    const float px = (nx + 1.0f) / 2.0f * (float)(W - 1);               // :115-117
+    const float py = (ny + 1.0f) / 2.0f * (float)(H - 1);
+    p1[2 * n] = px; p1[2 * n + 1] = py;
+    int64_t tx = (int64_t)px, ty = (int64_t)py;                         // .long() truncates toward zero, :121-122
+    tx = tx > W - 1 ? W - 1 : tx; tx = tx < 0 ? 0 : tx;
+    ty = ty > H - 1 ? H - 1 : ty; ty = ty < 0 ? 0 : ty;
+    safe_x[n] = tx; safe_y[n] = ty;
+    flow01[2 * n] = px - (float)(n % W);                                // :153
+    flow01[2 * n + 1] = py - (float)(n / W);
+}
+
+extern "C" int mpf_select_truncate(const float *d_p_static, const float *d_z_static, const float *d_p_obj, const float *d_z_obj,
+                                   const float *d_inst, int H, int W, float *d_p1, float *d_z1, int64_t *d_safe_x,
+                                   int64_t *d_safe_y, float *d_flow01, void *stream)
+{
+    MPF_REQUIRE(d_p_static && d_z_static && d_p_obj && d_z_obj && d_inst && d_p1 && d_z1 && d_safe_x && d_safe_y && d_flow01 &&
+                    H >= 1 && W >= 1, "mpf_select_truncate: bad argument");
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_select_truncate, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p_static,
+                       d_z_static, d_p_obj, d_z_obj, d_inst, H, W, d_p1, d_z1, d_safe_x, d_safe_y, d_flow01);
+    return mpf_launch_status("k_select_truncate");
+}
+
+// ---- sort -------------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_fw_keys(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy, int h, int w, uint32_t *__restrict__ keys,
+          uint32_t *__restrict__ vals)
+{
+    const int64_t N = (int64_t)h * w;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    int64_t x = idx[n], y = idy[n];
+    // the reference does no bounds check (caller pre-clamps, moving_obj.py:121-122); clamp instead of scribbling
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+    keys[n] = (uint32_t)(y * w + x);
+    vals[n] = (uint32_t)n;
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t nb, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = base + it * SORT_THREADS + threadIdx.x;
+        if (i < N) atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];      // digit-major, so one linear scan orders the scatter
+}
+
+// exclusive scan of M = RADIX*nb counters by one 1024-thread workgroup (M is ~1e5 at most)
+__global__ void __launch_bounds__(1024)
+k_scan_exclusive(uint32_t *__restrict__ data, uint32_t M)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t chunk = (M + 1023) / 1024;
+    const uint32_t b = threadIdx.x * chunk, e = min(b + chunk, M);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += data[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {              // Hillis-Steele inclusive scan of the partials
+        uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t i = b; i < e; ++i) {
+        uint32_t v = data[i];
+        data[i] = run;
+        run += v;
+    }
+}
+
+// Stable scatter of one tile.  Keys are visited in index order: iteration `it` covers 256 consecutive keys, wave k of
+// the workgroup the k-th 64 of them, lane l the l-th.  rank-in-wave comes from 8 ballots (one per digit bit), waves
+// are ordered through per-wave digit counts in LDS, iterations through a running per-digit cursor.
+__global__ void __launch_bounds__(SORT_THREADS)
+k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+                uint32_t *__restrict__ vals_out, uint32_t N, int shift, uint32_t nb, const uint32_t *__restrict__ offsets)
+{
+    __shared__ uint32_t running[RADIX];
+    __shared__ uint32_t cnt[SORT_THREADS / 64][RADIX];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    running[tid] = offsets[tid * nb + blockIdx.x];
+    const uint32_t base = blockIdx.x * SORT_TILE;
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = base + it * SORT_THREADS + tid;
+        const bool valid = i < N;
+        const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
+        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t digit = (key >> shift) & (RADIX - 1);
+#pragma unroll
+        for (int k = 0; k < RADIX / 64; ++k) cnt[wave][lane + 64 * k] = 0;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const bool bit = (digit >> b) & 1;
+            const unsigned long long bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) cnt[wave][digit] = __popcll(mask);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[digit] + rank;
+            for (uint32_t k = 0; k < wave; ++k) pos += cnt[k][digit];
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        uint32_t add = 0;
+#pragma unroll
+        for (int k = 0; k < SORT_THREADS / 64; ++k) add += cnt[k][tid];
+        running[tid] += add;
+        __syncthreads();
+    }
+}
+
+// ---- resolve ----------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_fw_mark(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const float *__restrict__ z, uint32_t N,
+          uint32_t *__restrict__ win)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t t = keys[j];
+    const bool has_pred = (j > 0) && (keys[j - 1] == t);
+    const float zprev = has_pred ? z[vals[j - 1]] : 1000.0f;          // dlut, warping.c:11, :29
+    if (z[vals[j]] < zprev) atomicMax(&win[t], j + 1);                // warping.c:19
+}
+
+__global__ void __launch_bounds__(256)
+k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const float *__restrict__ z,
+           const uint8_t *__restrict__ src, uint32_t N, const uint32_t *__restrict__ win, uint8_t *__restrict__ warped)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t t = keys[j];
+    if (j + 1 < N && keys[j + 1] == t) return;                        // only the last visitor of a target writes
+    const bool has_pred = (j > 0) && (keys[j - 1] == t);
+    const float zprev = has_pred ? z[vals[j - 1]] : 1000.0f;
+    uint8_t *o = warped + (size_t)t * 5;
+    const uint32_t wj = win[t];
+    if (wj) {                                                         // no visitor ever passed the z test: colour bytes
+        const uint8_t *s = src + (size_t)vals[wj - 1] * 3;            // keep what they held (warping.c:19-21)
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+    }
+    o[3] = 1;                                                         // warping.c:23
+    o[4] = (zprev == 1000.0f) ? 1 : 0;                                // warping.c:24-27
+}
+
+static inline uint32_t fw_blocks(int64_t N) { return (uint32_t)((N + SORT_TILE - 1) / SORT_TILE); }
+
+extern "C" size_t mpf_forward_warp_workspace(int h, int w)
+{
+    const int64_t N = (int64_t)h * w;
+    if (N <= 0) return 0;
+    const size_t a = ((size_t)N * 4 + 255) & ~(size_t)255;
+    const size_t hs = (((size_t)RADIX * fw_blocks(N)) * 4 + 255) & ~(size_t)255;
+    return 5 * a + hs;                // keysA, keysB, valsA, valsB, win, hist
+}
+
+static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_idy, const float *d_z, uint8_t *d_warped, int h,
+                  int w, void *d_workspace, size_t workspace_bytes, void *stream, bool zero_fill)
+{
+    MPF_REQUIRE(d_src && d_idx && d_idy && d_z && d_warped && d_workspace && h >= 1 && w >= 1, "mpf_forward_warp: bad argument");
+    const int64_t N64 = (int64_t)h * w;
+    MPF_REQUIRE(N64 < ((int64_t)1 << 31), "mpf_forward_warp: image too large");
+    MPF_REQUIRE(workspace_bytes >= mpf_forward_warp_workspace(h, w), "mpf_forward_warp: workspace too small");
+    MPF_REQUIRE((((uintptr_t)d_workspace) & 255) == 0, "mpf_forward_warp: workspace must be 256-byte aligned");
+    const uint32_t N = (uint32_t)N64;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t a = ((size_t)N * 4 + 255) & ~(size_t)255;
+    uint8_t *ws = (uint8_t *)d_workspace;
+    uint32_t *keys[2] = { (uint32_t *)ws, (uint32_t *)(ws + a) };
+    uint32_t *vals[2] = { (uint32_t *)(ws + 2 * a), (uint32_t *)(ws + 3 * a) };
+    uint32_t *win = (uint32_t *)(ws + 4 * a);
+    uint32_t *hist = (uint32_t *)(ws + 5 * a);
+    const uint32_t nb = fw_blocks(N);
+    const uint32_t g256 = (N + 255) / 256;
+
+    hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0]);
+    int bits = 0;
+    while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)N) ++bits;
+    int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
+    if (passes < 1) passes = 1;
+    int cur = 0;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * RADIX_BITS;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SORT_THREADS), 0, st, keys[cur], N, shift, nb, hist);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, hist, (uint32_t)RADIX * nb);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(SORT_THREADS), 0, st, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
+                           N, shift, nb, hist);
+        cur ^= 1;
+    }
+    MPF_HIP(hipMemsetAsync(win, 0, (size_t)N * 4, st));
+    if (zero_fill) MPF_HIP(hipMemsetAsync(d_warped, 0, (size_t)N * 5, st));   // unvisited targets: 0 (moving_obj.py:123 zero-inits)
+    hipLaunchKernelGGL(k_fw_mark, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, N, win);
+    hipLaunchKernelGGL(k_fw_write, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, d_src, N, win, d_warped);
+    return mpf_launch_status("forward_warp kernels");
+}
+
+extern "C" int mpf_forward_warp(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_idy, const float *d_z,
+                                uint8_t *d_warped, int h, int w, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    return fw_run(d_src, d_idx, d_idy, d_z, d_warped, h, w, d_workspace, workspace_bytes, stream, true);
+}
+
+// ---- moving_obj.py:133-150 --------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_warp_masks(const uint8_t *__restrict__ warped, int H, int W, uint8_t *__restrict__ Hm, uint8_t *__restrict__ M,
+             uint8_t *__restrict__ Md, uint8_t *__restrict__ P, uint8_t *__restrict__ Hp)
+{
+    const int64_t N = (int64_t)H * W;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int x = (int)(n % W), y = (int)(n / W);
+    const uint8_t hv = warped[n * 5 + 3];
+    const uint8_t m = (uint8_t)(1 - (warped[n * 5 + 4] == hv));       // M = 1 - (collision == valid)
+    uint8_t md = 0;                                                    // cv2.dilate 3x3, border never wins the max
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const int64_t k = (int64_t)yy * W + xx;
+                const uint8_t mk = (uint8_t)(1 - (warped[k * 5 + 4] == warped[k * 5 + 3]));
+                md = mk > md ? mk : md;
+            }
+        }
+    Hm[n] = hv; M[n] = m; Md[n] = md;
+    const uint8_t p = (uint8_t)(md == m);
+    P[n] = p;
+    Hp[n] = (uint8_t)(hv * p);
+}
+
+extern "C" int mpf_warp_masks(const uint8_t *d_warped, int H, int W, uint8_t *d_Hm, uint8_t *d_M, uint8_t *d_Md, uint8_t *d_P,
+                              uint8_t *d_Hp, void *stream)
+{
+    MPF_REQUIRE(d_warped && d_Hm && d_M && d_Md && d_P && d_Hp && H >= 1 && W >= 1, "mpf_warp_masks: bad argument");
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_warp_masks, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_warped, H, W, d_Hm,
+                       d_M, d_Md, d_P, d_Hp);
+    return mpf_launch_status("k_warp_masks");
+}
+
+// ---- the reference's FFI symbol (host pointers) -----------------------------------------------------------------
+
+extern "C" int mpf_forward_warping_host(const void *src, const void *idx, const void *idy, const void *z, void *warped, int h, int w)
+{
+    MPF_REQUIRE(src && idx && idy && z && warped && h >= 1 && w >= 1, "forward_warping: bad argument");
+    const size_t N = (size_t)h * w;
+    const size_t wsb = mpf_forward_warp_workspace(h, w);
+    uint8_t *d = nullptr;
+    // one allocation: src | idx | idy | z | warped | workspace, each 256-byte aligned
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_src = 0, o_idx = o_src + al(N * 3), o_idy = o_idx + al(N * 8), o_z = o_idy + al(N * 8), o_w = o_z + al(N * 4),
+                 o_ws = o_w + al(N * 5), total = o_ws + wsb;
+    MPF_HIP(hipMalloc((void **)&d, total));
+    int rc = 0;
+    hipError_t e;
+    do {
+        if ((e = hipMemcpy(d + o_src, src, N * 3, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipMemcpy(d + o_idx, idx, N * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipMemcpy(d + o_idy, idy, N * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipMemcpy(d + o_z, z, N * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
+        // warping.c only touches the bytes of visited targets; everything else keeps the caller's contents
+        if ((e = hipMemcpy(d + o_w, warped, N * 5, hipMemcpyHostToDevice)) != hipSuccess) break;
+        rc = fw_run(d + o_src, (const int64_t *)(d + o_idx), (const int64_t *)(d + o_idy), (const float *)(d + o_z), d + o_w, h, w,
+                    d + o_ws, wsb, nullptr, false);
+        if (rc) break;
+        if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) break;
+        e = hipMemcpy(warped, d + o_w, N * 5, hipMemcpyDeviceToHost);
+    } while (0);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) {
+        mpf_set_error("forward_warping: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" void forward_warping(const void *src, const void *idx, const void *idy, const void *z, void *warped, int h, int w)
+{
+    if (mpf_forward_warping_host(src, idx, idy, z, warped, h, w) != 0)
+        fprintf(stderr, "libmpiflow_hip forward_warping: %s\n", mpf_last_error());
+}

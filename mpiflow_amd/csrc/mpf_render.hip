@@ -1,0 +1,512 @@
+// mpf_render.hip - fused MPI render / flow kernels for MI355X (gfx950, wave64) and their C-ABI launchers.
+//
+//   k_src_blend_flow   Stage A + C  (source frame: transmittance chain -> blended RGBA stack + volume-rendered flows)
+//   k_warp_composite   Stage B      (target frame: per-plane homography warp + front-to-back composite)
+//   k_mask_quads, k_merge, k_to_u8_bgr   small per-pixel helpers around them
+//
+// All of them are HBM-streaming kernels (30-40 flop per 16 B); none is GEMM-shaped, so no MFMA.  What matters is
+// coalesced 16-byte accesses, enough waves in flight to cover gather latency, an XCD-aware tile order so the texel
+// rows two neighbouring tiles share are found in the same L2, and keeping the whole S-plane recurrence in
+// registers so that no [S,...] intermediate is ever written (the reference materialises ~8 of them per view).
+#include <string.h>
+#include "mpf_common.h"
+#include "mpf_math.h"
+
+#define MPF_TILE_W 64   // one wavefront = 64 consecutive target pixels of one row
+#define MPF_TILE_H 4    // 4 waves per 256-thread workgroup
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage B
+// ---------------------------------------------------------------------------------------------------------------
+
+struct MpfPlaneTaps {
+    int o00, o01, o10, o11;   // texel offsets (y*W + x) of the four taps, clamped in range
+    bool e_in, s_in, valid;
+    float nw, ne, sw, se;
+    float X, Y, Z;            // xyz_tgt at the clamped source coordinate
+};
+
+// Coordinates of target pixel (fx,fy) in source plane s, bilinear taps, validity, and the warped xyz_tgt.
+// reference: utils/mpi/homography_sampler.py:131-147 (H_src_tgt . p, divide, valid), :151-156 (normalise +
+// grid_sample), and the three xyz channels of mpi_rendering.py:288-301 evaluated analytically:
+// xyz_tgt = G . (K^-1 (ix,iy,1) * d_s ; 1)  (mpi_rendering.py:213-256 at the clamped coordinate).
+MPF_DEV MpfPlaneTaps mpf_plane_taps(const float *__restrict__ params, int s, float fx, float fy, int W, int H)
+{
+    const float *rec = params + MPF_PARAMS_HEADER + MPF_PLANE_RECORD * s;
+    float qx = mpf_row3_xy1(rec[0], rec[1], rec[2], fx, fy);
+    float qy = mpf_row3_xy1(rec[3], rec[4], rec[5], fx, fy);
+    float qz = mpf_row3_xy1(rec[6], rec[7], rec[8], fx, fy);
+    float u = qx / qz, v = qy / qz;
+    MpfPlaneTaps p;
+    p.valid = (u < (float)W) && (u > -1.0f) && (v < (float)H) && (v > -1.0f);
+    MpfTaps t = mpf_make_taps(u, v, W, H);
+    p.e_in = t.e_in; p.s_in = t.s_in;
+    p.nw = t.nw; p.ne = t.ne; p.sw = t.sw; p.se = t.se;
+    p.o00 = t.y0 * W + t.x0;
+    p.o01 = p.o00 + (t.e_in ? 1 : 0);
+    p.o10 = p.o00 + (t.s_in ? W : 0);
+    p.o11 = p.o10 + (t.e_in ? 1 : 0);
+    const float d = rec[9];
+    float rx = mpf_row3_xy1(params[0], params[1], params[2], t.ix, t.iy) * d;
+    float ry = mpf_row3_xy1(params[3], params[4], params[5], t.ix, t.iy) * d;
+    float rz = mpf_row3_xy1(params[6], params[7], params[8], t.ix, t.iy) * d;
+    p.X = mpf_row4_xyz1(params[9], params[10], params[11], params[12], rx, ry, rz);
+    p.Y = mpf_row4_xyz1(params[13], params[14], params[15], params[16], rx, ry, rz);
+    p.Z = mpf_row4_xyz1(params[17], params[18], params[19], params[20], rx, ry, rz);
+    return p;
+}
+
+struct MpfRaw {          // the 4 taps x 4 channels of one plane as fetched, plus the mask quad
+    float4 t00, t01, t10, t11;
+    float4 mq;
+};
+
+template <bool INTERLEAVED, bool HAS_MASK>
+MPF_DEV MpfRaw mpf_fetch(const float *__restrict__ rgba, const float *__restrict__ quads, int s, int64_t N,
+                         const MpfPlaneTaps &p)
+{
+    MpfRaw r;
+    if (INTERLEAVED) {
+        const float4 *pl = reinterpret_cast<const float4 *>(rgba) + (int64_t)s * N;
+        r.t00 = pl[p.o00]; r.t01 = pl[p.o01]; r.t10 = pl[p.o10]; r.t11 = pl[p.o11];
+    } else {
+        const float *pl = rgba + (int64_t)s * 4 * N;
+        r.t00 = make_float4(pl[p.o00], pl[N + p.o00], pl[2 * N + p.o00], pl[3 * N + p.o00]);
+        r.t01 = make_float4(pl[p.o01], pl[N + p.o01], pl[2 * N + p.o01], pl[3 * N + p.o01]);
+        r.t10 = make_float4(pl[p.o10], pl[N + p.o10], pl[2 * N + p.o10], pl[3 * N + p.o10]);
+        r.t11 = make_float4(pl[p.o11], pl[N + p.o11], pl[2 * N + p.o11], pl[3 * N + p.o11]);
+    }
+    if (HAS_MASK) r.mq = reinterpret_cast<const float4 *>(quads)[p.o00];
+    return r;
+}
+
+MPF_DEV float mpf_tap4(const MpfPlaneTaps &p, float a, float b, float c, float d)
+{
+    // out-of-range neighbours are read as 0 (ATen masks them), their weight is 0 as well
+    float o = a * p.nw;
+    o = fmaf(p.e_in ? b : 0.0f, p.ne, o);
+    o = fmaf(p.s_in ? c : 0.0f, p.sw, o);
+    o = fmaf((p.e_in && p.s_in) ? d : 0.0f, p.se, o);
+    return o;
+}
+
+template <bool INTERLEAVED, bool HAS_MASK, int NL>
+__global__ void __launch_bounds__(MPF_TILE_W *MPF_TILE_H)
+k_warp_composite(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
+                 int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                 float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
+{
+    const int64_t N = (int64_t)H * W;
+    const unsigned tiles_x = (W + MPF_TILE_W - 1) / MPF_TILE_W;
+    const unsigned tile = mpf_xcd_remap(blockIdx.x, gridDim.x);
+    const int x = (tile % tiles_x) * MPF_TILE_W + (threadIdx.x & (MPF_TILE_W - 1));
+    const int y = (tile / tiles_x) * MPF_TILE_H + (threadIdx.x / MPF_TILE_W);
+    const bool active = (x < W) && (y < H);
+    // threads past the image edge shadow the last pixel (in-range loads, no store)
+    const float fx = (float)min(x, W - 1), fy = (float)min(y, H - 1);
+
+    MpfPlaneTaps cur = mpf_plane_taps(params, 0, fx, fy, W, H);
+    MpfRaw raw = mpf_fetch<INTERLEAVED, HAS_MASK>(rgba, quads, 0, N, cur);
+
+    double acc = 1.0;                       // torch.cumprod keeps its running product in double on CPU
+    MpfCsum<NL> cw, cd, co, c0, c1, c2;
+    cw.init(); cd.init(); co.init(); c0.init(); c1.init(); c2.init();
+    float nvalid = 0.0f;
+
+    for (int s = 0; s < S; ++s) {
+        // 1. geometry of plane s+1 (pure ALU) and its gathers, issued before plane s is composited
+        MpfPlaneTaps nxt = cur;
+        MpfRaw raw_n = raw;
+        float dist = 1e3f;                                         // mpi_rendering.py:73-78
+        if (s + 1 < S) {
+            nxt = mpf_plane_taps(params, s + 1, fx, fy, W, H);
+            raw_n = mpf_fetch<INTERLEAVED, HAS_MASK>(rgba, quads, s + 1, N, nxt);
+            dist = mpf_norm3(nxt.X - cur.X, nxt.Y - cur.Y, nxt.Z - cur.Z);   // :68-70
+        }
+        // 2. plane s: bilinear taps -> warped rgb, sigma, mask
+        float r = mpf_tap4(cur, raw.t00.x, raw.t01.x, raw.t10.x, raw.t11.x);
+        float g = mpf_tap4(cur, raw.t00.y, raw.t01.y, raw.t10.y, raw.t11.y);
+        float b = mpf_tap4(cur, raw.t00.z, raw.t01.z, raw.t10.z, raw.t11.z);
+        float sg = mpf_tap4(cur, raw.t00.w, raw.t01.w, raw.t10.w, raw.t11.w);
+        sg = (cur.Z >= 0.0f) ? sg : 0.0f;                          // :336-338
+        // 3. front-to-back composite step                          // :79-90
+        float T = mpf_expf(-sg * dist);
+        float alpha = 1.0f - T;
+        float tacc = (float)acc;
+        float w = tacc * alpha;
+        acc *= (double)(T + 1e-6f);
+        cw.push(w);
+        c0.push(w * r); c1.push(w * g); c2.push(w * b);
+        cd.push(w * cur.Z);
+        if (HAS_MASK) {
+            float om = raw.mq.x * cur.nw;        // quads carry the zeros of out-of-range neighbours already
+            om = fmaf(raw.mq.y, cur.ne, om);
+            om = fmaf(raw.mq.z, cur.sw, om);
+            om = fmaf(raw.mq.w, cur.se, om);
+            co.push(w * om);
+        }
+        nvalid += cur.valid ? 1.0f : 0.0f;                         // :347
+        if (((s + 1) & 15) == 0) {
+            cw.fold(s + 1); cd.fold(s + 1); c0.fold(s + 1); c1.fold(s + 1); c2.fold(s + 1);
+            if (HAS_MASK) co.fold(s + 1);
+        }
+        cur = nxt;
+        raw = raw_n;
+    }
+    if (active) {
+        const int64_t n = (int64_t)y * W + x;
+        rgb_out[n] = c0.final();
+        rgb_out[N + n] = c1.final();
+        rgb_out[2 * N + n] = c2.final();
+        if (depth_out) depth_out[n] = cd.final() / (cw.final() + 1e-5f);   // :152
+        if (HAS_MASK) om_out[n] = co.final();
+        if (tgt_mask_out) tgt_mask_out[n] = nvalid;
+    }
+}
+
+template <bool INTERLEAVED, bool HAS_MASK>
+static int launch_warp_composite(const float *rgba, const float *quads, const float *params, int S, int H, int W,
+                                 float *rgb, float *depth, float *om, float *tm, hipStream_t st)
+{
+    const unsigned tiles = ((W + MPF_TILE_W - 1) / MPF_TILE_W) * ((H + MPF_TILE_H - 1) / MPF_TILE_H);
+    dim3 grid(tiles), block(MPF_TILE_W * MPF_TILE_H);
+    if (S < 256)
+        hipLaunchKernelGGL((k_warp_composite<INTERLEAVED, HAS_MASK, 2>), grid, block, 0, st, rgba, quads, params, S, H, W,
+                           rgb, depth, om, tm);
+    else
+        hipLaunchKernelGGL((k_warp_composite<INTERLEAVED, HAS_MASK, 3>), grid, block, 0, st, rgba, quads, params, S, H, W,
+                           rgb, depth, om, tm);
+    return mpf_launch_status("k_warp_composite");
+}
+
+extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const float *d_mask_quads, const float *d_params,
+                                  int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask,
+                                  float *d_tgt_mask, void *stream)
+{
+    MPF_REQUIRE(d_rgba && d_params && d_rgb, "mpf_warp_composite: null pointer");
+    MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_warp_composite: bad shape S=%d H=%d W=%d", S, H, W);
+    MPF_REQUIRE((int64_t)H * W < ((int64_t)1 << 29), "mpf_warp_composite: H*W too large for 32-bit texel offsets");
+    MPF_REQUIRE((d_mask_quads == nullptr) == (d_objmask == nullptr), "mpf_warp_composite: mask quads and objmask output go together");
+    MPF_REQUIRE(!interleaved || mpf_aligned16(d_rgba), "mpf_warp_composite: interleaved stack must be 16-byte aligned");
+    MPF_REQUIRE(!d_mask_quads || mpf_aligned16(d_mask_quads), "mpf_warp_composite: mask quads must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (interleaved) {
+        if (d_mask_quads) return launch_warp_composite<true, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
+        return launch_warp_composite<true, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
+    }
+    if (d_mask_quads) return launch_warp_composite<false, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
+    return launch_warp_composite<false, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
+}
+
+// mask quads ---------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_mask_quads(const float *__restrict__ m, int complement, int H, int W, float4 *__restrict__ q)
+{
+    const int64_t N = (int64_t)H * W;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int x = (int)(n % W), y = (int)(n / W);
+    const bool e = (x + 1) < W, s = (y + 1) < H;
+    float a = m[n];
+    float b = e ? m[n + 1] : 0.0f;
+    float c = s ? m[n + W] : 0.0f;
+    float d = (e && s) ? m[n + W + 1] : 0.0f;
+    if (complement) {                       // utils/utils.py:225 passes (1 - obj_mask); padding zeros stay zeros
+        a = 1.0f - a;
+        b = e ? 1.0f - b : 0.0f;
+        c = s ? 1.0f - c : 0.0f;
+        d = (e && s) ? 1.0f - d : 0.0f;
+    }
+    q[n] = make_float4(a, b, c, d);
+}
+
+extern "C" int mpf_build_mask_quads(const float *d_obj_mask, int complement, int H, int W, float *d_quads, void *stream)
+{
+    MPF_REQUIRE(d_obj_mask && d_quads && H >= 1 && W >= 1, "mpf_build_mask_quads: bad argument");
+    MPF_REQUIRE(mpf_aligned16(d_quads), "mpf_build_mask_quads: output must be 16-byte aligned");
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_mask_quads, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_obj_mask,
+                       complement, H, W, reinterpret_cast<float4 *>(d_quads));
+    return mpf_launch_status("k_mask_quads");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage A + C
+// ---------------------------------------------------------------------------------------------------------------
+
+// One thread owns PX consecutive pixels of one row and walks the S planes front to back.
+//   A: dist_s = |ray*d_{s+1} - ray*d_s|, T = exp(-sigma*dist), Tacc (double cumprod), blend rgb   (utils/utils.py:190-204)
+//   C: w = Tacc*(1-T); flow_p += w * (H_tgt_src[p][s].(x,y,1) / z - (x,y))                       (mpi_rendering.py:102-139,
+//                                                                                                 homography_sampler.py:208-218)
+template <int PX, int P, int NL>
+__global__ void __launch_bounds__(256)
+k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, const float *__restrict__ params, int S,
+                 int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
+                 float *__restrict__ out_tacc, float *__restrict__ flows)
+{
+    const int64_t N = (int64_t)H * W;
+    const int64_t n0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * PX;
+    if (n0 >= N) return;
+    const int y = (int)(n0 / W), x0 = (int)(n0 % W);     // PX divides W: the PX pixels share a row
+    constexpr int NP = (P > 0) ? P : 1;
+    constexpr int RS = MPF_PLANE_RECORD * NP;            // floats between two planes' records
+
+    float fx[PX], ray[PX][3], im[PX][3], cur[PX][3];
+    double acc[PX];
+    MpfCsum<NL> cf[PX][NP][2];
+    const float fy = (float)y;
+    const float d0 = params[MPF_PARAMS_HEADER + 9];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        fx[i] = (float)(x0 + i);
+        ray[i][0] = mpf_row3_xy1(params[0], params[1], params[2], fx[i], fy);      // mpi_rendering.py:234
+        ray[i][1] = mpf_row3_xy1(params[3], params[4], params[5], fx[i], fy);
+        ray[i][2] = mpf_row3_xy1(params[6], params[7], params[8], fx[i], fy);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            im[i][c] = img[c * N + n0 + i];
+            cur[i][c] = ray[i][c] * d0;                                             // :235-236
+        }
+        acc[i] = 1.0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { cf[i][p][0].init(); cf[i][p][1].init(); }
+    }
+
+    for (int s = 0; s < S; ++s) {
+        const float *rec = params + MPF_PARAMS_HEADER + RS * s;
+        const bool last = (s + 1 == S);
+        const float dn = last ? 0.0f : rec[RS + 9];
+        // planar loads of plane s: 4 channel rows, PX consecutive floats each
+        float ch[4][PX];
+        const float *pl = mpi + (int64_t)s * 4 * N + n0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (PX == 4) {
+                float4 v = *reinterpret_cast<const float4 *>(pl + c * N);
+                ch[c][0] = v.x; ch[c][1] = v.y; ch[c][2] = v.z; ch[c][3] = v.w;
+            } else if (PX == 2) {
+                float2 v = *reinterpret_cast<const float2 *>(pl + c * N);
+                ch[c][0] = v.x; ch[c][1] = v.y;
+            } else {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) ch[c][i] = pl[c * N + i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            float nx = ray[i][0] * dn, ny = ray[i][1] * dn, nz = ray[i][2] * dn;
+            float dist = last ? 1e3f : mpf_norm3(nx - cur[i][0], ny - cur[i][1], nz - cur[i][2]);
+            cur[i][0] = nx; cur[i][1] = ny; cur[i][2] = nz;
+            const float sg = ch[3][i];
+            float T = mpf_expf(-sg * dist);
+            float alpha = 1.0f - T;
+            float tacc = (float)acc[i];
+            float w = tacc * alpha;
+            acc[i] *= (double)(T + 1e-6f);
+            float one_m = 1.0f - tacc;
+            float o[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a = tacc * im[i][c];                 // blend_weights * src_imgs          utils/utils.py:202-204
+                float bb = one_m * ch[c][i];               // (1 - blend_weights) * mpi_rgb
+                o[c] = a + bb;
+            }
+            const int64_t n = n0 + i;
+            if (out_rgba) reinterpret_cast<float4 *>(out_rgba)[(int64_t)s * N + n] = make_float4(o[0], o[1], o[2], sg);
+            if (out_planar) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) out_planar[((int64_t)s * 3 + c) * N + n] = o[c];
+            }
+            if (out_tacc) out_tacc[(int64_t)s * N + n] = tacc;
+            if (P > 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float *h = rec + MPF_PLANE_RECORD * p;
+                    float qx = mpf_row3_xy1(h[0], h[1], h[2], fx[i], fy);
+                    float qy = mpf_row3_xy1(h[3], h[4], h[5], fx[i], fy);
+                    float qz = mpf_row3_xy1(h[6], h[7], h[8], fx[i], fy);
+                    cf[i][p][0].push(w * (qx / qz - fx[i]));
+                    cf[i][p][1].push(w * (qy / qz - fy));
+                }
+            }
+        }
+        if (P > 0 && ((s + 1) & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < PX; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { cf[i][p][0].fold(s + 1); cf[i][p][1].fold(s + 1); }
+        }
+    }
+    if (P > 0) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float f = cf[i][p][k].final();
+                    if (flow_clip > 0.0f) f = fminf(fmaxf(f, -flow_clip), flow_clip);   // utils/utils.py:348
+                    flows[((int64_t)p * 2 + k) * N + n0 + i] = f;
+                }
+    }
+}
+
+template <int PX, int P>
+static int launch_sbf(const float *mpi, const float *img, const float *params, int S, int H, int W, float clip,
+                      float *rgba, float *planar, float *tacc, float *flows, hipStream_t st)
+{
+    const int64_t N = (int64_t)H * W;
+    const int64_t threads = N / PX;
+    dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (S < 256)
+        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 2>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows);
+    else
+        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 3>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows);
+    return mpf_launch_status("k_src_blend_flow");
+}
+
+static int g_sbf_px = 0;   // 0 = auto; tuning knob for benches (mpf_tune)
+
+extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const float *d_params, int P, int S, int H, int W,
+                                  float flow_clip, float *d_out_rgba, float *d_out_rgb_planar, float *d_out_tacc,
+                                  float *d_flows, void *stream)
+{
+    MPF_REQUIRE(d_mpi && d_img && d_params, "mpf_src_blend_flow: null pointer");
+    MPF_REQUIRE(P >= 0 && P <= 2, "mpf_src_blend_flow: P must be 0, 1 or 2 (got %d)", P);
+    MPF_REQUIRE((P == 0) == (d_flows == nullptr), "mpf_src_blend_flow: flows output iff P > 0");
+    MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_src_blend_flow: bad shape S=%d H=%d W=%d", S, H, W);
+    MPF_REQUIRE(!d_out_rgba || mpf_aligned16(d_out_rgba), "mpf_src_blend_flow: rgba output must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec_ok = (W % 4 == 0) && mpf_aligned16(d_mpi) && (((int64_t)H * W) % 4 == 0);
+    int px = g_sbf_px ? g_sbf_px : 1;
+    if (px == 4 && !vec_ok) px = 1;
+#define MPF_SBF(PXv)                                                                                                     \
+    switch (P) {                                                                                                         \
+    case 0: return launch_sbf<PXv, 0>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
+    case 1: return launch_sbf<PXv, 1>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
+    default: return launch_sbf<PXv, 2>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
+    }
+    if (px == 4) { MPF_SBF(4) }
+    MPF_SBF(1)
+#undef MPF_SBF
+}
+
+extern "C" int mpf_tune(const char *key, int value)
+{
+    if (key && !strcmp(key, "sbf_px")) { g_sbf_px = value; return 0; }
+    mpf_set_error("mpf_tune: unknown key");
+    return MPF_ERR_BAD_ARGUMENT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage D and uint8 conversion
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_merge(const float *__restrict__ frame, const float *__restrict__ frame_dyn, const float *__restrict__ mask,
+        const float *__restrict__ mask_dyn, const float *__restrict__ flow, const float *__restrict__ flow_dyn,
+        const float *__restrict__ obj_mask, float th, int64_t N, float *__restrict__ flow_mix,
+        uint8_t *__restrict__ frame_mix, uint8_t *__restrict__ fill_mask)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const bool obj = obj_mask[n] >= th;                 // source-frame mask   utils/utils.py:270-271, :277-278
+    flow_mix[2 * n] = obj ? flow[n] : flow_dyn[n];
+    flow_mix[2 * n + 1] = obj ? flow[N + n] : flow_dyn[N + n];
+    const float m = mask[n], md = mask_dyn[n];
+    const bool sel = m >= th;                           // target-frame masks  :273-276
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                       // BGR order           :240-242
+        uint8_t a = (m < th) ? (uint8_t)255 : mpf_to_u8(frame[(2 - c) * N + n]);
+        uint8_t b = (md < th) ? (uint8_t)255 : mpf_to_u8(frame_dyn[(2 - c) * N + n]);
+        frame_mix[3 * n + c] = sel ? a : b;
+    }
+    const float f = sel ? 1.0f : md;                    // :280-283
+    fill_mask[n] = (f < th) ? 1 : 0;
+}
+
+extern "C" int mpf_merge(const float *d_frame, const float *d_frame_dyn, const float *d_mask, const float *d_mask_dyn,
+                         const float *d_flow, const float *d_flow_dyn, const float *d_obj_mask, float thresh, int H, int W,
+                         float *d_flow_mix, uint8_t *d_frame_mix, uint8_t *d_fill_mask, void *stream)
+{
+    MPF_REQUIRE(d_frame && d_frame_dyn && d_mask && d_mask_dyn && d_flow && d_flow_dyn && d_obj_mask && d_flow_mix &&
+                    d_frame_mix && d_fill_mask && H >= 1 && W >= 1, "mpf_merge: bad argument");
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_frame, d_frame_dyn,
+                       d_mask, d_mask_dyn, d_flow, d_flow_dyn, d_obj_mask, thresh, N, d_flow_mix, d_frame_mix, d_fill_mask);
+    return mpf_launch_status("k_merge");
+}
+
+__global__ void __launch_bounds__(256)
+k_to_u8_bgr(const float *__restrict__ img, int64_t N, uint8_t *__restrict__ out)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[3 * n + c] = mpf_to_u8(img[(2 - c) * N + n]);
+}
+
+extern "C" int mpf_to_u8_bgr(const float *d_img, int H, int W, uint8_t *d_out, void *stream)
+{
+    MPF_REQUIRE(d_img && d_out && H >= 1 && W >= 1, "mpf_to_u8_bgr: bad argument");
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_to_u8_bgr, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_img, N, d_out);
+    return mpf_launch_status("k_to_u8_bgr");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hole filling for the merged frame (row A13: the reference calls cv2.inpaint(frame_mix, fill_mask, 3, INPAINT_NS),
+// utils/utils.py:284-286 - third-party OpenCV arithmetic, parity unpinned).  This is NOT OpenCV's Navier-Stokes
+// inpainting: it is a deterministic onion-peel fill (each pass gives every hole pixel that touches a known pixel the
+// rounded mean of its known 8-neighbours), used when OpenCV is not installed.  Its inputs (frame_mix, fill_mask)
+// are pinned exactly; its output is documented as a deviation in DESIGN.md.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_fill_step(const uint8_t *__restrict__ img_in, const uint8_t *__restrict__ hole_in, int H, int W, uint8_t *__restrict__ img_out,
+            uint8_t *__restrict__ hole_out, unsigned *__restrict__ remaining)
+{
+    const int64_t N = (int64_t)H * W;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool still = false;
+    if (n < N) {
+        const int x = (int)(n % W), y = (int)(n / W);
+        if (!hole_in[n]) {
+            img_out[3 * n] = img_in[3 * n]; img_out[3 * n + 1] = img_in[3 * n + 1]; img_out[3 * n + 2] = img_in[3 * n + 2];
+            hole_out[n] = 0;
+        } else {
+            unsigned sum0 = 0, sum1 = 0, sum2 = 0, cnt = 0;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if ((dx || dy) && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        const int64_t k = (int64_t)yy * W + xx;
+                        if (!hole_in[k]) { sum0 += img_in[3 * k]; sum1 += img_in[3 * k + 1]; sum2 += img_in[3 * k + 2]; ++cnt; }
+                    }
+                }
+            if (cnt) {
+                img_out[3 * n] = (uint8_t)((sum0 + cnt / 2) / cnt);
+                img_out[3 * n + 1] = (uint8_t)((sum1 + cnt / 2) / cnt);
+                img_out[3 * n + 2] = (uint8_t)((sum2 + cnt / 2) / cnt);
+                hole_out[n] = 0;
+            } else {
+                img_out[3 * n] = img_in[3 * n]; img_out[3 * n + 1] = img_in[3 * n + 1]; img_out[3 * n + 2] = img_in[3 * n + 2];
+                hole_out[n] = 1;
+                still = true;
+            }
+        }
+    }
+    const unsigned long long b = __ballot(still);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(remaining, (unsigned)__popcll(b));
+}
+
+extern "C" int mpf_fill_holes_step(const uint8_t *d_img_in, const uint8_t *d_hole_in, int H, int W, uint8_t *d_img_out,
+                                   uint8_t *d_hole_out, unsigned *d_remaining, void *stream)
+{
+    MPF_REQUIRE(d_img_in && d_hole_in && d_img_out && d_hole_out && d_remaining && H >= 1 && W >= 1, "mpf_fill_holes_step: bad argument");
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_fill_step, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_img_in, d_hole_in, H, W,
+                       d_img_out, d_hole_out, d_remaining);
+    return mpf_launch_status("k_fill_step");
+}

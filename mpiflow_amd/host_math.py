@@ -1,0 +1,167 @@
+"""Host-side small-matrix maths of the MPI-Flow path (a few 3x3 / 4x4 matrices per image pair).
+
+These stay on the host, in torch-CPU, using the reference's *batched* expressions on purpose: the composite
+amplifies a 1-ulp change of a homography entry into >1e-4 on the rendered RGB (SURVEY.md §7 hard part 1), and the
+last ulp of `[S,3,3] @ [S,3,3]` / batched fp64 `inverse` depends on the BLAS/LAPACK kernel torch dispatches to.
+Everything per-pixel happens in the HIP kernels; what is computed here is packed into the `d_params` buffer of
+include/mpiflow_hip.h (S x 16 floats).
+"""
+import math
+
+import numpy as np
+import torch
+
+PARAMS_HEADER = 32
+PLANE_RECORD = 16
+
+
+def _cpu32(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().to(device="cpu", dtype=torch.float32)
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32)
+
+
+def plane_depths(disparity):
+    """mpi_depth_src = torch.reciprocal(disparity)   (reference utils/mpi/mpi_rendering.py:225, :284) -> [S]"""
+    return torch.reciprocal(_cpu32(disparity).reshape(-1))
+
+
+def inverse(matrices):
+    """Batched inverse with the reference's retry-on-NaN behaviour (utils/mpi/homography_sampler.py:6-27):
+    up to 5 attempts, then Exception("Matrix inverse contains nan!").  Runs on CPU like the reference's."""
+    inv = None
+    tries = 5
+    m_cpu = matrices.detach().cpu()
+    while inv is None or torch.isnan(inv).any():
+        inv = torch.inverse(m_cpu)
+        tries -= 1
+        if tries == 0:
+            break
+    if torch.isnan(inv).any():
+        raise Exception("Matrix inverse contains nan!")
+    return inv.to(matrices.device)
+
+
+def k_inverse(K):
+    """torch.inverse(k_src.double().cpu()).to(dtype)   (utils/utils.py:186-187).  K [..,3,3] -> [3,3] fp32 CPU"""
+    return torch.inverse(_cpu32(K).reshape(3, 3).to(torch.float64)).to(torch.float32)
+
+
+def homographies(G_tgt_src, K_src_inv, K_tgt, depth_S):
+    """(H_tgt_src [S,3,3], H_src_tgt [S,3,3]) fp32 CPU, built as HomographySample.sample does
+    (utils/mpi/homography_sampler.py:105-122): H_tgt_src = K_tgt (R - t n^T / -d) K_src^-1 with batched matmuls on the
+    [S,3,3] stack, H_src_tgt = one batched fp64 inverse cast back to fp32."""
+    d = _cpu32(depth_S).reshape(-1)
+    S = d.numel()
+    G = _cpu32(G_tgt_src).reshape(4, 4).unsqueeze(0).repeat(S, 1, 1)
+    Kinv = _cpu32(K_src_inv).reshape(1, 3, 3).repeat(S, 1, 1)
+    Kt = _cpu32(K_tgt).reshape(1, 3, 3).repeat(S, 1, 1)
+    R = G[:, 0:3, 0:3]
+    t = G[:, 0:3, 3]
+    n = torch.tensor([0, 0, 1], dtype=torch.float32).unsqueeze(0).repeat(S, 1)
+    d33 = d.reshape(S, 1, 1).repeat(1, 3, 3)
+    R_tnd = R - torch.matmul(t.unsqueeze(2), n.unsqueeze(1)) / -d33
+    H_ts = torch.matmul(Kt, torch.matmul(R_tnd, Kinv))
+    H_st = inverse(H_ts.to(torch.float64)).to(torch.float32)
+    return H_ts, H_st
+
+
+def pack_params(K_inv=None, G=None, homs=None, depths=None, records=None):
+    """Build the `d_params` host image (float32 CPU tensor) of include/mpiflow_hip.h.
+    homs: [R,3,3] (record r = s*P + p), depths: [R] (already repeated per record)."""
+    if records is None:
+        records = 0 if homs is None else int(homs.shape[0])
+        if homs is None and depths is not None:
+            records = int(depths.numel())
+    buf = torch.zeros(PARAMS_HEADER + PLANE_RECORD * max(records, 1), dtype=torch.float32)
+    if K_inv is not None:
+        buf[0:9] = _cpu32(K_inv).reshape(9)
+    if G is not None:
+        buf[9:21] = _cpu32(G).reshape(4, 4)[0:3, :].reshape(12)
+    if records:
+        rec = buf[PARAMS_HEADER:].view(-1, PLANE_RECORD)
+        if homs is not None:
+            rec[:records, 0:9] = _cpu32(homs).reshape(records, 9)
+        if depths is not None:
+            rec[:records, 9] = _cpu32(depths).reshape(records)
+    return buf
+
+
+# ---- poses (geometry.py:79-153, utils/utils.py:121-156) -----------------------------------------------------------
+
+def rot_from_axisangle(vec):
+    """Axis-angle [B,1,3] -> rotation [B,4,4] (geometry.py:114-153; Rodrigues with angle + 1e-7)."""
+    angle = torch.norm(vec, 2, 2, True)
+    axis = vec / (angle + 1e-7)
+    ca = torch.cos(angle)
+    sa = torch.sin(angle)
+    C = 1 - ca
+    x = axis[..., 0].unsqueeze(1)
+    y = axis[..., 1].unsqueeze(1)
+    z = axis[..., 2].unsqueeze(1)
+    xs, ys, zs = x * sa, y * sa, z * sa
+    xC, yC, zC = x * C, y * C, z * C
+    xyC, yzC, zxC = x * yC, y * zC, z * xC
+    rot = torch.zeros((vec.shape[0], 4, 4)).to(device=vec.device)
+    rot[:, 0, 0] = torch.squeeze(x * xC + ca)
+    rot[:, 0, 1] = torch.squeeze(xyC - zs)
+    rot[:, 0, 2] = torch.squeeze(zxC + ys)
+    rot[:, 1, 0] = torch.squeeze(xyC + zs)
+    rot[:, 1, 1] = torch.squeeze(y * yC + ca)
+    rot[:, 1, 2] = torch.squeeze(yzC - xs)
+    rot[:, 2, 0] = torch.squeeze(zxC - ys)
+    rot[:, 2, 1] = torch.squeeze(yzC + xs)
+    rot[:, 2, 2] = torch.squeeze(z * zC + ca)
+    rot[:, 3, 3] = 1
+    return rot
+
+
+def get_translation_matrix(translation_vector):
+    """Translation [B,3] (or [B,1,3]) -> [B,4,4] (geometry.py:98-111)."""
+    T = torch.zeros(translation_vector.shape[0], 4, 4).to(device=translation_vector.device)
+    t = translation_vector.contiguous().view(-1, 3, 1)
+    T[:, 0, 0] = 1
+    T[:, 1, 1] = 1
+    T[:, 2, 2] = 1
+    T[:, 3, 3] = 1
+    T[:, :3, 3, None] = t
+    return T
+
+
+def transformation_from_parameters(axisangle, translation, invert=False):
+    """(axisangle [B,1,3], translation [B,3]) -> 4x4: M = T.R, or R^T.T(-t) when invert (geometry.py:79-95)."""
+    R = rot_from_axisangle(axisangle)
+    t = translation.clone()
+    if invert:
+        R = R.transpose(1, 2)
+        t *= -1
+    T = get_translation_matrix(t)
+    return torch.matmul(R, T) if invert else torch.matmul(T, R)
+
+
+def generate_random_pose(ext_cz, base_motions=(0.1, 0.1, 0.1), rng=None):
+    """Random camera extrinsic (utils/utils.py:121-156).  Draw order - 3x randrange(2), 3x random(), 3x randrange(2),
+    3x random() on Python's `random` - is part of the contract (seeded runs reproduce the reference's poses).
+    `rng`: a random.Random; default = the module-level generator the reference uses.  Returns a [4,4] fp32 CPU tensor."""
+    import random as _random
+    rng = rng or _random
+    scx = (-1) ** rng.randrange(2)
+    scy = (-1) ** rng.randrange(2)
+    scz = (-1) ** rng.randrange(2)
+    if base_motions[0] == 0.1:
+        scz = -1                       # "most cameras move forward in kitti"
+    else:
+        scx, scy, scz = scx * 0.5, scy * 0.5, scz * 0.5
+    cx = (rng.random() * 0.1 + base_motions[0]) * scx
+    cy = (rng.random() * 0.1 + base_motions[1]) * scy
+    cz = (rng.random() * ext_cz + base_motions[2]) * scz
+    sax = (-1) ** rng.randrange(2)
+    say = (-1) ** rng.randrange(2)
+    saz = (-1) ** rng.randrange(2)
+    ax = (rng.random() * math.pi / 36.0) * sax
+    ay = (rng.random() * math.pi / 36.0) * say
+    az = (rng.random() * math.pi / 36.0) * saz
+    camera_ang = [ax * 0.4, ay * 0.4, az * 0.4]
+    axisangle = torch.from_numpy(np.array([[camera_ang]], dtype=np.float32)).float()
+    translation = torch.from_numpy(np.array([[[cx, cy, cz]]])).float()
+    return transformation_from_parameters(axisangle, translation)[0]

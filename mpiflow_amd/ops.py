@@ -1,0 +1,330 @@
+"""Tensor-level wrappers over the C ABI (include/mpiflow_hip.h): torch CUDA tensors in, torch CUDA tensors out.
+
+PyTorch is plumbing here (device memory, current stream); all arithmetic on tensors happens in the HIP kernels of
+libmpiflow_hip.so.  Every function launches asynchronously on torch's current stream and raises MpiFlowHipError if
+the library is missing or a launch fails - there is no eager/CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, host_math
+
+_f32 = torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=_f32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise _lib.MpiFlowHipError("%s must live on the GPU (got %s); mpiflow_amd has no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def upload_params(host_buf, device):
+    """Small per-call matrices -> device (one async H2D copy of a few KB on the current stream)."""
+    return host_buf.to(device=device, non_blocking=False)
+
+
+# ---- fused hot path ---------------------------------------------------------------------------------------------
+
+def blend_flow_params(K_inv, depth_S, homs_tgt_src=None):
+    """Host image of d_params for mpf_src_blend_flow.  homs_tgt_src: None or [P,S,3,3] (P <= 2).  -> (buf, P)"""
+    d = host_math._cpu32(depth_S).reshape(-1)
+    S = d.numel()
+    if homs_tgt_src is None:
+        return host_math.pack_params(K_inv=K_inv, depths=d), 0
+    hts = host_math._cpu32(homs_tgt_src).reshape(-1, S, 3, 3)
+    P = hts.shape[0]
+    homs = hts.permute(1, 0, 2, 3).reshape(S * P, 3, 3)               # record = s*P + p
+    return host_math.pack_params(K_inv=K_inv, homs=homs, depths=d.repeat_interleave(P)), P
+
+
+def warp_params(H_src_tgt, K_inv, G, depth_S):
+    """Host image of d_params for mpf_warp_composite."""
+    d = host_math._cpu32(depth_S).reshape(-1)
+    return host_math.pack_params(K_inv=K_inv, G=G, homs=host_math._cpu32(H_src_tgt).reshape(d.numel(), 3, 3), depths=d)
+
+
+def src_blend_flow(mpi_S4HW, img_3HW, K_inv=None, depth_S=None, homs_tgt_src=None, flow_clip=200.0,
+                   want_rgba=True, want_planar=False, want_tacc=False, out_rgba=None, out_flows=None,
+                   dparams=None, P=None):
+    """Stage A + C.  homs_tgt_src: None or [P,S,3,3] CPU (P <= 2), or pass a pre-uploaded `dparams` + P.
+    Returns dict(rgba, rgb_planar, tacc, flows)."""
+    lib = _lib.load()
+    mpi = _dev(mpi_S4HW, "mpi")
+    S, C, H, W = mpi.shape
+    assert C == 4
+    img = _dev(img_3HW, "img").reshape(3, H, W)
+    if dparams is None:
+        params, P = blend_flow_params(K_inv, depth_S, homs_tgt_src)
+        dparams = upload_params(params, mpi.device)
+    rgba = out_rgba if out_rgba is not None else (torch.empty((S, H, W, 4), dtype=_f32, device=mpi.device) if want_rgba else None)
+    planar = torch.empty((S, 3, H, W), dtype=_f32, device=mpi.device) if want_planar else None
+    tacc = torch.empty((S, H, W), dtype=_f32, device=mpi.device) if want_tacc else None
+    flows = out_flows if out_flows is not None else (torch.empty((P, 2, H, W), dtype=_f32, device=mpi.device) if P else None)
+    _lib.check(lib.mpf_src_blend_flow(_ptr(mpi), _ptr(img), _ptr(dparams), P, S, H, W, float(flow_clip), _ptr(rgba),
+                                      _ptr(planar), _ptr(tacc), _ptr(flows), _stream()), "mpf_src_blend_flow")
+    return dict(rgba=rgba, rgb_planar=planar, tacc=tacc, flows=flows)
+
+
+def mask_quads(obj_mask_HW, complement=False):
+    lib = _lib.load()
+    m = _dev(obj_mask_HW, "obj_mask")
+    H, W = m.shape[-2:]
+    m = m.reshape(H, W)
+    q = torch.empty((H, W, 4), dtype=_f32, device=m.device)
+    _lib.check(lib.mpf_build_mask_quads(_ptr(m), int(bool(complement)), H, W, _ptr(q), _stream()), "mpf_build_mask_quads")
+    return q
+
+
+def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None, interleaved=True, want_depth=True,
+                   want_tgt_mask=True, dparams=None, out=None):
+    """Stage B.  rgba [S,H,W,4] (interleaved) or [S,4,H,W]; quads from mask_quads() or None.  Either pass the small
+    matrices or a pre-uploaded `dparams`.  `out`: optional dict of preallocated outputs to reuse.
+    Returns dict(rgb [3,H,W], depth [H,W], objmask [H,W] | None, tgt_mask [H,W])."""
+    lib = _lib.load()
+    a = _dev(rgba, "rgba")
+    if interleaved:
+        S, H, W, C = a.shape
+    else:
+        S, C, H, W = a.shape
+    assert C == 4
+    if dparams is None:
+        dparams = upload_params(warp_params(H_src_tgt, K_inv, G, depth_S), a.device)
+    q = _dev(quads, "mask quads") if quads is not None else None
+    if out is not None:
+        rgb, depth, om, tm = out["rgb"], out.get("depth"), out.get("objmask"), out.get("tgt_mask")
+    else:
+        rgb = torch.empty((3, H, W), dtype=_f32, device=a.device)
+        depth = torch.empty((H, W), dtype=_f32, device=a.device) if want_depth else None
+        om = torch.empty((H, W), dtype=_f32, device=a.device) if q is not None else None
+        tm = torch.empty((H, W), dtype=_f32, device=a.device) if want_tgt_mask else None
+    _lib.check(lib.mpf_warp_composite(_ptr(a), int(bool(interleaved)), _ptr(q), _ptr(dparams), S, H, W, _ptr(rgb),
+                                      _ptr(depth), _ptr(om), _ptr(tm), _stream()), "mpf_warp_composite")
+    return dict(rgb=rgb, depth=depth, objmask=om, tgt_mask=tm)
+
+
+def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.99):
+    lib = _lib.load()
+    frame = _dev(frame, "frame")
+    _, H, W = frame.shape
+    dev = frame.device
+    flow_mix = torch.empty((H, W, 2), dtype=_f32, device=dev)
+    frame_mix = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    fill = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    args = [_dev(frame_dyn, "frame_dyn").reshape(3, H, W), _dev(mask, "mask").reshape(H, W),
+            _dev(mask_dyn, "mask_dyn").reshape(H, W), _dev(flow, "flow").reshape(2, H, W),
+            _dev(flow_dyn, "flow_dyn").reshape(2, H, W), _dev(obj_mask, "obj_mask").reshape(H, W)]
+    import numpy as np
+    _lib.check(lib.mpf_merge(_ptr(frame), *[_ptr(a) for a in args], float(np.float32(thresh)), H, W, _ptr(flow_mix),
+                             _ptr(frame_mix), _ptr(fill), _stream()), "mpf_merge")
+    return flow_mix, frame_mix, fill
+
+
+def fill_holes(img_HW3_u8, hole_HW_u8, max_passes=None):
+    """Built-in deterministic hole fill (onion peel; NOT OpenCV's algorithm - see DESIGN.md, row A13)."""
+    lib = _lib.load()
+    a = _dev(img_HW3_u8, "img", torch.uint8).clone()
+    ha = _dev(hole_HW_u8, "hole", torch.uint8).clone()
+    H, W, _ = a.shape
+    b, hb = torch.empty_like(a), torch.empty_like(ha)
+    rem = torch.zeros(1, dtype=torch.int32, device=a.device)
+    max_passes = max_passes or (H + W)
+    for it in range(max_passes):
+        rem.zero_()
+        _lib.check(lib.mpf_fill_holes_step(_ptr(a), _ptr(ha), H, W, _ptr(b), _ptr(hb), _ptr(rem), _stream()), "mpf_fill_holes_step")
+        a, b, ha, hb = b, a, hb, ha
+        if it % 4 == 3 and int(rem.item()) == 0:
+            break
+    return a
+
+
+def to_u8_bgr(img_3HW):
+    lib = _lib.load()
+    img = _dev(img_3HW, "img")
+    _, H, W = img.shape
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=img.device)
+    _lib.check(lib.mpf_to_u8_bgr(_ptr(img), H, W, _ptr(out), _stream()), "mpf_to_u8_bgr")
+    return out
+
+
+# ---- generic ops ----------------------------------------------------------------------------------------------------
+
+def src_xyz(K_inv, depth_S, H, W, device):
+    lib = _lib.load()
+    d = host_math._cpu32(depth_S).reshape(-1)
+    S = d.numel()
+    dparams = upload_params(host_math.pack_params(K_inv=K_inv, depths=d), device)
+    out = torch.empty((S, 3, H, W), dtype=_f32, device=device)
+    _lib.check(lib.mpf_src_xyz(_ptr(dparams), S, H, W, _ptr(out), _stream()), "mpf_src_xyz")
+    return out
+
+
+def transform_xyz(G, xyz_S3N):
+    lib = _lib.load()
+    xyz = _dev(xyz_S3N, "xyz")
+    S = xyz.shape[0]
+    N = xyz[0, 0].numel()
+    dparams = upload_params(host_math.pack_params(G=G, records=1), xyz.device)
+    out = torch.empty_like(xyz)
+    _lib.check(lib.mpf_transform_xyz(_ptr(dparams), _ptr(xyz), S, N, _ptr(out), _stream()), "mpf_transform_xyz")
+    return out
+
+
+def homography_sample(src_SCHW, H_src_tgt, want_flow=True):
+    lib = _lib.load()
+    src = _dev(src_SCHW, "src")
+    S, C, H, W = src.shape
+    dparams = upload_params(host_math.pack_params(homs=host_math._cpu32(H_src_tgt).reshape(S, 3, 3)), src.device)
+    tgt = torch.empty_like(src)
+    valid = torch.empty((S, H, W), dtype=torch.uint8, device=src.device)
+    flow = torch.empty((S, H, W, 2), dtype=_f32, device=src.device) if want_flow else None
+    _lib.check(lib.mpf_homography_sample(_ptr(src), _ptr(dparams), S, C, H, W, _ptr(tgt), _ptr(valid), _ptr(flow), _stream()),
+               "mpf_homography_sample")
+    return tgt, valid.to(torch.bool), flow
+
+
+def homography_flow(H_tgt_src, H, W, device):
+    lib = _lib.load()
+    hts = host_math._cpu32(H_tgt_src).reshape(-1, 3, 3)
+    S = hts.shape[0]
+    dparams = upload_params(host_math.pack_params(homs=hts), device)
+    flow = torch.empty((S, H, W, 2), dtype=_f32, device=device)
+    _lib.check(lib.mpf_homography_flow(_ptr(dparams), S, H, W, _ptr(flow), _stream()), "mpf_homography_flow")
+    return flow
+
+
+def volume_render(rgb_S3N, sigma_SN, xyz_S3N, extra_SEN=None, hard=False, want_tacc=True, want_weights=True):
+    """Generic plane_volume_rendering on materialised tensors.  Trailing dims are flattened to N."""
+    lib = _lib.load()
+    xyz = _dev(xyz_S3N, "xyz")
+    S = xyz.shape[0]
+    tail = tuple(xyz.shape[2:])
+    N = xyz[0, 0].numel()
+    sigma = _dev(sigma_SN, "sigma")
+    rgb = _dev(rgb_S3N, "rgb") if rgb_S3N is not None else None
+    extra = _dev(extra_SEN, "extra") if extra_SEN is not None else None
+    E = 0 if extra is None else extra.shape[1]
+    dev = xyz.device
+    out = dict(rgb=torch.empty((3,) + tail, dtype=_f32, device=dev) if rgb is not None else None,
+               depth=torch.empty(tail, dtype=_f32, device=dev),
+               tacc=torch.empty((S,) + tail, dtype=_f32, device=dev) if want_tacc else None,
+               weights=torch.empty((S,) + tail, dtype=_f32, device=dev) if want_weights else None,
+               extra=torch.empty((E,) + tail, dtype=_f32, device=dev) if E else None)
+    _lib.check(lib.mpf_volume_render(_ptr(rgb), _ptr(sigma), _ptr(xyz), S, N, _ptr(out["rgb"]), _ptr(out["depth"]),
+                                     _ptr(out["tacc"]), _ptr(out["weights"]), _ptr(extra), E, _ptr(out["extra"]),
+                                     int(bool(hard)), _stream()), "mpf_volume_render")
+    return out
+
+
+def weighted_sum(weights_SN, values_SCN=None):
+    """cascade-sum over S of weights (* values).  weights [S,*tail], values [S,C,*tail] -> [C,*tail] ([1,*tail] if None)"""
+    lib = _lib.load()
+    w = _dev(weights_SN, "weights")
+    S = w.shape[0]
+    tail = tuple(w.shape[1:])
+    N = w[0].numel()
+    v = _dev(values_SCN, "values") if values_SCN is not None else None
+    C = v.shape[1] if v is not None else 1
+    out = torch.empty((C,) + tail, dtype=_f32, device=w.device)
+    _lib.check(lib.mpf_weighted_sum(_ptr(w), _ptr(v), S, C, N, _ptr(out), _stream()), "mpf_weighted_sum")
+    return out
+
+
+# ---- depth -> flow, forward warp -----------------------------------------------------------------------------------
+
+def disp_to_depth(disp):
+    lib = _lib.load()
+    d = _dev(disp, "disp")
+    out = torch.empty_like(d)
+    _lib.check(lib.mpf_disp_to_depth(_ptr(d), d.numel(), _ptr(out), _stream()), "mpf_disp_to_depth")
+    return out
+
+
+def backproject_project(depth_HW, inv_K33, P34):
+    lib = _lib.load()
+    depth = _dev(depth_HW, "depth")
+    H, W = depth.shape[-2:]
+    depth = depth.reshape(H, W)
+    ik = host_math._cpu32(inv_K33).reshape(9).contiguous()
+    P = host_math._cpu32(P34).reshape(12).contiguous()
+    pix = torch.empty((H, W, 2), dtype=_f32, device=depth.device)
+    z = torch.empty((H, W), dtype=_f32, device=depth.device)
+    _lib.check(lib.mpf_backproject_project(_ptr(depth), ctypes.c_void_p(ik.data_ptr()), ctypes.c_void_p(P.data_ptr()), H, W,
+                                           _ptr(pix), _ptr(z), _stream()), "mpf_backproject_project")
+    return pix, z
+
+
+def backproject(depth_HW, inv_K33):
+    """BackprojectDepth.forward -> [4, H*W] camera points (rows X, Y, Z, 1)"""
+    lib = _lib.load()
+    depth = _dev(depth_HW, "depth")
+    H, W = depth.shape[-2:]
+    ik = host_math._cpu32(inv_K33).reshape(9).contiguous()
+    cam = torch.empty((4, H * W), dtype=_f32, device=depth.device)
+    _lib.check(lib.mpf_backproject(_ptr(depth.reshape(H, W)), ctypes.c_void_p(ik.data_ptr()), H, W, _ptr(cam), _stream()), "mpf_backproject")
+    return cam
+
+
+def project3d(points_4N, P34, H, W, eps=1e-7):
+    """Project3D.forward on homogeneous points [4, H*W] -> (pix [H,W,2] normalised, z [H*W])"""
+    lib = _lib.load()
+    pts = _dev(points_4N, "points").reshape(4, H * W)
+    P = host_math._cpu32(P34).reshape(12).contiguous()
+    pix = torch.empty((H, W, 2), dtype=_f32, device=pts.device)
+    z = torch.empty((H * W,), dtype=_f32, device=pts.device)
+    _lib.check(lib.mpf_project3d(_ptr(pts), ctypes.c_void_p(P.data_ptr()), float(eps), H, W, _ptr(pix), _ptr(z), _stream()), "mpf_project3d")
+    return pix, z
+
+
+def select_truncate(p_static, z_static, p_obj, z_obj, inst_HW):
+    lib = _lib.load()
+    inst = _dev(inst_HW, "instance mask")
+    H, W = inst.shape[-2:]
+    dev = inst.device
+    p1 = torch.empty((H, W, 2), dtype=_f32, device=dev)
+    z1 = torch.empty((H, W), dtype=_f32, device=dev)
+    sx = torch.empty((H, W), dtype=torch.int64, device=dev)
+    sy = torch.empty((H, W), dtype=torch.int64, device=dev)
+    fl = torch.empty((H, W, 2), dtype=_f32, device=dev)
+    _lib.check(lib.mpf_select_truncate(_ptr(_dev(p_static, "p_static")), _ptr(_dev(z_static, "z_static")),
+                                       _ptr(_dev(p_obj, "p_obj")), _ptr(_dev(z_obj, "z_obj")), _ptr(inst.reshape(H, W)), H, W,
+                                       _ptr(p1), _ptr(z1), _ptr(sx), _ptr(sy), _ptr(fl), _stream()), "mpf_select_truncate")
+    return p1, z1, sx, sy, fl
+
+
+def forward_warp(src_u8, idx_i64, idy_i64, z_f32, h, w):
+    """Device-resident forward splat, byte-identical to the reference's serial C.  -> warped u8 [h,w,5]"""
+    lib = _lib.load()
+    src = _dev(src_u8, "src", torch.uint8).reshape(-1)
+    idx = _dev(idx_i64, "idx", torch.int64).reshape(-1)
+    idy = _dev(idy_i64, "idy", torch.int64).reshape(-1)
+    z = _dev(z_f32, "z").reshape(-1)
+    assert src.numel() == h * w * 3 and idx.numel() == h * w and idy.numel() == h * w and z.numel() == h * w
+    ws_bytes = lib.mpf_forward_warp_workspace(h, w)
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=src.device)
+    off = (-ws.data_ptr()) % 256
+    warped = torch.empty((h, w, 5), dtype=torch.uint8, device=src.device)
+    _lib.check(lib.mpf_forward_warp(_ptr(src), _ptr(idx), _ptr(idy), _ptr(z), _ptr(warped), h, w,
+                                    ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, _stream()), "mpf_forward_warp")
+    return warped
+
+
+def warp_masks(warped_HW5):
+    lib = _lib.load()
+    w5 = _dev(warped_HW5, "warped", torch.uint8)
+    H, W, _ = w5.shape
+    outs = [torch.empty((H, W), dtype=torch.uint8, device=w5.device) for _ in range(5)]
+    _lib.check(lib.mpf_warp_masks(_ptr(w5), H, W, *[_ptr(o) for o in outs], _stream()), "mpf_warp_masks")
+    return dict(zip(["H", "M", "M'", "P", "H'"], outs))

@@ -1,0 +1,135 @@
+"""Fused per-image pipeline on one GPU + image-sharded multi-GPU driver.
+
+`PairRenderer` is the fast path behind `utils.utils.render_3dphoto_dynamic`:
+
+    Stage A+C  mpf_src_blend_flow   planar [S,4,H,W] stack + image -> interleaved blended RGBA stack + 1-2 flows
+    Stage B    mpf_warp_composite   x1 (camera-only) or x2 (object + background poses)
+    Stage D    mpf_merge            threshold / select / uint8 BGR / fill mask
+
+All buffers are allocated once per (S,H,W) and reused; per pair only ~10 KB of small matrices are uploaded.  With
+288 GB of HBM per MI355X a rank can keep hundreds of 629 MB plane stacks resident, so the driver batches images
+per rank and never exchanges tensor data between GPUs: images are independent (reference loop
+gen_3dphoto_dynamic_v2.py:78-122), the only collective is one all-reduce of a ~10-float statistics vector per batch.
+"""
+import random
+
+import numpy as np
+import torch
+
+from . import host_math, ops
+
+MASK_THRESH = 0.99
+
+
+class PairRenderer:
+    """Preallocated fused renderer for one (S, H, W) on one device."""
+
+    def __init__(self, S, H, W, device, n_views=2):
+        self.S, self.H, self.W, self.device = S, H, W, torch.device(device)
+        f32 = torch.float32
+        dev = self.device
+        self.rgba = torch.empty((S, H, W, 4), dtype=f32, device=dev)             # blended interleaved stack
+        self.flows = torch.empty((n_views, 2, H, W), dtype=f32, device=dev)
+        self.views = [dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), depth=torch.empty((H, W), dtype=f32, device=dev),
+                           objmask=torch.empty((H, W), dtype=f32, device=dev), tgt_mask=torch.empty((H, W), dtype=f32, device=dev))
+                      for _ in range(n_views)]
+        self.n_views = n_views
+
+    # -- host side: small matrices ---------------------------------------------------------------------------------
+    def prepare(self, K, disparity, poses):
+        """poses: list of 4x4 G_tgt_src (1 or 2).  Computes K^-1, plane depths, per-plane homographies on the host
+        (torch-CPU, reference expressions) and uploads them.  Returns a dict handed to run()."""
+        k_inv = host_math.k_inverse(K)
+        d = host_math.plane_depths(disparity)
+        hts, wp = [], []
+        for G in poses:
+            H_ts, H_st = host_math.homographies(G, k_inv, K, d)
+            hts.append(H_ts)
+            wp.append(ops.upload_params(ops.warp_params(H_st, k_inv, G, d), self.device))
+        bf, P = ops.blend_flow_params(k_inv, d, torch.stack(hts))
+        return dict(P=P, blend=ops.upload_params(bf, self.device), warp=wp)
+
+    # -- device side: launches only ------------------------------------------------------------------------------------
+    def run(self, mpi, image, prep, quads):
+        """mpi [S,4,H,W], image [3,H,W] on device; quads: list (per view) of mask-quad tensors or None.
+        Launches A+C then one B per view; returns (flows [P,2,H,W], views)."""
+        ops.src_blend_flow(mpi, image, out_rgba=self.rgba, out_flows=self.flows[: prep["P"]], dparams=prep["blend"], P=prep["P"])
+        for v in range(prep["P"]):
+            q = quads[v] if quads is not None else None
+            out = self.views[v] if q is not None else dict(rgb=self.views[v]["rgb"], depth=self.views[v]["depth"],
+                                                           tgt_mask=self.views[v]["tgt_mask"])
+            ops.warp_composite(self.rgba, q, dparams=prep["warp"][v], out=out)
+        return self.flows, self.views
+
+
+def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, thresh=MASK_THRESH, renderer=None):
+    """Everything render_3dphoto_dynamic does up to the inputs of cv2.inpaint (reference utils/utils.py:159-283), for
+    explicit poses: G_cam renders with obj_mask, G_dyn with 1 - obj_mask (sic - SURVEY §3.2).  Device tensors in/out."""
+    mpi = mpi_S4HW
+    S, _, H, W = mpi.shape
+    r = renderer or PairRenderer(S, H, W, mpi.device)
+    om = obj_mask_HW.reshape(H, W).to(torch.float32)
+    prep = r.prepare(K, disparity_S, [G_cam, G_dyn])
+    quads = [ops.mask_quads(om, False), ops.mask_quads(om, True)]
+    flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, quads)
+    flow_mix, frame_mix, fill = ops.merge(views[0]["rgb"], views[1]["rgb"], views[0]["objmask"], views[1]["objmask"],
+                                          flows[0], flows[1], om, thresh)
+    return dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill, src_np=ops.to_u8_bgr(image_3HW.reshape(3, H, W)),
+                view_cam=views[0], view_dyn=views[1], flows=flows, rgba=r.rgba)
+
+
+# ---- multi-GPU: image sharding + end-of-batch statistics ------------------------------------------------------------
+
+def shard_indices(n_items, rank, world_size):
+    """Images i with i % world_size == rank; every image is owned by exactly one rank."""
+    return list(range(rank, n_items, world_size))
+
+
+def pose_schedule(seed, n_pairs, ext_cz):
+    """Replay of the reference's global RNG stream (gen_3dphoto_dynamic_v2.py:38-39 seeds once; every pair then draws a
+    dynamic pose and a camera pose, utils/utils.py:207-208).  Every rank replays the whole schedule and indexes it by
+    global pair id, so an N-GPU run produces the same poses as a 1-GPU run."""
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n_pairs):
+        dyn = host_math.generate_random_pose(ext_cz, rng=rng)
+        cam = host_math.generate_random_pose(ext_cz, base_motions=(0, 0, 0), rng=rng)
+        out.append((cam, dyn))
+    return out
+
+
+STAT_NAMES = ["pairs", "sum_flow_mag", "hole_px", "kernel_seconds", "max_flow_mag", "wall_seconds", "neg_min_flow"]
+_N_SUM = 4   # first 4 are SUM-reduced, the rest MAX-reduced
+
+
+def reduce_stats(stats, group=None):
+    """One all-reduce pair (SUM part, MAX part) on a 7-float vector: RCCL over xGMI when the process group's backend is
+    "nccl", gloo on CPU.  No tensor data ever crosses GPUs."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return stats
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    v = torch.tensor([float(stats[k]) for k in STAT_NAMES], dtype=torch.float64, device=dev)
+    s, m = v[:_N_SUM].clone(), v[_N_SUM:].clone()
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    out = torch.cat([s, m]).cpu().tolist()
+    return dict(zip(STAT_NAMES, out))
+
+
+def pair_stats(flow_mix, fill_mask):
+    mag = torch.linalg.vector_norm(flow_mix.reshape(-1, 2), dim=1)
+    return dict(pairs=1, sum_flow_mag=float(mag.sum()), hole_px=float(fill_mask.sum()), kernel_seconds=0.0,
+                max_flow_mag=float(mag.max()), wall_seconds=0.0, neg_min_flow=float(-flow_mix.min()))
+
+
+def merge_stats(a, b):
+    out = {}
+    for i, k in enumerate(STAT_NAMES):
+        out[k] = (a[k] + b[k]) if i < _N_SUM else max(a[k], b[k])
+    return out
+
+
+def empty_stats():
+    return dict(pairs=0, sum_flow_mag=0.0, hole_px=0.0, kernel_seconds=0.0, max_flow_mag=0.0, wall_seconds=0.0,
+                neg_min_flow=-float("inf"))

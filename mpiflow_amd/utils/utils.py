@@ -1,0 +1,124 @@
+"""Drop-in for the reference's per-image pipeline module utils/utils.py (render_3dphoto_dynamic,
+render_novel_view_dynamic, generate_random_pose, gen_swing_path, image/disparity loaders) on MI355X.
+
+Same positional signatures and return values as the reference; tensors live on the GPU; arithmetic runs in the fused
+HIP kernels of libmpiflow_hip.so (mpiflow_amd.pipeline).  Inputs of any float dtype are promoted to fp32 - the
+parity target is the reference's fp32 CPU path.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import host_math, ops, pipeline
+from ..geometry import transformation_from_parameters  # noqa: F401
+from .mpi import mpi_rendering  # noqa: F401
+from .mpi.homography_sampler import HomographySample  # noqa: F401
+
+
+def image_to_tensor(img_path, unsqueeze=True):
+    """RGB image file -> [1,3,h,w] float in [0,1]   (reference utils/utils.py:35-39; torchvision's ToTensor = /255)"""
+    from PIL import Image
+    rgb = torch.from_numpy(np.asarray(Image.open(img_path).convert("RGB")).copy()).permute(2, 0, 1).float().div(255)
+    return rgb.unsqueeze(0) if unsqueeze else rgb
+
+
+def disparity_to_tensor(disp_path, unsqueeze=True):
+    """grey-scale disparity file -> [1,1,h,w] float in [0,1]   (reference :42-52; cv2.imread(path, 0) / 255)"""
+    from PIL import Image
+    disp = np.asarray(Image.open(disp_path).convert("L")).astype(np.float64) / 255
+    disp = torch.from_numpy(disp)[None, ...]
+    if unsqueeze:
+        disp = disp.unsqueeze(0)
+    return disp.float()
+
+
+def gen_swing_path(num_frames=90, r_x=0.14, r_y=0.0, r_z=0.10):
+    """List of [4,4] poses on a swing path (reference :55-62)."""
+    t = torch.arange(num_frames) / (num_frames - 1)
+    poses = torch.eye(4).repeat(num_frames, 1, 1)
+    poses[:, 0, 3] = r_x * torch.sin(2.0 * math.pi * t)
+    poses[:, 1, 3] = r_y * torch.cos(2.0 * math.pi * t)
+    poses[:, 2, 3] = r_z * (torch.cos(2.0 * math.pi * t) - 1.0)
+    return poses.unbind()
+
+
+def generate_random_pose(ext_cz, base_motions=[0.1, 0.1, 0.1]):
+    """Random camera extrinsic from Python's global `random` stream (reference :121-156) -> [4,4] tensor (CPU; the
+    pose only ever feeds host-side 3x3 algebra)."""
+    return host_math.generate_random_pose(ext_cz, base_motions=base_motions)
+
+
+def _inpaint(frame_mix_dev, fill_mask_dev, method):
+    """Row A13.  'cv2' = the reference's own call (third-party; used when OpenCV is installed), 'hip' = built-in
+    onion-peel fill (documented deviation), 'none' = leave holes white."""
+    if method == "auto":
+        try:
+            import cv2  # noqa: F401
+            method = "cv2"
+        except Exception:
+            method = "hip"
+    if method == "cv2":
+        import cv2
+        return cv2.inpaint(frame_mix_dev.cpu().numpy(), fill_mask_dev.cpu().numpy().astype(np.uint8), 3, cv2.INPAINT_NS)
+    if method == "hip":
+        return ops.fill_holes(frame_mix_dev, fill_mask_dev).cpu().numpy()
+    return frame_mix_dev.cpu().numpy()
+
+
+def render_3dphoto_dynamic(opt, src_imgs, obj_mask, disp, mpi_all_src, disparity_all_src, k_src, k_tgt, data_path=None,
+                           name=None, hard_flow=False, mask_thresh=0.99, inpaint="auto", return_intermediates=False):
+    """One training pair from one MPI (reference utils/utils.py:159-288).
+
+    Draws the dynamic pose then the camera pose from `random` (same order as the reference), blends the source image
+    into the planes, renders the object layer with the camera pose and the background layer with the dynamic pose
+    (sic), merges by the rendered masks and fills the holes.
+    :return: (flow_mix [H,W,2] float32, src_np [H,W,3] uint8 BGR, inpainted [H,W,3] uint8 BGR, None) as numpy arrays
+    """
+    name = name.split(".")[0]
+    if hard_flow:
+        raise NotImplementedError("hard_flow=True is only available through utils.mpi.mpi_rendering (generic path)")
+    dev = mpi_all_src.device
+    S = mpi_all_src.shape[1]
+    h, w = mpi_all_src.shape[-2:]
+    cam_ext_dynamic = generate_random_pose(opt.ext_cz)
+    cam_ext = generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0])
+    out = pipeline.render_pair(src_imgs[0].to(dev, torch.float32), obj_mask.reshape(h, w).to(dev, torch.float32),
+                               mpi_all_src[0].to(torch.float32), disparity_all_src[0], k_src, cam_ext, cam_ext_dynamic,
+                               thresh=mask_thresh)
+    inpainted = _inpaint(out["frame_mix"], out["fill_mask"], inpaint)
+    flow_mix = out["flow_mix"].cpu().numpy()
+    src_np = out["src_np"].cpu().numpy()
+    if return_intermediates:
+        return flow_mix, src_np, inpainted, None, out
+    return flow_mix, src_np, inpainted, None
+
+
+def render_novel_view_dynamic(obj_mask, mpi_all_rgb_src, mpi_all_sigma_src, disparity_all_src, G_tgt_src, K_src_inv, K_tgt,
+                              K_src, src_pose, homography_sampler, hard_flow=False):
+    """One posed view of an already-blended MPI (reference utils/utils.py:291-349).
+    :return: (tgt_imgs_syn [1,3,H,W], tgt_depth_syn [1,1,H,W], flow_syn [1,2,H,W] clipped to +-200, obj_mask [1,1,H,W])
+
+    Fused path: planar rgb/sigma are consumed in place (no repack), xyz channels are evaluated analytically, the flow
+    comes from the source-frame weights of the same stack."""
+    B, S = disparity_all_src.size()
+    assert B == 1, "the reference's entry point is batch-1 (utils/utils.py:314 indexes [0])"
+    H, W = mpi_all_rgb_src.shape[-2:]
+    dev = mpi_all_rgb_src.device
+    d = host_math.plane_depths(disparity_all_src[0])
+    H_ts, H_st = host_math.homographies(G_tgt_src, K_src_inv, K_tgt, d)
+    planar = torch.cat((mpi_all_rgb_src[0].to(torch.float32), mpi_all_sigma_src[0].to(torch.float32)), dim=1).contiguous()
+    quads = ops.mask_quads(obj_mask.reshape(H, W).to(dev, torch.float32), False)
+    v = ops.warp_composite(planar, quads, H_st, K_src_inv, G_tgt_src, d, interleaved=False)
+    if hard_flow:
+        hs = homography_sampler or HomographySample(H, W, dev)
+        xyz_src = mpi_rendering.get_src_xyz_from_plane_disparity(hs.meshgrid, disparity_all_src, K_src_inv)
+        flow_s = ops.homography_flow(H_ts, H, W, dev).permute(0, 3, 1, 2).unsqueeze(0)
+        flow = mpi_rendering.plane_volume_rendering_flow(mpi_all_sigma_src.to(torch.float32), flow_s, xyz_src, False, hard_flow=True)
+        flow = torch.clip(flow, -200, 200)
+    else:
+        # source-frame weights: Stage A+C kernel without the blend outputs (flow only)
+        zeros = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+        a = ops.src_blend_flow(planar, zeros, K_src_inv, d, H_ts.unsqueeze(0), flow_clip=200.0, want_rgba=False)
+        flow = a["flows"][0:1]
+    return v["rgb"].unsqueeze(0), v["depth"].reshape(1, 1, H, W), flow.reshape(1, 2, H, W), v["objmask"].reshape(1, 1, H, W)

@@ -1,0 +1,112 @@
+"""CPU-only tests of the host logic: small-matrix maths vs goldens from the reference, parameter packing, the pose
+schedule replay, image sharding and the world_size-2 statistics all-reduce (gloo)."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["tiny_white", "tiny_smooth"])
+def test_host_matrices_match_reference(name):
+    from mpiflow_amd import host_math
+    g = load_golden(name)
+    k_inv = host_math.k_inverse(g["K"])
+    assert bits_equal(k_inv.numpy(), g["k_inv"]) == 0
+    d = host_math.plane_depths(g["disparity"])
+    assert bits_equal(d.numpy(), g["depth_S"]) == 0
+    H_ts, H_st = host_math.homographies(g["G_cam"], k_inv, g["K"], d)
+    assert bits_equal(H_ts.numpy(), g["H_tgt_src_cam"]) == 0
+    assert bits_equal(H_st.numpy(), g["H_src_tgt_cam"]) == 0
+
+
+def test_pose_schedule_matches_reference_rng_stream():
+    from mpiflow_amd import pipeline
+    g = load_golden("pose_schedule")
+    sched = pipeline.pose_schedule(int(g["seed"]), g["G_dyn"].shape[0], float(g["ext_cz"]))
+    for i, (cam, dyn) in enumerate(sched):
+        assert bits_equal(dyn.numpy(), g["G_dyn"][i]) == 0
+        assert bits_equal(cam.numpy(), g["G_cam"][i]) == 0
+    # and through the module-level `random`, as the reference's entry point uses it
+    from mpiflow_amd.utils import utils as U
+    random.seed(int(g["seed"]))
+    assert bits_equal(U.generate_random_pose(float(g["ext_cz"])).numpy(), g["G_dyn"][0]) == 0
+    assert bits_equal(U.generate_random_pose(float(g["ext_cz"]), base_motions=[0, 0, 0]).numpy(), g["G_cam"][0]) == 0
+
+
+def test_geometry_pose_algebra_matches_reference():
+    from mpiflow_amd import geometry
+    g = load_golden("geometry")
+    M = geometry.transformation_from_parameters(torch.from_numpy(g["axisangle"]), torch.from_numpy(g["translation"]))
+    Mi = geometry.transformation_from_parameters(torch.from_numpy(g["axisangle"]), torch.from_numpy(g["translation"]), invert=True)
+    assert bits_equal(M.numpy(), g["M"]) == 0 and bits_equal(Mi.numpy(), g["M_inv"]) == 0
+
+
+def test_inverse_raises_like_the_reference():
+    from mpiflow_amd.utils.mpi.homography_sampler import inverse
+    with pytest.raises(Exception, match="Matrix inverse contains nan!"):
+        inverse(torch.full((2, 3, 3), float("nan"), dtype=torch.float64))
+
+
+def test_param_packing_layout():
+    from mpiflow_amd import host_math, ops
+    S = 5
+    k_inv = torch.arange(9, dtype=torch.float32).reshape(3, 3)
+    G = torch.arange(16, dtype=torch.float32).reshape(4, 4) + 100
+    homs = torch.arange(S * 9, dtype=torch.float32).reshape(S, 3, 3) + 1000
+    d = torch.arange(S, dtype=torch.float32) + 0.5
+    buf = ops.warp_params(homs, k_inv, G, d)
+    assert buf.numel() == 32 + 16 * S
+    assert torch.equal(buf[0:9], k_inv.reshape(9)) and torch.equal(buf[9:21], G[:3].reshape(12)) and float(buf[21:32].abs().sum()) == 0
+    rec = buf[32:].view(S, 16)
+    assert torch.equal(rec[:, :9], homs.reshape(S, 9)) and torch.equal(rec[:, 9], d) and float(rec[:, 10:].abs().sum()) == 0
+    two = torch.stack([homs, homs + 5000])
+    buf2, P = ops.blend_flow_params(k_inv, d, two)
+    assert P == 2 and buf2.numel() == 32 + 16 * S * 2
+    rec2 = buf2[32:].view(S, 2, 16)
+    assert torch.equal(rec2[:, 0, :9], homs.reshape(S, 9)) and torch.equal(rec2[:, 1, :9], (homs + 5000).reshape(S, 9))
+    assert torch.equal(rec2[:, 0, 9], d) and torch.equal(rec2[:, 1, 9], d)
+
+
+def test_sharding_partitions_images():
+    from mpiflow_amd import pipeline
+    for n, w in [(512, 8), (7, 2), (3, 8), (0, 4)]:
+        seen = sorted(i for r in range(w) for i in pipeline.shard_indices(n, r, w))
+        assert seen == list(range(n))
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mpiflow_amd import pipeline
+dist.init_process_group(backend="gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+mine = pipeline.shard_indices(11, r, w)
+st = pipeline.empty_stats()
+for i in mine:
+    st = pipeline.merge_stats(st, dict(pairs=1, sum_flow_mag=float(i), hole_px=2.0 * i, kernel_seconds=0.5, max_flow_mag=float(i),
+                                      wall_seconds=1.0 + r, neg_min_flow=-float(i)))
+tot = pipeline.reduce_stats(st)
+if r == 0:
+    print("RESULT", tot["pairs"], tot["sum_flow_mag"], tot["hole_px"], tot["max_flow_mag"], tot["wall_seconds"], tot["neg_min_flow"])
+dist.destroy_process_group()
+'''
+
+
+def test_stats_all_reduce_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    pairs, sflow, holes, mx, wall, negmin = map(float, line[1:])
+    assert pairs == 11 and sflow == sum(range(11)) and holes == 2 * sum(range(11)) and mx == 10 and wall == 2.0 and negmin == 0.0

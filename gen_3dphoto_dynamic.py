@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""gen_3dphoto_dynamic.py - optical-flow training-pair generation from single images on MI355X.
+
+Drop-in for the reference's entry point (gen_3dphoto_dynamic_v2.py; the README and scripts call it
+gen_3dphoto_dynamic.py): same flags (--width --height --seed --ext_cz --ckpt_path --repeat --base --out), same input
+layout (base/{images,disps,masks}), same outputs (out/{src_images,dst_images}/NAME_r.png, out/flows/NAME_r.flo), same
+RNG draw order (np.random for the instance id, `random` for the two poses of every pair) - so a seeded run draws the
+reference's instance ids and poses.
+
+What is different:
+  * the render/flow path runs in the HIP kernels of mpiflow_amd (fp32);
+  * images are sharded over ranks when launched under torchrun (rank r takes images i = r mod world); every rank
+    replays the whole RNG schedule, so an N-GPU run produces exactly the files of a 1-GPU run; one all-reduce of a
+    7-float statistics vector (RCCL over xGMI) closes the batch;
+  * the MPI producer: the AdaMPI network (reference model/) is outside this build and its weights
+    are not in the reference tree.  `--mpi-from npz` reads precomputed stacks from base/mpis/NAME.npz
+    (arrays `mpi` [S,4,H,W], `disparity` [S]); `--mpi-from disparity` (default) builds a hard-assignment MPI from the
+    monocular disparity map: every plane carries the image colours, the plane nearest to the pixel's disparity is
+    opaque.  Both feed the identical render path.
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mpiflow_amd import host_math, io_formats, pipeline, synth  # noqa: E402
+from mpiflow_amd.utils import utils as U  # noqa: E402
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--width", type=int, default=1280)
+    p.add_argument("--height", type=int, default=384)
+    p.add_argument("--seed", type=int, default=114514)
+    p.add_argument("--ext_cz", type=float, default=0.15)
+    p.add_argument("--ckpt_path", type=str, default="adampiweight/adampi_64p.pth", help="accepted for CLI parity; unused")
+    p.add_argument("--repeat", type=int, default=5)
+    p.add_argument("--base", type=str, required=True)
+    p.add_argument("--out", type=str, required=True)
+    p.add_argument("--planes", type=int, default=64)
+    p.add_argument("--mpi-from", choices=["disparity", "npz"], default="disparity")
+    p.add_argument("--inpaint", choices=["auto", "cv2", "hip", "none"], default="auto")
+    opt, _ = p.parse_known_args(argv)
+    return opt
+
+
+def mpi_from_disparity(image_3HW, disp_HW, S):
+    """Stand-in MPI producer: colours on every plane, sigma = 1e-4 except 50 on the plane nearest to the pixel's
+    disparity (a hard depth assignment).  Returns (mpi [S,4,H,W], disparity [S])."""
+    planes = torch.from_numpy(synth.plane_disparities(S)).to(disp_HW.device)
+    idx = (disp_HW.unsqueeze(0) - planes.view(S, 1, 1)).abs().argmin(0)
+    sigma = torch.full((S,) + tuple(disp_HW.shape), 1e-4, dtype=torch.float32, device=disp_HW.device)
+    sigma.scatter_(0, idx.unsqueeze(0), 50.0)
+    mpi = torch.cat([image_3HW.unsqueeze(0).expand(S, -1, -1, -1), sigma.unsqueeze(1)], dim=1).contiguous()
+    return mpi, planes
+
+
+def main(argv=None):
+    opt = parse(argv)
+    print(opt)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    random.seed(opt.seed)                         # gen_3dphoto_dynamic_v2.py:38-39
+    np.random.seed(opt.seed)
+    K = torch.tensor([[0.58, 0, 0.5], [0, 0.58, 0.5], [0, 0, 1]])      # :42-49
+    K[0, :] *= opt.width
+    K[1, :] *= opt.height
+    K = K.unsqueeze(0)
+
+    out = opt.out
+    if rank == 0:
+        for d in ("", "src_images", "dst_images", "flows", "obj_mask"):
+            os.makedirs(os.path.join(out, d), exist_ok=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+    img_base, disp_base, mask_base = (os.path.join(opt.base, d) for d in ("images", "disps", "masks"))
+    names = sorted(os.listdir(img_base))
+    renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
+    stats = pipeline.empty_stats()
+    t_start = time.perf_counter()
+    from PIL import Image
+    import torch.nn.functional as F
+    for i, img in enumerate(names):
+        name = img.split(".")[0]
+        mine = (i % world) == rank
+        obj_mask_np = np.array(Image.open(os.path.join(mask_base, img)).convert("L"))
+        if mine:
+            image = U.image_to_tensor(os.path.join(img_base, img)).to(dev)
+            disp = U.disparity_to_tensor(os.path.join(disp_base, img)).to(dev)
+            image = F.interpolate(image, size=(opt.height, opt.width), mode="bilinear", align_corners=True)   # :86-89
+            disp = F.interpolate(disp, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
+            if opt.mpi_from == "npz":
+                z = np.load(os.path.join(opt.base, "mpis", name + ".npz"))
+                mpi, planes = torch.from_numpy(z["mpi"]).to(dev), torch.from_numpy(z["disparity"]).to(dev)
+            else:
+                mpi, planes = mpi_from_disparity(image[0], disp[0, 0], opt.planes)
+        for r in range(opt.repeat):
+            # every rank draws for every pair, so the stream position is identical to a single-process run
+            obj_index = np.random.randint(obj_mask_np.max()) + 1                                             # :101
+            cam_ext_dynamic = host_math.generate_random_pose(opt.ext_cz)                                      # utils.py:207
+            cam_ext = host_math.generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0])                      # utils.py:208
+            if not mine:
+                continue
+            obj_mask = torch.from_numpy((obj_mask_np == obj_index).astype(np.float32)).to(dev)[None, None]    # :102-105
+            obj_mask = F.interpolate(obj_mask, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
+            t0 = time.perf_counter()
+            res = pipeline.render_pair(image[0], obj_mask[0, 0], mpi, planes, K, cam_ext, cam_ext_dynamic, renderer=renderer)
+            inpainted = U._inpaint(res["frame_mix"], res["fill_mask"], opt.inpaint)
+            torch.cuda.synchronize()
+            st = pipeline.pair_stats(res["flow_mix"], res["fill_mask"])
+            st["kernel_seconds"] = time.perf_counter() - t0
+            stats = pipeline.merge_stats(stats, st)
+            io_formats.write_flo(os.path.join(out, "flows", f"{name}_{r}.flo"), res["flow_mix"].cpu().numpy())   # :120
+            io_formats.write_png_bgr(os.path.join(out, "dst_images", f"{name}_{r}.png"), inpainted)            # :121
+            io_formats.write_png_bgr(os.path.join(out, "src_images", f"{name}_{r}.png"), res["src_np"].cpu().numpy())
+    stats["wall_seconds"] = time.perf_counter() - t_start
+    total = pipeline.reduce_stats(stats)
+    if rank == 0:
+        print("pairs %d  mean|flow| %.3f px  max|flow| %.2f px  hole px/pair %.0f  wall %.1f s  (%d rank%s)" % (
+            total["pairs"], total["sum_flow_mag"] / max(total["pairs"], 1) / (opt.height * opt.width), total["max_flow_mag"],
+            total["hole_px"] / max(total["pairs"], 1), total["wall_seconds"], world, "s" if world > 1 else ""))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

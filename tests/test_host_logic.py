@@ -110,3 +110,17 @@ def test_stats_all_reduce_world_size_2_gloo(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
     pairs, sflow, holes, mx, wall, negmin = map(float, line[1:])
     assert pairs == 11 and sflow == sum(range(11)) and holes == 2 * sum(range(11)) and mx == 10 and wall == 2.0 and negmin == 0.0
+
+
+def test_flo_round_trip_and_layout(tmp_path):
+    from mpiflow_amd import io_formats
+    rs = np.random.RandomState(0)
+    flow = rs.randn(5, 7, 2).astype(np.float32)
+    p = str(tmp_path / "a.flo")
+    io_formats.write_flo(p, flow)
+    raw = open(p, "rb").read()
+    assert len(raw) == 12 + 5 * 7 * 8
+    assert np.frombuffer(raw[:4], np.float32)[0] == np.float32(202021.25)
+    assert tuple(np.frombuffer(raw[4:12], np.int32)) == (7, 5)            # width then height (write_flow.py:95-96)
+    assert np.frombuffer(raw[12:20], np.float32).tolist() == flow[0, 0].tolist()   # u, v interleaved
+    assert bits_equal(io_formats.read_flo(p), flow) == 0

@@ -6,6 +6,11 @@ The shared library is built in-tree by `python __graft_entry__.py` / `make -C mp
 import ctypes
 import os
 
+# PyTorch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  It must be the first HIP runtime mapped into the
+# process so that libmpiflow_hip.so binds to the one that owns torch's device context and streams; loading ours first
+# leaves two half-initialised runtimes ("no ROCm-capable device is detected").
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpiflow_hip.so")
 

@@ -65,6 +65,64 @@ MPF_DEV float mpf_expf(float d)
     return u;
 }
 
+// ---- normal-range fast paths ------------------------------------------------------------------------------------
+// hipcc expands an IEEE fp32 division into v_div_scale x2, v_rcp, a 6-fma Newton/residual chain, v_div_fmas and
+// v_div_fixup (11 VALU ops); the scale/fixup ops only act on denormal / huge-exponent-gap / zero / inf / NaN operands.
+// Homography denominators are O(1) and the grid normalisation divides by W/2, so the hot kernels run the SAME fma chain
+// without the range guards - bit-identical quotients for normal-range operands - and share the refined reciprocal
+// between the quotients that have a common denominator.
+MPF_DEV float mpf_rcp_nr(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = fmaf(-d, r, 1.0f);
+    return fmaf(e, r, r);
+}
+MPF_DEV float mpf_div_nr(float n, float d, float r /* = mpf_rcp_nr(d) */)
+{
+    float q = n * r;
+    float e = fmaf(-d, q, n);
+    q = fmaf(e, r, q);
+    e = fmaf(-d, q, n);
+    return fmaf(e, r, q);
+}
+// correctly rounded sqrt for normal-range x: v_sqrt_f32 then the +-1 ulp residual test hipcc itself emits, without the
+// denormal pre-scaling and the class fix-up
+MPF_DEV float mpf_sqrt_nr(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    float sm = __int_as_float(__float_as_int(s) - 1);
+    float sp = __int_as_float(__float_as_int(s) + 1);
+    float rm = fmaf(-sm, s, x);
+    float rp = fmaf(-sp, s, x);
+    s = (rm <= 0.0f) ? sm : s;
+    s = (rp > 0.0f) ? sp : s;
+    return s;
+}
+MPF_DEV float mpf_norm3_nr(float x, float y, float z)
+{
+    return mpf_sqrt_nr(fmaf(z, z, fmaf(y, y, x * x)));
+}
+// same value as mpf_expf for every input: the argument clamp replaces the two range selects (exp(-105) already rounds
+// to 0, exp(100) already overflows to +inf) and v_ldexp_f32 replaces the two exact power-of-two multiplies
+MPF_DEV float mpf_expf_fast(float d)
+{
+    const float R_LN2f = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    const float L2Uf = 0.693145751953125f;
+    const float L2Lf = 1.428606765330187045e-06f;
+    d = fminf(fmaxf(d, -105.0f), 100.0f);
+    float qf = rintf(d * R_LN2f);
+    float s = fmaf(qf, -L2Uf, d);
+    s = fmaf(qf, -L2Lf, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = 1.0f + fmaf(s * s, u, s);
+    return ldexpf(u, (int)qf);
+}
+
 // ATen's cascade sum behind every torch.sum(dim=1) over the S planes (aten/src/ATen/native/cpu/SumKernel.cpp
 // multi_row_sum; reference call sites utils/mpi/mpi_rendering.py:93-96, :132, :143-152): level 0 takes 16 addends,
 // then folds into level 1, every 256 into level 2.  NL = 2 covers S < 256, NL = 3 covers S < 4096.

@@ -164,6 +164,212 @@ k_warp_composite(const float *__restrict__ rgba, const float *__restrict__ quads
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stage B, version 2 (interleaved RGBA stack only): same arithmetic as k_warp_composite, restructured for the machine
+//   * two register sets (A/B) ping-pong across an x2-unrolled plane loop: the gathers of plane s+1 are issued a whole
+//     composite step before their first use, and nothing is copied (v1's `cur = nxt` forced hipcc to wait for the loads
+//     right after issuing them)
+//   * the four divisions per plane share refined reciprocals and skip the denormal/overflow guards (mpf_div_nr), sqrt and
+//     exp likewise (mpf_sqrt_nr, mpf_expf_fast) - bit-identical results in the range the path operates in
+//   * out-of-range bilinear neighbours: their weight is exactly 0 (x0+1 == W only when ix == W-1 exactly), the tap
+//     re-reads the in-range texel and 0 * finite adds nothing - no selects (rgb, sigma >= 0, finite)
+//   * plane base pointers stay scalar (SGPR base + 32-bit VGPR byte offset), validity is counted where it is computed
+// ---------------------------------------------------------------------------------------------------------------
+
+struct MpfGeom {
+    float nw, ne, sw, se;
+    float X, Y, Z;
+    unsigned b00, b01, b10, b11;     // byte offsets of the four taps inside one [H,W,4] fp32 plane
+};
+
+struct MpfConsts {
+    float fx, fy;
+    float halfW, halfH, rhalfW, rhalfH, maxx, maxy;
+    float Wf, Hf;
+    int W, H;
+};
+
+MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts &c, MpfGeom &g)
+{
+    const float *rec = params + MPF_PARAMS_HEADER + MPF_PLANE_RECORD * s;
+    float qx = mpf_row3_xy1(rec[0], rec[1], rec[2], c.fx, c.fy);
+    float qy = mpf_row3_xy1(rec[3], rec[4], rec[5], c.fx, c.fy);
+    float qz = mpf_row3_xy1(rec[6], rec[7], rec[8], c.fx, c.fy);
+    const float rz = mpf_rcp_nr(qz);
+    float u = mpf_div_nr(qx, qz, rz), v = mpf_div_nr(qy, qz, rz);
+    const float valid = ((u < c.Wf) && (u > -1.0f) && (v < c.Hf) && (v > -1.0f)) ? 1.0f : 0.0f;
+    float gx = mpf_div_nr(u + 0.5f, c.halfW, c.rhalfW) - 1.0f;
+    float gy = mpf_div_nr(v + 0.5f, c.halfH, c.rhalfH) - 1.0f;
+    float ix = (gx + 1.0f) * c.halfW - 0.5f;
+    float iy = (gy + 1.0f) * c.halfH - 0.5f;
+    ix = fminf(c.maxx, fmaxf(ix, 0.0f));
+    iy = fminf(c.maxy, fmaxf(iy, 0.0f));
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    float w = ix - fx0, e = 1.0f - w;
+    float n = iy - fy0, sgt = 1.0f - n;
+    g.nw = sgt * e; g.ne = sgt * w; g.sw = n * e; g.se = n * w;
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const unsigned o00 = (unsigned)(y0 * c.W + x0);
+    const unsigned dx = (x0 + 1 < c.W) ? 16u : 0u;
+    const unsigned dy = (y0 + 1 < c.H) ? (unsigned)c.W * 16u : 0u;
+    g.b00 = o00 * 16u;
+    g.b01 = g.b00 + dx;
+    g.b10 = g.b00 + dy;
+    g.b11 = g.b10 + dx;
+    const float d = rec[9];
+    float rx = mpf_row3_xy1(params[0], params[1], params[2], ix, iy) * d;
+    float ry = mpf_row3_xy1(params[3], params[4], params[5], ix, iy) * d;
+    float rzz = mpf_row3_xy1(params[6], params[7], params[8], ix, iy) * d;
+    g.X = mpf_row4_xyz1(params[9], params[10], params[11], params[12], rx, ry, rzz);
+    g.Y = mpf_row4_xyz1(params[13], params[14], params[15], params[16], rx, ry, rzz);
+    g.Z = mpf_row4_xyz1(params[17], params[18], params[19], params[20], rx, ry, rzz);
+    return valid;
+}
+
+struct MpfRaw4 { float4 t00, t01, t10, t11, mq; };
+
+template <bool HAS_MASK>
+MPF_DEV void mpf_fetch2(const char *__restrict__ plane, const char *__restrict__ quads, const MpfGeom &g, MpfRaw4 &r)
+{
+    r.t00 = *reinterpret_cast<const float4 *>(plane + g.b00);
+    r.t01 = *reinterpret_cast<const float4 *>(plane + g.b01);
+    r.t10 = *reinterpret_cast<const float4 *>(plane + g.b10);
+    r.t11 = *reinterpret_cast<const float4 *>(plane + g.b11);
+    if (HAS_MASK) r.mq = *reinterpret_cast<const float4 *>(quads + g.b00);
+}
+
+MPF_DEV float mpf_tap4w(const MpfGeom &g, float a, float b, float c, float d)
+{
+    float o = a * g.nw;
+    o = fmaf(b, g.ne, o);
+    o = fmaf(c, g.sw, o);
+    o = fmaf(d, g.se, o);
+    return o;
+}
+
+template <int NL, bool HAS_MASK>
+struct MpfAcc {
+    double acc;
+    MpfCsum<NL> cw, cd, co, c0, c1, c2;
+    float nvalid;
+    MPF_DEV void init()
+    {
+        acc = 1.0; nvalid = 0.0f;
+        cw.init(); cd.init(); co.init(); c0.init(); c1.init(); c2.init();
+    }
+    // composite plane s (geometry g, fetched taps r) given the distance to plane s+1
+    MPF_DEV void step(const MpfGeom &g, const MpfRaw4 &r, float dist, int s)
+    {
+        float cr = mpf_tap4w(g, r.t00.x, r.t01.x, r.t10.x, r.t11.x);
+        float cg = mpf_tap4w(g, r.t00.y, r.t01.y, r.t10.y, r.t11.y);
+        float cb = mpf_tap4w(g, r.t00.z, r.t01.z, r.t10.z, r.t11.z);
+        float sg = mpf_tap4w(g, r.t00.w, r.t01.w, r.t10.w, r.t11.w);
+        sg = (g.Z >= 0.0f) ? sg : 0.0f;
+        float T = mpf_expf_fast(-sg * dist);
+        float alpha = 1.0f - T;
+        float tacc = (float)acc;
+        float w = tacc * alpha;
+        acc *= (double)(T + 1e-6f);
+        cw.push(w);
+        c0.push(w * cr); c1.push(w * cg); c2.push(w * cb);
+        cd.push(w * g.Z);
+        if (HAS_MASK) co.push(w * mpf_tap4w(g, r.mq.x, r.mq.y, r.mq.z, r.mq.w));
+        if (((s + 1) & 15) == 0) {
+            cw.fold(s + 1); cd.fold(s + 1); c0.fold(s + 1); c1.fold(s + 1); c2.fold(s + 1);
+            if (HAS_MASK) co.fold(s + 1);
+        }
+    }
+};
+
+template <bool HAS_MASK, int NL, int TW, int TH, int WPS>
+__global__ void __launch_bounds__(TW *TH, WPS)
+k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
+                    int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                    float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
+{
+    const int64_t N = (int64_t)H * W;
+    const unsigned tiles_x = (W + TW - 1) / TW;
+    const unsigned tile = mpf_xcd_remap(blockIdx.x, gridDim.x);
+    const int x = (tile % tiles_x) * TW + (threadIdx.x % TW);
+    const int y = (tile / tiles_x) * TH + (threadIdx.x / TW);
+    const bool active = (x < W) && (y < H);
+    MpfConsts c;
+    c.fx = (float)min(x, W - 1); c.fy = (float)min(y, H - 1);
+    c.W = W; c.H = H; c.Wf = (float)W; c.Hf = (float)H;
+    c.halfW = (float)W * 0.5f; c.halfH = (float)H * 0.5f;
+    c.rhalfW = mpf_rcp_nr(c.halfW); c.rhalfH = mpf_rcp_nr(c.halfH);
+    c.maxx = (float)(W - 1); c.maxy = (float)(H - 1);
+    const char *qbase = reinterpret_cast<const char *>(quads);
+    const char *pbase = reinterpret_cast<const char *>(rgba);
+    const size_t plane_bytes = (size_t)N * 16;
+
+    MpfAcc<NL, HAS_MASK> A;
+    A.init();
+    MpfGeom ga, gb;
+    MpfRaw4 ra, rb;
+    A.nvalid += mpf_geom(params, 0, c, ga);
+    mpf_fetch2<HAS_MASK>(pbase, qbase, ga, ra);
+
+    int s = 0;
+    while (s + 2 < S) {
+        A.nvalid += mpf_geom(params, s + 1, c, gb);
+        mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb);
+        A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
+        A.nvalid += mpf_geom(params, s + 2, c, ga);
+        mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 2) * plane_bytes, qbase, ga, ra);
+        A.step(gb, rb, mpf_norm3_nr(ga.X - gb.X, ga.Y - gb.Y, ga.Z - gb.Z), s + 1);
+        s += 2;
+    }
+    if (s + 1 < S) {
+        A.nvalid += mpf_geom(params, s + 1, c, gb);
+        mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb);
+        A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
+        A.step(gb, rb, 1e3f, s + 1);
+    } else {
+        A.step(ga, ra, 1e3f, s);
+    }
+    if (active) {
+        const int64_t n = (int64_t)y * W + x;
+        rgb_out[n] = A.c0.final();
+        rgb_out[N + n] = A.c1.final();
+        rgb_out[2 * N + n] = A.c2.final();
+        if (depth_out) depth_out[n] = A.cd.final() / (A.cw.final() + 1e-5f);
+        if (HAS_MASK) om_out[n] = A.co.final();
+        if (tgt_mask_out) tgt_mask_out[n] = A.nvalid;
+    }
+}
+
+static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = v2 shapes
+
+template <bool HAS_MASK, int TW, int TH, int WPS>
+static int launch_wc2(const float *rgba, const float *quads, const float *params, int S, int H, int W, float *rgb,
+                      float *depth, float *om, float *tm, hipStream_t st)
+{
+    const unsigned tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    dim3 grid(tiles), block(TW * TH);
+    if (S < 256)
+        hipLaunchKernelGGL((k_warp_composite_v2<HAS_MASK, 2, TW, TH, WPS>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+    else
+        hipLaunchKernelGGL((k_warp_composite_v2<HAS_MASK, 3, TW, TH, WPS>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+    return mpf_launch_status("k_warp_composite_v2");
+}
+
+template <bool HAS_MASK>
+static int dispatch_wc2(int variant, const float *rgba, const float *quads, const float *params, int S, int H, int W,
+                        float *rgb, float *depth, float *om, float *tm, hipStream_t st)
+{
+    switch (variant) {
+    case 2: return launch_wc2<HAS_MASK, 64, 4, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    case 3: return launch_wc2<HAS_MASK, 64, 4, 6>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    case 4: return launch_wc2<HAS_MASK, 32, 8, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    case 5: return launch_wc2<HAS_MASK, 16, 16, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    case 6: return launch_wc2<HAS_MASK, 64, 1, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    case 7: return launch_wc2<HAS_MASK, 64, 2, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    case 8: return launch_wc2<HAS_MASK, 64, 4, 8>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    default: return launch_wc2<HAS_MASK, 64, 4, 4>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    }
+}
+
 template <bool INTERLEAVED, bool HAS_MASK>
 static int launch_warp_composite(const float *rgba, const float *quads, const float *params, int S, int H, int W,
                                  float *rgb, float *depth, float *om, float *tm, hipStream_t st)
@@ -190,6 +396,10 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
     MPF_REQUIRE(!interleaved || mpf_aligned16(d_rgba), "mpf_warp_composite: interleaved stack must be 16-byte aligned");
     MPF_REQUIRE(!d_mask_quads || mpf_aligned16(d_mask_quads), "mpf_warp_composite: mask quads must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (interleaved && g_stage_b_variant > 0 && (int64_t)H * W < ((int64_t)1 << 27)) {
+        if (d_mask_quads) return dispatch_wc2<true>(g_stage_b_variant, d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
+        return dispatch_wc2<false>(g_stage_b_variant, d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
+    }
     if (interleaved) {
         if (d_mask_quads) return launch_warp_composite<true, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
         return launch_warp_composite<true, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
@@ -395,6 +605,7 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
 extern "C" int mpf_tune(const char *key, int value)
 {
     if (key && !strcmp(key, "sbf_px")) { g_sbf_px = value; return 0; }
+    if (key && !strcmp(key, "stage_b")) { g_stage_b_variant = value; return 0; }
     mpf_set_error("mpf_tune: unknown key");
     return MPF_ERR_BAD_ARGUMENT;
 }

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root:  bash profiles/run_profile.sh <tag>
+# Collects (1) rocprofv3 --kernel-trace --stats of the bench command, (2) separate PMC passes for FETCH_SIZE and
+# WRITE_SIZE (never combined with tracing flags), all under gpurun_out/<tag>/ ; profiles/summarize.py turns them into
+# the committed summaries.
+TAG=${1:-r1}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+cd $REPO
+find $OUT -type f | head -50
+python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the Stage B (warp + composite) kernel variants on one GPU (run through gpurun).
+
+For every variant selected with mpf_tune("stage_b", v): checks that the outputs are bit-identical to variant 0 (the
+straightforward kernel that tests/ pin against the oracle), then times N back-to-back launches with HIP events on the
+launch stream, interleaving variants across rounds (within-process A/B)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mpiflow_amd import _lib, host_math, ops, synth  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--variants", type=str, default="0,1,2,3,4,5,6,7,8")
+p.add_argument("--planes", type=int, default=64)
+p.add_argument("--height", type=int, default=640)
+p.add_argument("--width", type=int, default=960)
+p.add_argument("--rounds", type=int, default=5)
+p.add_argument("--launches", type=int, default=20)
+p.add_argument("--images", type=int, default=4)
+p.add_argument("--mask", type=int, default=1)
+a = p.parse_args()
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+S, H, W = a.planes, a.height, a.width
+g = torch.Generator(device=dev).manual_seed(0)
+stacks = []
+for i in range(a.images):
+    rgba = torch.rand((S, H, W, 4), generator=g, device=dev)
+    rgba[..., 3] = torch.relu(3.0 * torch.randn((S, H, W), generator=g, device=dev) - 4.0) + 1e-4
+    stacks.append(rgba)
+K = synth.intrinsics(H, W)
+k_inv = host_math.k_inverse(K)
+d = host_math.plane_depths(synth.plane_disparities(S))
+aa, tr = synth.bench_pose()
+G = host_math.transformation_from_parameters(torch.tensor([[aa]], dtype=torch.float32), torch.tensor([tr], dtype=torch.float32))[0]
+H_ts, H_st = host_math.homographies(G, k_inv, K, d)
+dparams = ops.upload_params(ops.warp_params(H_st, k_inv, G, d), dev)
+om = torch.from_numpy(synth.soft_box_mask(H, W)).to(dev)
+quads = ops.mask_quads(om) if a.mask else None
+variants = [int(v) for v in a.variants.split(",")]
+
+
+def run(v, rgba, out=None):
+    _lib.check(lib.mpf_tune(b"stage_b", v))
+    return ops.warp_composite(rgba, quads, dparams=dparams, out=out)
+
+
+ref = run(0, stacks[0])
+torch.cuda.synchronize()
+ok = {}
+for v in variants:
+    r = run(v, stacks[0])
+    torch.cuda.synchronize()
+    ok[v] = all(torch.equal(r[k].view(torch.int32), ref[k].view(torch.int32)) for k in ("rgb", "depth", "tgt_mask") + (("objmask",) if a.mask else ()))
+times = {v: [] for v in variants}
+out = {k: torch.empty_like(t) for k, t in ref.items() if t is not None}
+for rnd in range(a.rounds):
+    for v in variants:
+        run(v, stacks[0], out)       # warm
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(a.launches):
+            run(v, stacks[i % a.images], out)
+        e1.record()
+        torch.cuda.synchronize()
+        times[v].append(e0.elapsed_time(e1) / a.launches * 1e3)
+alg = 16.0 * S * H * W
+print("Stage B variants at %dx%dx%d, mask=%d, %d launches x %d rounds (us per launch: median / min; GB/s at median; frac of 8 TB/s)" % (S, H, W, a.mask, a.launches, a.rounds))
+for v in variants:
+    med, mn = float(np.median(times[v])), float(np.min(times[v]))
+    print("variant %2d  bit-identical-to-v0=%s  %8.1f / %8.1f us   %7.1f GB/s  frac %.3f" % (v, ok[v], med, mn, alg / med / 1e3, alg / med / 1e3 / 8000))
+print(json.dumps({str(v): float(np.median(times[v])) for v in variants}))

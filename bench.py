@@ -135,7 +135,7 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ops.warp_composite(renderer.rgba, q, dparams=prep["warp"][0], out=renderer.views[0])
+            ops.warp_composite(renderer.rgba, q, dparams=prep["warp"][0], out=renderer.views[0], interleaved=2)
             if timed:
                 e1.record()
                 ev.append((e0, e1))

@@ -51,7 +51,7 @@ const char *mpf_last_error(void);
 /* fills CU count, HBM bytes, gfx arch name (e.g. "gfx950"); any pointer may be NULL */
 int mpf_device_info(int device, int *cu_count, size_t *hbm_bytes, char *arch, size_t arch_len);
 
-/* bench/tuning knobs (never change results): "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 4) */
+/* bench/tuning knobs (never change results): "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2); "stage_b" = Stage B kernel variant */
 int mpf_tune(const char *key, int value);
 
 /* ================= fused hot path =============================================================================== */
@@ -78,7 +78,9 @@ int mpf_build_mask_quads(const float *d_obj_mask, int complement, int H, int W, 
  * 8-channel stack + render_tgt_rgb_depth's composite (utils/mpi/mpi_rendering.py:336-347 -> plane_volume_rendering
  * :62-99 -> weighted_sum_mpi :142-154), streamed per target pixel; xyz_tgt is evaluated analytically at the clamped
  * source coordinate instead of being warped as 3 extra channels.
- *   d_rgba: [S,H,W,4] if interleaved else planar [S,4,H,W];  d_mask_quads from mpf_build_mask_quads or NULL;
+ *   d_rgba: planar [S,4,H,W] if interleaved == 0; [S,H,W,4] if interleaved == 1; interleaved == 2 is [S,H,W,4] with the
+ *   promise that at least (W+1)*16 bytes of readable, FINITE padding follow the last plane (lets the east/south taps use
+ *   fixed offsets; an out-of-image tap has weight exactly 0).  d_mask_quads from mpf_build_mask_quads or NULL;
  *   d_params with S records holding H_src_tgt.  Outputs: d_rgb [3,H,W], d_depth [H,W] (NULL ok),
  *   d_objmask [H,W] (NULL iff d_mask_quads NULL), d_tgt_mask [H,W] = number of planes whose source coordinate is in
  *   range (NULL ok). */

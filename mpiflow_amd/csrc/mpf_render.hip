@@ -187,8 +187,15 @@ struct MpfConsts {
     float halfW, halfH, rhalfW, rhalfH, maxx, maxy;
     float Wf, Hf;
     int W, H;
+    unsigned row_bytes;
 };
 
+// KS: K_src^-1 has the pinhole form [[a,0,b],[0,c,e],[0,0,1]] (checked at run time, uniform).  Then the reference's dense
+//     3x3 . (ix,iy,1) chain collapses exactly: a*ix + 0*iy is a*ix, 0*ix + c*iy is c*iy, the third row is exactly 1, and
+//     1 * d is d - same bits, 6 fewer VALU ops per plane.
+// TP: the stack is followed by >= (W+1) texels of finite padding, so the east / south taps can always be read at
+//     +16 / +row bytes (immediate offsets); where they fall outside the image their weight is exactly 0.
+template <bool KS, bool TP>
 MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts &c, MpfGeom &g)
 {
     const float *rec = params + MPF_PARAMS_HEADER + MPF_PLANE_RECORD * s;
@@ -197,7 +204,8 @@ MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts 
     float qz = mpf_row3_xy1(rec[6], rec[7], rec[8], c.fx, c.fy);
     const float rz = mpf_rcp_nr(qz);
     float u = mpf_div_nr(qx, qz, rz), v = mpf_div_nr(qy, qz, rz);
-    const float valid = ((u < c.Wf) && (u > -1.0f) && (v < c.Hf) && (v > -1.0f)) ? 1.0f : 0.0f;
+    const bool inside = (u < c.Wf) & (u > -1.0f) & (v < c.Hf) & (v > -1.0f);
+    const float valid = inside ? 1.0f : 0.0f;
     float gx = mpf_div_nr(u + 0.5f, c.halfW, c.rhalfW) - 1.0f;
     float gy = mpf_div_nr(v + 0.5f, c.halfH, c.rhalfH) - 1.0f;
     float ix = (gx + 1.0f) * c.halfW - 0.5f;
@@ -209,17 +217,30 @@ MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts 
     float n = iy - fy0, sgt = 1.0f - n;
     g.nw = sgt * e; g.ne = sgt * w; g.sw = n * e; g.se = n * w;
     const int x0 = (int)fx0, y0 = (int)fy0;
-    const unsigned o00 = (unsigned)(y0 * c.W + x0);
-    const unsigned dx = (x0 + 1 < c.W) ? 16u : 0u;
-    const unsigned dy = (y0 + 1 < c.H) ? (unsigned)c.W * 16u : 0u;
+    const unsigned o00 = __umul24((unsigned)y0, (unsigned)c.W) + (unsigned)x0;   // H*W < 2^27, W < 2^24
     g.b00 = o00 * 16u;
-    g.b01 = g.b00 + dx;
-    g.b10 = g.b00 + dy;
-    g.b11 = g.b10 + dx;
+    if (TP) {
+        g.b01 = g.b00 + 16u;
+        g.b10 = g.b00 + c.row_bytes;
+        g.b11 = g.b10 + 16u;
+    } else {
+        const unsigned dx = (fx0 < c.maxx) ? 16u : 0u;                // x0 + 1 < W
+        const unsigned dy = (fy0 < c.maxy) ? c.row_bytes : 0u;        // y0 + 1 < H
+        g.b01 = g.b00 + dx;
+        g.b10 = g.b00 + dy;
+        g.b11 = g.b10 + dx;
+    }
     const float d = rec[9];
-    float rx = mpf_row3_xy1(params[0], params[1], params[2], ix, iy) * d;
-    float ry = mpf_row3_xy1(params[3], params[4], params[5], ix, iy) * d;
-    float rzz = mpf_row3_xy1(params[6], params[7], params[8], ix, iy) * d;
+    float rx, ry, rzz;
+    if (KS) {
+        rx = (params[0] * ix + params[2]) * d;
+        ry = (params[4] * iy + params[5]) * d;
+        rzz = d;
+    } else {
+        rx = mpf_row3_xy1(params[0], params[1], params[2], ix, iy) * d;
+        ry = mpf_row3_xy1(params[3], params[4], params[5], ix, iy) * d;
+        rzz = mpf_row3_xy1(params[6], params[7], params[8], ix, iy) * d;
+    }
     g.X = mpf_row4_xyz1(params[9], params[10], params[11], params[12], rx, ry, rzz);
     g.Y = mpf_row4_xyz1(params[13], params[14], params[15], params[16], rx, ry, rzz);
     g.Z = mpf_row4_xyz1(params[17], params[18], params[19], params[20], rx, ry, rzz);
@@ -281,11 +302,12 @@ struct MpfAcc {
     }
 };
 
-template <bool HAS_MASK, int NL, int TW, int TH, int WPS>
-__global__ void __launch_bounds__(TW *TH, WPS)
-k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
-                    int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
-                    float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
+// DBG (bench-only ablations, results are NOT valid): 1 = no gathers (taps synthesised from the geometry), 2 = gathers and
+// bilinear sums only (geometry of plane 0 reused for every plane, no distance / exp / composite)
+template <bool HAS_MASK, int NL, int TW, int TH, bool KS, bool TP, int DBG = 0>
+MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
+                          int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                          float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
 {
     const int64_t N = (int64_t)H * W;
     const unsigned tiles_x = (W + TW - 1) / TW;
@@ -299,6 +321,7 @@ k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ qu
     c.halfW = (float)W * 0.5f; c.halfH = (float)H * 0.5f;
     c.rhalfW = mpf_rcp_nr(c.halfW); c.rhalfH = mpf_rcp_nr(c.halfH);
     c.maxx = (float)(W - 1); c.maxy = (float)(H - 1);
+    c.row_bytes = (unsigned)W * 16u;
     const char *qbase = reinterpret_cast<const char *>(quads);
     const char *pbase = reinterpret_cast<const char *>(rgba);
     const size_t plane_bytes = (size_t)N * 16;
@@ -307,26 +330,45 @@ k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ qu
     A.init();
     MpfGeom ga, gb;
     MpfRaw4 ra, rb;
-    A.nvalid += mpf_geom(params, 0, c, ga);
+    A.nvalid += mpf_geom<KS, TP>(params, 0, c, ga);
+    if (DBG == 1) {
+        for (int s = 0; s < S; ++s) {
+            A.nvalid += mpf_geom<KS, TP>(params, min(s + 1, S - 1), c, gb);
+            ra.t00 = make_float4(ga.nw, ga.ne, ga.sw, ga.se); ra.t01 = make_float4(ga.X, ga.Y, ga.Z, ga.nw);
+            ra.t10 = ra.t00; ra.t11 = ra.t01; ra.mq = ra.t00;
+            A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
+            ga = gb;
+        }
+    } else if (DBG == 2) {
+        float acc4 = 0.0f;
+        for (int s = 0; s < S; ++s) {
+            mpf_fetch2<HAS_MASK>(pbase + (size_t)s * plane_bytes, qbase, ga, ra);
+            acc4 += mpf_tap4w(ga, ra.t00.x, ra.t01.x, ra.t10.x, ra.t11.x) + mpf_tap4w(ga, ra.t00.y, ra.t01.y, ra.t10.y, ra.t11.y) +
+                    mpf_tap4w(ga, ra.t00.z, ra.t01.z, ra.t10.z, ra.t11.z) + mpf_tap4w(ga, ra.t00.w, ra.t01.w, ra.t10.w, ra.t11.w);
+            if (HAS_MASK) acc4 += mpf_tap4w(ga, ra.mq.x, ra.mq.y, ra.mq.z, ra.mq.w);
+        }
+        A.c0.a[0] = acc4;
+    } else {
     mpf_fetch2<HAS_MASK>(pbase, qbase, ga, ra);
 
     int s = 0;
     while (s + 2 < S) {
-        A.nvalid += mpf_geom(params, s + 1, c, gb);
+        A.nvalid += mpf_geom<KS, TP>(params, s + 1, c, gb);
         mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb);
         A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
-        A.nvalid += mpf_geom(params, s + 2, c, ga);
+        A.nvalid += mpf_geom<KS, TP>(params, s + 2, c, ga);
         mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 2) * plane_bytes, qbase, ga, ra);
         A.step(gb, rb, mpf_norm3_nr(ga.X - gb.X, ga.Y - gb.Y, ga.Z - gb.Z), s + 1);
         s += 2;
     }
     if (s + 1 < S) {
-        A.nvalid += mpf_geom(params, s + 1, c, gb);
+        A.nvalid += mpf_geom<KS, TP>(params, s + 1, c, gb);
         mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb);
         A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
         A.step(gb, rb, 1e3f, s + 1);
     } else {
         A.step(ga, ra, 1e3f, s);
+    }
     }
     if (active) {
         const int64_t n = (int64_t)y * W + x;
@@ -339,34 +381,62 @@ k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ qu
     }
 }
 
+template <bool HAS_MASK, int TW, int TH, int DBG>
+__global__ void __launch_bounds__(TW *TH, 4)
+k_warp_composite_dbg(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
+                     int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                     float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
+{
+    mpf_wc2_body<HAS_MASK, 2, TW, TH, true, true, DBG>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out);
+}
+
+template <bool HAS_MASK, int NL, int TW, int TH, int WPS, bool TP>
+__global__ void __launch_bounds__(TW *TH, WPS)
+k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
+                    int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                    float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
+{
+    const bool pinhole = (params[1] == 0.0f) & (params[3] == 0.0f) & (params[6] == 0.0f) & (params[7] == 0.0f) & (params[8] == 1.0f);
+    if (pinhole)
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out);
+    else
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, false, TP>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out);
+}
+
 static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = v2 shapes
 
 template <bool HAS_MASK, int TW, int TH, int WPS>
-static int launch_wc2(const float *rgba, const float *quads, const float *params, int S, int H, int W, float *rgb,
+static int launch_wc2(bool tail_padded, const float *rgba, const float *quads, const float *params, int S, int H, int W, float *rgb,
                       float *depth, float *om, float *tm, hipStream_t st)
 {
     const unsigned tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     dim3 grid(tiles), block(TW * TH);
-    if (S < 256)
-        hipLaunchKernelGGL((k_warp_composite_v2<HAS_MASK, 2, TW, TH, WPS>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
-    else
-        hipLaunchKernelGGL((k_warp_composite_v2<HAS_MASK, 3, TW, TH, WPS>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+#define MPF_WC2(NLv, TPv) hipLaunchKernelGGL((k_warp_composite_v2<HAS_MASK, NLv, TW, TH, WPS, TPv>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm)
+    if (S < 256) { if (tail_padded) MPF_WC2(2, true); else MPF_WC2(2, false); }
+    else         { if (tail_padded) MPF_WC2(3, true); else MPF_WC2(3, false); }
+#undef MPF_WC2
     return mpf_launch_status("k_warp_composite_v2");
 }
 
 template <bool HAS_MASK>
-static int dispatch_wc2(int variant, const float *rgba, const float *quads, const float *params, int S, int H, int W,
+static int dispatch_wc2(int variant, bool tp, const float *rgba, const float *quads, const float *params, int S, int H, int W,
                         float *rgb, float *depth, float *om, float *tm, hipStream_t st)
 {
+    if (variant == 101 || variant == 102) {   // bench-only ablations (invalid results)
+        dim3 grid(((W + 63) / 64) * ((H + 3) / 4)), block(256);
+        if (variant == 101) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 1>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+        else hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 2>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+        return mpf_launch_status("k_warp_composite_dbg");
+    }
     switch (variant) {
-    case 2: return launch_wc2<HAS_MASK, 64, 4, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-    case 3: return launch_wc2<HAS_MASK, 64, 4, 6>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-    case 4: return launch_wc2<HAS_MASK, 32, 8, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-    case 5: return launch_wc2<HAS_MASK, 16, 16, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-    case 6: return launch_wc2<HAS_MASK, 64, 1, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-    case 7: return launch_wc2<HAS_MASK, 64, 2, 5>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-    case 8: return launch_wc2<HAS_MASK, 64, 4, 8>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-    default: return launch_wc2<HAS_MASK, 64, 4, 4>(rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    case 2: return launch_wc2<HAS_MASK, 64, 4, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+
+    case 4: return launch_wc2<HAS_MASK, 32, 8, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+
+
+    case 7: return launch_wc2<HAS_MASK, 64, 2, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+
+    default: return launch_wc2<HAS_MASK, 64, 4, 4>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
     }
 }
 
@@ -397,8 +467,9 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
     MPF_REQUIRE(!d_mask_quads || mpf_aligned16(d_mask_quads), "mpf_warp_composite: mask quads must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (interleaved && g_stage_b_variant > 0 && (int64_t)H * W < ((int64_t)1 << 27)) {
-        if (d_mask_quads) return dispatch_wc2<true>(g_stage_b_variant, d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
-        return dispatch_wc2<false>(g_stage_b_variant, d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
+        const bool tp = (interleaved == 2);
+        if (d_mask_quads) return dispatch_wc2<true>(g_stage_b_variant, tp, d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
+        return dispatch_wc2<false>(g_stage_b_variant, tp, d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
     }
     if (interleaved) {
         if (d_mask_quads) return launch_warp_composite<true, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
@@ -445,38 +516,45 @@ extern "C" int mpf_build_mask_quads(const float *d_obj_mask, int complement, int
 // Stage A + C
 // ---------------------------------------------------------------------------------------------------------------
 
-// One thread owns PX consecutive pixels of one row and walks the S planes front to back.
+// One thread owns PX pixels (pixel t, t + T, ... with T = number of threads, so every load/store instruction of a wave
+// stays a contiguous run) and walks the S planes front to back.
 //   A: dist_s = |ray*d_{s+1} - ray*d_s|, T = exp(-sigma*dist), Tacc (double cumprod), blend rgb   (utils/utils.py:190-204)
 //   C: w = Tacc*(1-T); flow_p += w * (H_tgt_src[p][s].(x,y,1) / z - (x,y))                       (mpi_rendering.py:102-139,
 //                                                                                                 homography_sampler.py:208-218)
+// PX = 2 halves the workgroup count so that all of them are resident at once on 256 CUs at 640x960 (2400 workgroups of
+// one-pixel threads are 1.17 residency rounds: the second round runs at a fraction of the bandwidth).
 template <int PX, int P, int NL>
 __global__ void __launch_bounds__(256)
 k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, const float *__restrict__ params, int S,
                  int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
-                 float *__restrict__ out_tacc, float *__restrict__ flows)
+                 float *__restrict__ out_tacc, float *__restrict__ flows, int64_t T)
 {
     const int64_t N = (int64_t)H * W;
-    const int64_t n0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * PX;
-    if (n0 >= N) return;
-    const int y = (int)(n0 / W), x0 = (int)(n0 % W);     // PX divides W: the PX pixels share a row
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
     constexpr int NP = (P > 0) ? P : 1;
     constexpr int RS = MPF_PLANE_RECORD * NP;            // floats between two planes' records
 
-    float fx[PX], ray[PX][3], im[PX][3], cur[PX][3];
+    int64_t n[PX];
+    bool live[PX];
+    float fx[PX], fy[PX], ray[PX][3], im[PX][3], cur[PX][3];
     double acc[PX];
     MpfCsum<NL> cf[PX][NP][2];
-    const float fy = (float)y;
     const float d0 = params[MPF_PARAMS_HEADER + 9];
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
-        fx[i] = (float)(x0 + i);
-        ray[i][0] = mpf_row3_xy1(params[0], params[1], params[2], fx[i], fy);      // mpi_rendering.py:234
-        ray[i][1] = mpf_row3_xy1(params[3], params[4], params[5], fx[i], fy);
-        ray[i][2] = mpf_row3_xy1(params[6], params[7], params[8], fx[i], fy);
+        const int64_t ni = t + (int64_t)i * T;
+        live[i] = ni < N;
+        n[i] = live[i] ? ni : (N - 1);                   // dead slots shadow the last pixel: in-range loads, no stores
+        fx[i] = (float)(n[i] % W);
+        fy[i] = (float)(n[i] / W);
+        ray[i][0] = mpf_row3_xy1(params[0], params[1], params[2], fx[i], fy[i]);      // mpi_rendering.py:234
+        ray[i][1] = mpf_row3_xy1(params[3], params[4], params[5], fx[i], fy[i]);
+        ray[i][2] = mpf_row3_xy1(params[6], params[7], params[8], fx[i], fy[i]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            im[i][c] = img[c * N + n0 + i];
-            cur[i][c] = ray[i][c] * d0;                                             // :235-236
+            im[i][c] = img[c * N + n[i]];
+            cur[i][c] = ray[i][c] * d0;                                               // :235-236
         }
         acc[i] = 1.0;
 #pragma unroll
@@ -487,57 +565,49 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
         const float *rec = params + MPF_PARAMS_HEADER + RS * s;
         const bool last = (s + 1 == S);
         const float dn = last ? 0.0f : rec[RS + 9];
-        // planar loads of plane s: 4 channel rows, PX consecutive floats each
-        float ch[4][PX];
-        const float *pl = mpi + (int64_t)s * 4 * N + n0;
+        float ch[PX][4];
+        const float *pl = mpi + (int64_t)s * 4 * N;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (PX == 4) {
-                float4 v = *reinterpret_cast<const float4 *>(pl + c * N);
-                ch[c][0] = v.x; ch[c][1] = v.y; ch[c][2] = v.z; ch[c][3] = v.w;
-            } else if (PX == 2) {
-                float2 v = *reinterpret_cast<const float2 *>(pl + c * N);
-                ch[c][0] = v.x; ch[c][1] = v.y;
-            } else {
+        for (int i = 0; i < PX; ++i)
 #pragma unroll
-                for (int i = 0; i < PX; ++i) ch[c][i] = pl[c * N + i];
-            }
-        }
+            for (int c = 0; c < 4; ++c) ch[i][c] = pl[c * N + n[i]];
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             float nx = ray[i][0] * dn, ny = ray[i][1] * dn, nz = ray[i][2] * dn;
-            float dist = last ? 1e3f : mpf_norm3(nx - cur[i][0], ny - cur[i][1], nz - cur[i][2]);
+            float dist = last ? 1e3f : mpf_norm3_nr(nx - cur[i][0], ny - cur[i][1], nz - cur[i][2]);
             cur[i][0] = nx; cur[i][1] = ny; cur[i][2] = nz;
-            const float sg = ch[3][i];
-            float T = mpf_expf(-sg * dist);
-            float alpha = 1.0f - T;
+            const float sg = ch[i][3];
+            float Tr = mpf_expf_fast(-sg * dist);
+            float alpha = 1.0f - Tr;
             float tacc = (float)acc[i];
             float w = tacc * alpha;
-            acc[i] *= (double)(T + 1e-6f);
+            acc[i] *= (double)(Tr + 1e-6f);
             float one_m = 1.0f - tacc;
             float o[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float a = tacc * im[i][c];                 // blend_weights * src_imgs          utils/utils.py:202-204
-                float bb = one_m * ch[c][i];               // (1 - blend_weights) * mpi_rgb
+                float bb = one_m * ch[i][c];               // (1 - blend_weights) * mpi_rgb
                 o[c] = a + bb;
             }
-            const int64_t n = n0 + i;
-            if (out_rgba) reinterpret_cast<float4 *>(out_rgba)[(int64_t)s * N + n] = make_float4(o[0], o[1], o[2], sg);
-            if (out_planar) {
+            if (live[i]) {
+                if (out_rgba) reinterpret_cast<float4 *>(out_rgba)[(int64_t)s * N + n[i]] = make_float4(o[0], o[1], o[2], sg);
+                if (out_planar) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) out_planar[((int64_t)s * 3 + c) * N + n] = o[c];
+                    for (int c = 0; c < 3; ++c) out_planar[((int64_t)s * 3 + c) * N + n[i]] = o[c];
+                }
+                if (out_tacc) out_tacc[(int64_t)s * N + n[i]] = tacc;
             }
-            if (out_tacc) out_tacc[(int64_t)s * N + n] = tacc;
             if (P > 0) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const float *h = rec + MPF_PLANE_RECORD * p;
-                    float qx = mpf_row3_xy1(h[0], h[1], h[2], fx[i], fy);
-                    float qy = mpf_row3_xy1(h[3], h[4], h[5], fx[i], fy);
-                    float qz = mpf_row3_xy1(h[6], h[7], h[8], fx[i], fy);
-                    cf[i][p][0].push(w * (qx / qz - fx[i]));
-                    cf[i][p][1].push(w * (qy / qz - fy));
+                    float qx = mpf_row3_xy1(h[0], h[1], h[2], fx[i], fy[i]);
+                    float qy = mpf_row3_xy1(h[3], h[4], h[5], fx[i], fy[i]);
+                    float qz = mpf_row3_xy1(h[6], h[7], h[8], fx[i], fy[i]);
+                    const float rz = mpf_rcp_nr(qz);
+                    cf[i][p][0].push(w * (mpf_div_nr(qx, qz, rz) - fx[i]));
+                    cf[i][p][1].push(w * (mpf_div_nr(qy, qz, rz) - fy[i]));
                 }
             }
         }
@@ -557,7 +627,7 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
                 for (int k = 0; k < 2; ++k) {
                     float f = cf[i][p][k].final();
                     if (flow_clip > 0.0f) f = fminf(fmaxf(f, -flow_clip), flow_clip);   // utils/utils.py:348
-                    flows[((int64_t)p * 2 + k) * N + n0 + i] = f;
+                    if (live[i]) flows[((int64_t)p * 2 + k) * N + n[i]] = f;
                 }
     }
 }
@@ -567,12 +637,12 @@ static int launch_sbf(const float *mpi, const float *img, const float *params, i
                       float *rgba, float *planar, float *tacc, float *flows, hipStream_t st)
 {
     const int64_t N = (int64_t)H * W;
-    const int64_t threads = N / PX;
-    dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    const int64_t T = (N + PX - 1) / PX;
+    dim3 grid((unsigned)((T + 255) / 256)), block(256);
     if (S < 256)
-        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 2>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows);
+        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 2>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows, T);
     else
-        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 3>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows);
+        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 3>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows, T);
     return mpf_launch_status("k_src_blend_flow");
 }
 
@@ -588,16 +658,19 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
     MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_src_blend_flow: bad shape S=%d H=%d W=%d", S, H, W);
     MPF_REQUIRE(!d_out_rgba || mpf_aligned16(d_out_rgba), "mpf_src_blend_flow: rgba output must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const bool vec_ok = (W % 4 == 0) && mpf_aligned16(d_mpi) && (((int64_t)H * W) % 4 == 0);
-    int px = g_sbf_px ? g_sbf_px : 1;
-    if (px == 4 && !vec_ok) px = 1;
+    int px = g_sbf_px;
+    if (px != 1 && px != 2) {
+        // residency heuristic (256 CUs x 8 resident 256-thread workgroups): prefer the split that leaves no thin second round
+        const int64_t wg1 = ((int64_t)H * W + 255) / 256;
+        px = (wg1 > 2048 && wg1 <= 4096) ? 2 : 1;
+    }
 #define MPF_SBF(PXv)                                                                                                     \
     switch (P) {                                                                                                         \
     case 0: return launch_sbf<PXv, 0>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
     case 1: return launch_sbf<PXv, 1>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
     default: return launch_sbf<PXv, 2>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
     }
-    if (px == 4) { MPF_SBF(4) }
+    if (px == 2) { MPF_SBF(2) }
     MPF_SBF(1)
 #undef MPF_SBF
 }

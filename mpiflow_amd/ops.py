@@ -78,6 +78,14 @@ def src_blend_flow(mpi_S4HW, img_3HW, K_inv=None, depth_S=None, homs_tgt_src=Non
     return dict(rgba=rgba, rgb_planar=planar, tacc=tacc, flows=flows)
 
 
+def alloc_rgba_stack(S, H, W, device):
+    """Interleaved [S,H,W,4] stack followed by (W+2) zeroed texels: lets Stage B read the east/south bilinear taps at fixed
+    +16 / +row-byte offsets (`interleaved=2`); taps that fall outside the image carry weight exactly 0."""
+    n = S * H * W * 4
+    store = torch.zeros(n + (W + 2) * 4, dtype=_f32, device=device)
+    return store[:n].view(S, H, W, 4)
+
+
 def mask_quads(obj_mask_HW, complement=False):
     lib = _lib.load()
     m = _dev(obj_mask_HW, "obj_mask")
@@ -95,6 +103,8 @@ def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None
     Returns dict(rgb [3,H,W], depth [H,W], objmask [H,W] | None, tgt_mask [H,W])."""
     lib = _lib.load()
     a = _dev(rgba, "rgba")
+    if interleaved == 2:      # caller guarantees >= (W+1) texels of finite padding after the last plane (alloc_rgba_stack)
+        assert a.untyped_storage().nbytes() - a.storage_offset() * 4 >= a.numel() * 4 + (a.shape[2] + 1) * 16
     if interleaved:
         S, H, W, C = a.shape
     else:
@@ -110,7 +120,7 @@ def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None
         depth = torch.empty((H, W), dtype=_f32, device=a.device) if want_depth else None
         om = torch.empty((H, W), dtype=_f32, device=a.device) if q is not None else None
         tm = torch.empty((H, W), dtype=_f32, device=a.device) if want_tgt_mask else None
-    _lib.check(lib.mpf_warp_composite(_ptr(a), int(bool(interleaved)), _ptr(q), _ptr(dparams), S, H, W, _ptr(rgb),
+    _lib.check(lib.mpf_warp_composite(_ptr(a), int(interleaved), _ptr(q), _ptr(dparams), S, H, W, _ptr(rgb),
                                       _ptr(depth), _ptr(om), _ptr(tm), _stream()), "mpf_warp_composite")
     return dict(rgb=rgb, depth=depth, objmask=om, tgt_mask=tm)
 

@@ -28,7 +28,7 @@ class PairRenderer:
         self.S, self.H, self.W, self.device = S, H, W, torch.device(device)
         f32 = torch.float32
         dev = self.device
-        self.rgba = torch.empty((S, H, W, 4), dtype=f32, device=dev)             # blended interleaved stack
+        self.rgba = ops.alloc_rgba_stack(S, H, W, dev)                            # blended interleaved stack (+ tail padding)
         self.flows = torch.empty((n_views, 2, H, W), dtype=f32, device=dev)
         self.views = [dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), depth=torch.empty((H, W), dtype=f32, device=dev),
                            objmask=torch.empty((H, W), dtype=f32, device=dev), tgt_mask=torch.empty((H, W), dtype=f32, device=dev))
@@ -58,7 +58,7 @@ class PairRenderer:
             q = quads[v] if quads is not None else None
             out = self.views[v] if q is not None else dict(rgb=self.views[v]["rgb"], depth=self.views[v]["depth"],
                                                            tgt_mask=self.views[v]["tgt_mask"])
-            ops.warp_composite(self.rgba, q, dparams=prep["warp"][v], out=out)
+            ops.warp_composite(self.rgba, q, dparams=prep["warp"][v], out=out, interleaved=2)
         return self.flows, self.views
 
 

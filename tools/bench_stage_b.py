@@ -24,6 +24,7 @@ p.add_argument("--rounds", type=int, default=5)
 p.add_argument("--launches", type=int, default=20)
 p.add_argument("--images", type=int, default=4)
 p.add_argument("--mask", type=int, default=1)
+p.add_argument("--layout", type=int, default=1, help="1 = interleaved, 2 = interleaved + tail padding")
 a = p.parse_args()
 
 lib = _lib.load()
@@ -32,7 +33,8 @@ S, H, W = a.planes, a.height, a.width
 g = torch.Generator(device=dev).manual_seed(0)
 stacks = []
 for i in range(a.images):
-    rgba = torch.rand((S, H, W, 4), generator=g, device=dev)
+    rgba = ops.alloc_rgba_stack(S, H, W, dev)
+    rgba.copy_(torch.rand((S, H, W, 4), generator=g, device=dev))
     rgba[..., 3] = torch.relu(3.0 * torch.randn((S, H, W), generator=g, device=dev) - 4.0) + 1e-4
     stacks.append(rgba)
 K = synth.intrinsics(H, W)
@@ -49,7 +51,7 @@ variants = [int(v) for v in a.variants.split(",")]
 
 def run(v, rgba, out=None):
     _lib.check(lib.mpf_tune(b"stage_b", v))
-    return ops.warp_composite(rgba, quads, dparams=dparams, out=out)
+    return ops.warp_composite(rgba, quads, dparams=dparams, out=out, interleaved=(a.layout if v > 0 else 1))
 
 
 ref = run(0, stacks[0])

@@ -6,11 +6,12 @@
 
 Workload (BASELINE.json configs[1]): 64 planes, 640 x 960, camera-only novel view.  One *step* = every rank renders
 `--images` distinct image pairs whose plane stacks are already resident in HBM (synthetic data of the shape AdaMPI
-emits; random poses are fixed per image).  Per pair:
-    mpf_build_mask_quads (all-ones object mask, as the reference's camera-only call does)
+emits; random poses are fixed per image).  Per pair, two launches:
     mpf_src_blend_flow   Stage A+C: blend source image into the stack, volume-rendered flow for the pose   (P = 1)
+                         (+ fused: source frame as uint8 BGR, bilinear tap quads of the all-ones object mask - the
+                          reference's camera-only call passes an all-ones mask through the same 8-channel warp)
     mpf_warp_composite   Stage B  : 64-plane homography warp + front-to-back composite  <- dominant / roofline kernel
-    mpf_to_u8_bgr x2     dst and src frames as uint8 BGR
+                         (+ fused: rendered frame as uint8 BGR; rendered object mask)
 Images are independent, so ranks share nothing; the only collective is the end-of-step statistics all-reduce
 (RCCL over xGMI under torchrun).  `value` = pairs rendered by all ranks / max-over-ranks wall time.
 
@@ -130,17 +131,15 @@ def main():
 
     def step(timed):
         for (mpi, img), prep in zip(images, preps):
-            q = ops.mask_quads(ones, False)
-            ops.src_blend_flow(mpi, img, out_rgba=renderer.rgba, out_flows=renderer.flows[:1], dparams=prep["blend"], P=1)
+            ops.src_blend_flow(mpi, img, out_rgba=renderer.rgba, out_flows=renderer.flows[:1], dparams=prep["blend"], P=1,
+                               src_u8=renderer.src_u8, obj_mask=ones, quads=renderer.quads[0])
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ops.warp_composite(renderer.rgba, q, dparams=prep["warp"][0], out=renderer.views[0], interleaved=2)
+            ops.warp_composite(renderer.rgba, renderer.quads[0], dparams=prep["warp"][0], out=renderer.views[0], interleaved=2)
             if timed:
                 e1.record()
                 ev.append((e0, e1))
-            ops.to_u8_bgr(renderer.views[0]["rgb"])
-            ops.to_u8_bgr(img)
         st = pipeline.empty_stats()
         st["pairs"] = B
         return pipeline.reduce_stats(st)

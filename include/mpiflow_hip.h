@@ -64,10 +64,13 @@ int mpf_tune(const char *key, int value);
  *   depth is read then).  Outputs, each optional (NULL to skip):
  *   d_out_rgba [S,H,W,4] interleaved blended rgb + sigma (the layout mpf_warp_composite streams fastest);
  *   d_out_rgb_planar [S,3,H,W];  d_out_tacc [S,H,W] (= "blend_weights");  d_flows [P,2,H,W], clipped to
- *   +-flow_clip when flow_clip > 0 (utils/utils.py:348). */
+ *   +-flow_clip when flow_clip > 0 (utils/utils.py:348).
+ *   Per-pixel by-products fused into the same pass (each NULL to skip): d_src_u8_bgr [H,W,3] = the source frame as uint8
+ *   BGR (utils/utils.py:174-177);  d_quads / d_quads_complement = mpf_build_mask_quads(d_obj_mask, 0 / 1). */
 int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const float *d_params, int P, int S, int H, int W,
                        float flow_clip, float *d_out_rgba, float *d_out_rgb_planar, float *d_out_tacc,
-                       float *d_flows, void *stream);
+                       float *d_flows, uint8_t *d_src_u8_bgr, const float *d_obj_mask, float *d_quads,
+                       float *d_quads_complement, void *stream);
 
 /* obj_mask [H,W] -> per-texel quads (m[y,x], m[y,x+1], m[y+1,x], m[y+1,x+1]) as float4 [H,W,4], out-of-range
  * neighbours 0, of (complement ? 1 - m : m): the four bilinear taps of the mask channel in one 16-byte load.
@@ -83,10 +86,11 @@ int mpf_build_mask_quads(const float *d_obj_mask, int complement, int H, int W, 
  *   fixed offsets; an out-of-image tap has weight exactly 0).  d_mask_quads from mpf_build_mask_quads or NULL;
  *   d_params with S records holding H_src_tgt.  Outputs: d_rgb [3,H,W], d_depth [H,W] (NULL ok),
  *   d_objmask [H,W] (NULL iff d_mask_quads NULL), d_tgt_mask [H,W] = number of planes whose source coordinate is in
- *   range (NULL ok). */
+ *   range (NULL ok), d_rgb_u8_bgr [H,W,3] = the rendered frame as uint8 BGR, clip(rint(x*255)) (utils/utils.py:240-242;
+ *   NULL ok).  Passing NULL for both d_depth and d_tgt_mask selects a leaner kernel body. */
 int mpf_warp_composite(const float *d_rgba, int interleaved, const float *d_mask_quads, const float *d_params,
                        int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask, float *d_tgt_mask,
-                       void *stream);
+                       uint8_t *d_rgb_u8_bgr, void *stream);
 
 /* Stage D.  Replaces utils/utils.py:237-283 (uint8 BGR conversion, threshold, layer select, fill mask).
  * frames [3,H,W] RGB float, masks [H,W], flows [2,H,W], obj_mask [H,W] ->

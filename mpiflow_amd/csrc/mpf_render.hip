@@ -94,7 +94,7 @@ template <bool INTERLEAVED, bool HAS_MASK, int NL>
 __global__ void __launch_bounds__(MPF_TILE_W *MPF_TILE_H)
 k_warp_composite(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
                  int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
-                 float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
+                 float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
 {
     const int64_t N = (int64_t)H * W;
     const unsigned tiles_x = (W + MPF_TILE_W - 1) / MPF_TILE_W;
@@ -158,6 +158,7 @@ k_warp_composite(const float *__restrict__ rgba, const float *__restrict__ quads
         rgb_out[n] = c0.final();
         rgb_out[N + n] = c1.final();
         rgb_out[2 * N + n] = c2.final();
+        if (u8_out) { u8_out[3 * n] = mpf_to_u8(c2.final()); u8_out[3 * n + 1] = mpf_to_u8(c1.final()); u8_out[3 * n + 2] = mpf_to_u8(c0.final()); }
         if (depth_out) depth_out[n] = cd.final() / (cw.final() + 1e-5f);   // :152
         if (HAS_MASK) om_out[n] = co.final();
         if (tgt_mask_out) tgt_mask_out[n] = nvalid;
@@ -195,7 +196,7 @@ struct MpfConsts {
 //     1 * d is d - same bits, 6 fewer VALU ops per plane.
 // TP: the stack is followed by >= (W+1) texels of finite padding, so the east / south taps can always be read at
 //     +16 / +row bytes (immediate offsets); where they fall outside the image their weight is exactly 0.
-template <bool KS, bool TP>
+template <bool KS, bool TP, bool WANT_VALID = true>
 MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts &c, MpfGeom &g)
 {
     const float *rec = params + MPF_PARAMS_HEADER + MPF_PLANE_RECORD * s;
@@ -204,19 +205,22 @@ MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts 
     float qz = mpf_row3_xy1(rec[6], rec[7], rec[8], c.fx, c.fy);
     const float rz = mpf_rcp_nr(qz);
     float u = mpf_div_nr(qx, qz, rz), v = mpf_div_nr(qy, qz, rz);
-    const bool inside = (u < c.Wf) & (u > -1.0f) & (v < c.Hf) & (v > -1.0f);
-    const float valid = inside ? 1.0f : 0.0f;
+    float valid = 0.0f;
+    if (WANT_VALID) {
+        const bool inside = (u < c.Wf) & (u > -1.0f) & (v < c.Hf) & (v > -1.0f);
+        valid = inside ? 1.0f : 0.0f;
+    }
     float gx = mpf_div_nr(u + 0.5f, c.halfW, c.rhalfW) - 1.0f;
     float gy = mpf_div_nr(v + 0.5f, c.halfH, c.rhalfH) - 1.0f;
     float ix = (gx + 1.0f) * c.halfW - 0.5f;
     float iy = (gy + 1.0f) * c.halfH - 0.5f;
-    ix = fminf(c.maxx, fmaxf(ix, 0.0f));
-    iy = fminf(c.maxy, fmaxf(iy, 0.0f));
-    float fx0 = floorf(ix), fy0 = floorf(iy);
-    float w = ix - fx0, e = 1.0f - w;
-    float n = iy - fy0, sgt = 1.0f - n;
+    ix = __builtin_amdgcn_fmed3f(ix, 0.0f, c.maxx);       // min(max_val, max(x, 0)) in one op (inputs are never NaN here)
+    iy = __builtin_amdgcn_fmed3f(iy, 0.0f, c.maxy);
+    // ix >= 0: x - floor(x) is exact and equals v_fract_f32(x); trunc == floor
+    float w = __builtin_amdgcn_fractf(ix), e = 1.0f - w;
+    float n = __builtin_amdgcn_fractf(iy), sgt = 1.0f - n;
     g.nw = sgt * e; g.ne = sgt * w; g.sw = n * e; g.se = n * w;
-    const int x0 = (int)fx0, y0 = (int)fy0;
+    const int x0 = (int)ix, y0 = (int)iy;
     const unsigned o00 = __umul24((unsigned)y0, (unsigned)c.W) + (unsigned)x0;   // H*W < 2^27, W < 2^24
     g.b00 = o00 * 16u;
     if (TP) {
@@ -224,8 +228,8 @@ MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts 
         g.b10 = g.b00 + c.row_bytes;
         g.b11 = g.b10 + 16u;
     } else {
-        const unsigned dx = (fx0 < c.maxx) ? 16u : 0u;                // x0 + 1 < W
-        const unsigned dy = (fy0 < c.maxy) ? c.row_bytes : 0u;        // y0 + 1 < H
+        const unsigned dx = (x0 + 1 < c.W) ? 16u : 0u;
+        const unsigned dy = (y0 + 1 < c.H) ? c.row_bytes : 0u;
         g.b01 = g.b00 + dx;
         g.b10 = g.b00 + dy;
         g.b11 = g.b10 + dx;
@@ -268,7 +272,7 @@ MPF_DEV float mpf_tap4w(const MpfGeom &g, float a, float b, float c, float d)
     return o;
 }
 
-template <int NL, bool HAS_MASK>
+template <int NL, bool HAS_MASK, bool WANT_DEPTH = true>
 struct MpfAcc {
     double acc;
     MpfCsum<NL> cw, cd, co, c0, c1, c2;
@@ -291,12 +295,12 @@ struct MpfAcc {
         float tacc = (float)acc;
         float w = tacc * alpha;
         acc *= (double)(T + 1e-6f);
-        cw.push(w);
         c0.push(w * cr); c1.push(w * cg); c2.push(w * cb);
-        cd.push(w * g.Z);
+        if (WANT_DEPTH) { cw.push(w); cd.push(w * g.Z); }
         if (HAS_MASK) co.push(w * mpf_tap4w(g, r.mq.x, r.mq.y, r.mq.z, r.mq.w));
         if (((s + 1) & 15) == 0) {
-            cw.fold(s + 1); cd.fold(s + 1); c0.fold(s + 1); c1.fold(s + 1); c2.fold(s + 1);
+            c0.fold(s + 1); c1.fold(s + 1); c2.fold(s + 1);
+            if (WANT_DEPTH) { cw.fold(s + 1); cd.fold(s + 1); }
             if (HAS_MASK) co.fold(s + 1);
         }
     }
@@ -304,10 +308,10 @@ struct MpfAcc {
 
 // DBG (bench-only ablations, results are NOT valid): 1 = no gathers (taps synthesised from the geometry), 2 = gathers and
 // bilinear sums only (geometry of plane 0 reused for every plane, no distance / exp / composite)
-template <bool HAS_MASK, int NL, int TW, int TH, bool KS, bool TP, int DBG = 0>
+template <bool HAS_MASK, int NL, int TW, int TH, bool KS, bool TP, int DBG = 0, bool AUX = true>
 MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
                           int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
-                          float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
+                          float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
 {
     const int64_t N = (int64_t)H * W;
     const unsigned tiles_x = (W + TW - 1) / TW;
@@ -326,19 +330,31 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
     const char *pbase = reinterpret_cast<const char *>(rgba);
     const size_t plane_bytes = (size_t)N * 16;
 
-    MpfAcc<NL, HAS_MASK> A;
+    MpfAcc<NL, HAS_MASK, AUX> A;
     A.init();
     MpfGeom ga, gb;
     MpfRaw4 ra, rb;
-    A.nvalid += mpf_geom<KS, TP>(params, 0, c, ga);
+    A.nvalid += mpf_geom<KS, TP, AUX>(params, 0, c, ga);
     if (DBG == 1) {
         for (int s = 0; s < S; ++s) {
-            A.nvalid += mpf_geom<KS, TP>(params, min(s + 1, S - 1), c, gb);
+            A.nvalid += mpf_geom<KS, TP, AUX>(params, min(s + 1, S - 1), c, gb);
             ra.t00 = make_float4(ga.nw, ga.ne, ga.sw, ga.se); ra.t01 = make_float4(ga.X, ga.Y, ga.Z, ga.nw);
             ra.t10 = ra.t00; ra.t11 = ra.t01; ra.mq = ra.t00;
             A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
             ga = gb;
         }
+    } else if (DBG == 3 || DBG == 4) {   // 3: one 16-byte gather per plane (t00 only); 4: two (t00, t10)
+        float acc4 = 0.0f;
+        for (int s = 0; s < S; ++s) {
+            const char *pl = pbase + (size_t)s * plane_bytes;
+            float4 a = *reinterpret_cast<const float4 *>(pl + ga.b00);
+            acc4 += a.x * ga.nw + a.y * ga.ne + a.z * ga.sw + a.w * ga.se;
+            if (DBG == 4) {
+                float4 b = *reinterpret_cast<const float4 *>(pl + ga.b10);
+                acc4 += b.x * ga.nw + b.y * ga.ne + b.z * ga.sw + b.w * ga.se;
+            }
+        }
+        A.c0.a[0] = acc4;
     } else if (DBG == 2) {
         float acc4 = 0.0f;
         for (int s = 0; s < S; ++s) {
@@ -353,16 +369,16 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
 
     int s = 0;
     while (s + 2 < S) {
-        A.nvalid += mpf_geom<KS, TP>(params, s + 1, c, gb);
+        A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 1, c, gb);
         mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb);
         A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
-        A.nvalid += mpf_geom<KS, TP>(params, s + 2, c, ga);
+        A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 2, c, ga);
         mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 2) * plane_bytes, qbase, ga, ra);
         A.step(gb, rb, mpf_norm3_nr(ga.X - gb.X, ga.Y - gb.Y, ga.Z - gb.Z), s + 1);
         s += 2;
     }
     if (s + 1 < S) {
-        A.nvalid += mpf_geom<KS, TP>(params, s + 1, c, gb);
+        A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 1, c, gb);
         mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb);
         A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
         A.step(gb, rb, 1e3f, s + 1);
@@ -372,12 +388,14 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
     }
     if (active) {
         const int64_t n = (int64_t)y * W + x;
-        rgb_out[n] = A.c0.final();
-        rgb_out[N + n] = A.c1.final();
-        rgb_out[2 * N + n] = A.c2.final();
-        if (depth_out) depth_out[n] = A.cd.final() / (A.cw.final() + 1e-5f);
+        const float fr = A.c0.final(), fg = A.c1.final(), fb = A.c2.final();
+        rgb_out[n] = fr;
+        rgb_out[N + n] = fg;
+        rgb_out[2 * N + n] = fb;
+        if (u8_out) { u8_out[3 * n] = mpf_to_u8(fb); u8_out[3 * n + 1] = mpf_to_u8(fg); u8_out[3 * n + 2] = mpf_to_u8(fr); }   // BGR, utils/utils.py:240-242
+        if (AUX && depth_out) depth_out[n] = A.cd.final() / (A.cw.final() + 1e-5f);
         if (HAS_MASK) om_out[n] = A.co.final();
-        if (tgt_mask_out) tgt_mask_out[n] = A.nvalid;
+        if (AUX && tgt_mask_out) tgt_mask_out[n] = A.nvalid;
     }
 }
 
@@ -387,31 +405,34 @@ k_warp_composite_dbg(const float *__restrict__ rgba, const float *__restrict__ q
                      int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
                      float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
 {
-    mpf_wc2_body<HAS_MASK, 2, TW, TH, true, true, DBG>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out);
+    mpf_wc2_body<HAS_MASK, 2, TW, TH, true, true, DBG>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, nullptr);
 }
 
 template <bool HAS_MASK, int NL, int TW, int TH, int WPS, bool TP>
 __global__ void __launch_bounds__(TW *TH, WPS)
 k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
                     int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
-                    float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
+                    float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
 {
     const bool pinhole = (params[1] == 0.0f) & (params[3] == 0.0f) & (params[6] == 0.0f) & (params[7] == 0.0f) & (params[8] == 1.0f);
-    if (pinhole)
-        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out);
+    const bool aux = (depth_out != nullptr) | (tgt_mask_out != nullptr);   // depth / validity count wanted at all?
+    if (pinhole && !aux)
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP, 0, false>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out);
+    else if (pinhole)
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP, 0, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out);
     else
-        mpf_wc2_body<HAS_MASK, NL, TW, TH, false, TP>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out);
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, false, TP, 0, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out);
 }
 
 static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = v2 shapes
 
 template <bool HAS_MASK, int TW, int TH, int WPS>
 static int launch_wc2(bool tail_padded, const float *rgba, const float *quads, const float *params, int S, int H, int W, float *rgb,
-                      float *depth, float *om, float *tm, hipStream_t st)
+                      float *depth, float *om, float *tm, uint8_t *u8, hipStream_t st)
 {
     const unsigned tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     dim3 grid(tiles), block(TW * TH);
-#define MPF_WC2(NLv, TPv) hipLaunchKernelGGL((k_warp_composite_v2<HAS_MASK, NLv, TW, TH, WPS, TPv>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm)
+#define MPF_WC2(NLv, TPv) hipLaunchKernelGGL((k_warp_composite_v2<HAS_MASK, NLv, TW, TH, WPS, TPv>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8)
     if (S < 256) { if (tail_padded) MPF_WC2(2, true); else MPF_WC2(2, false); }
     else         { if (tail_padded) MPF_WC2(3, true); else MPF_WC2(3, false); }
 #undef MPF_WC2
@@ -420,44 +441,43 @@ static int launch_wc2(bool tail_padded, const float *rgba, const float *quads, c
 
 template <bool HAS_MASK>
 static int dispatch_wc2(int variant, bool tp, const float *rgba, const float *quads, const float *params, int S, int H, int W,
-                        float *rgb, float *depth, float *om, float *tm, hipStream_t st)
+                        float *rgb, float *depth, float *om, float *tm, uint8_t *u8, hipStream_t st)
 {
-    if (variant == 101 || variant == 102) {   // bench-only ablations (invalid results)
+    if (variant >= 101 && variant <= 104) {   // bench-only ablations (invalid results)
         dim3 grid(((W + 63) / 64) * ((H + 3) / 4)), block(256);
         if (variant == 101) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 1>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+        else if (variant == 103) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 3>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+        else if (variant == 104) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 4>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
         else hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 2>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
         return mpf_launch_status("k_warp_composite_dbg");
     }
     switch (variant) {
-    case 2: return launch_wc2<HAS_MASK, 64, 4, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-
-    case 4: return launch_wc2<HAS_MASK, 32, 8, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-
-
-    case 7: return launch_wc2<HAS_MASK, 64, 2, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
-
-    default: return launch_wc2<HAS_MASK, 64, 4, 4>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, st);
+    case 2: return launch_wc2<HAS_MASK, 64, 4, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
+    case 7: return launch_wc2<HAS_MASK, 64, 2, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
+    case 9: return launch_wc2<HAS_MASK, 64, 4, 4>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
+    default:   // 32x8 target tile per workgroup (a wave = 32 px x 2 rows): measured best, the two rows of a wave share a source row
+        return launch_wc2<HAS_MASK, 32, 8, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
     }
 }
 
 template <bool INTERLEAVED, bool HAS_MASK>
 static int launch_warp_composite(const float *rgba, const float *quads, const float *params, int S, int H, int W,
-                                 float *rgb, float *depth, float *om, float *tm, hipStream_t st)
+                                 float *rgb, float *depth, float *om, float *tm, uint8_t *u8, hipStream_t st)
 {
     const unsigned tiles = ((W + MPF_TILE_W - 1) / MPF_TILE_W) * ((H + MPF_TILE_H - 1) / MPF_TILE_H);
     dim3 grid(tiles), block(MPF_TILE_W * MPF_TILE_H);
     if (S < 256)
         hipLaunchKernelGGL((k_warp_composite<INTERLEAVED, HAS_MASK, 2>), grid, block, 0, st, rgba, quads, params, S, H, W,
-                           rgb, depth, om, tm);
+                           rgb, depth, om, tm, u8);
     else
         hipLaunchKernelGGL((k_warp_composite<INTERLEAVED, HAS_MASK, 3>), grid, block, 0, st, rgba, quads, params, S, H, W,
-                           rgb, depth, om, tm);
+                           rgb, depth, om, tm, u8);
     return mpf_launch_status("k_warp_composite");
 }
 
 extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const float *d_mask_quads, const float *d_params,
                                   int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask,
-                                  float *d_tgt_mask, void *stream)
+                                  float *d_tgt_mask, uint8_t *d_rgb_u8_bgr, void *stream)
 {
     MPF_REQUIRE(d_rgba && d_params && d_rgb, "mpf_warp_composite: null pointer");
     MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_warp_composite: bad shape S=%d H=%d W=%d", S, H, W);
@@ -468,15 +488,15 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
     hipStream_t st = (hipStream_t)stream;
     if (interleaved && g_stage_b_variant > 0 && (int64_t)H * W < ((int64_t)1 << 27)) {
         const bool tp = (interleaved == 2);
-        if (d_mask_quads) return dispatch_wc2<true>(g_stage_b_variant, tp, d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
-        return dispatch_wc2<false>(g_stage_b_variant, tp, d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
+        if (d_mask_quads) return dispatch_wc2<true>(g_stage_b_variant, tp, d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
+        return dispatch_wc2<false>(g_stage_b_variant, tp, d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, d_rgb_u8_bgr, st);
     }
     if (interleaved) {
-        if (d_mask_quads) return launch_warp_composite<true, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
-        return launch_warp_composite<true, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
+        if (d_mask_quads) return launch_warp_composite<true, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
+        return launch_warp_composite<true, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, d_rgb_u8_bgr, st);
     }
-    if (d_mask_quads) return launch_warp_composite<false, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, st);
-    return launch_warp_composite<false, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, st);
+    if (d_mask_quads) return launch_warp_composite<false, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
+    return launch_warp_composite<false, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, d_rgb_u8_bgr, st);
 }
 
 // mask quads ---------------------------------------------------------------------------------------------------
@@ -527,7 +547,8 @@ template <int PX, int P, int NL>
 __global__ void __launch_bounds__(256)
 k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, const float *__restrict__ params, int S,
                  int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
-                 float *__restrict__ out_tacc, float *__restrict__ flows, int64_t T)
+                 float *__restrict__ out_tacc, float *__restrict__ flows, int64_t T, uint8_t *__restrict__ src_u8,
+                 const float *__restrict__ obj_mask, float4 *__restrict__ quads, float4 *__restrict__ quads_c)
 {
     const int64_t N = (int64_t)H * W;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -559,6 +580,22 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
         acc[i] = 1.0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) { cf[i][p][0].init(); cf[i][p][1].init(); }
+        // by-products that need nothing but this pixel: the source frame as uint8 BGR (utils/utils.py:174-177) and the
+        // bilinear tap quads of obj_mask / 1 - obj_mask for Stage B (see k_mask_quads)
+        if (live[i] && src_u8) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) src_u8[3 * n[i] + c] = mpf_to_u8(im[i][2 - c]);
+        }
+        if (live[i] && obj_mask) {
+            const int x = (int)(n[i] % W), y = (int)(n[i] / W);
+            const bool e = (x + 1) < W, so = (y + 1) < H;
+            const float a = obj_mask[n[i]];
+            const float b = e ? obj_mask[n[i] + 1] : 0.0f;
+            const float c2 = so ? obj_mask[n[i] + W] : 0.0f;
+            const float d2 = (e && so) ? obj_mask[n[i] + W + 1] : 0.0f;
+            if (quads) quads[n[i]] = make_float4(a, b, c2, d2);
+            if (quads_c) quads_c[n[i]] = make_float4(1.0f - a, e ? 1.0f - b : 0.0f, so ? 1.0f - c2 : 0.0f, (e && so) ? 1.0f - d2 : 0.0f);
+        }
     }
 
     for (int s = 0; s < S; ++s) {
@@ -634,15 +671,18 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
 
 template <int PX, int P>
 static int launch_sbf(const float *mpi, const float *img, const float *params, int S, int H, int W, float clip,
-                      float *rgba, float *planar, float *tacc, float *flows, hipStream_t st)
+                      float *rgba, float *planar, float *tacc, float *flows, uint8_t *src_u8, const float *om, float *q0, float *q1,
+                      hipStream_t st)
 {
     const int64_t N = (int64_t)H * W;
     const int64_t T = (N + PX - 1) / PX;
     dim3 grid((unsigned)((T + 255) / 256)), block(256);
     if (S < 256)
-        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 2>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows, T);
+        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 2>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows, T, src_u8, om,
+                           reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1));
     else
-        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 3>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows, T);
+        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 3>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows, T, src_u8, om,
+                           reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1));
     return mpf_launch_status("k_src_blend_flow");
 }
 
@@ -650,9 +690,12 @@ static int g_sbf_px = 0;   // 0 = auto; tuning knob for benches (mpf_tune)
 
 extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const float *d_params, int P, int S, int H, int W,
                                   float flow_clip, float *d_out_rgba, float *d_out_rgb_planar, float *d_out_tacc,
-                                  float *d_flows, void *stream)
+                                  float *d_flows, uint8_t *d_src_u8_bgr, const float *d_obj_mask, float *d_quads,
+                                  float *d_quads_complement, void *stream)
 {
     MPF_REQUIRE(d_mpi && d_img && d_params, "mpf_src_blend_flow: null pointer");
+    MPF_REQUIRE((d_quads == nullptr && d_quads_complement == nullptr) || d_obj_mask, "mpf_src_blend_flow: quads need d_obj_mask");
+    MPF_REQUIRE(mpf_aligned16(d_quads) && mpf_aligned16(d_quads_complement), "mpf_src_blend_flow: quads must be 16-byte aligned");
     MPF_REQUIRE(P >= 0 && P <= 2, "mpf_src_blend_flow: P must be 0, 1 or 2 (got %d)", P);
     MPF_REQUIRE((P == 0) == (d_flows == nullptr), "mpf_src_blend_flow: flows output iff P > 0");
     MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_src_blend_flow: bad shape S=%d H=%d W=%d", S, H, W);
@@ -666,9 +709,9 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
     }
 #define MPF_SBF(PXv)                                                                                                     \
     switch (P) {                                                                                                         \
-    case 0: return launch_sbf<PXv, 0>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
-    case 1: return launch_sbf<PXv, 1>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
-    default: return launch_sbf<PXv, 2>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, st); \
+    case 0: return launch_sbf<PXv, 0>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, st); \
+    case 1: return launch_sbf<PXv, 1>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, st); \
+    default: return launch_sbf<PXv, 2>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, st); \
     }
     if (px == 2) { MPF_SBF(2) }
     MPF_SBF(1)

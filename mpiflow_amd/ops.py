@@ -58,9 +58,10 @@ def warp_params(H_src_tgt, K_inv, G, depth_S):
 
 def src_blend_flow(mpi_S4HW, img_3HW, K_inv=None, depth_S=None, homs_tgt_src=None, flow_clip=200.0,
                    want_rgba=True, want_planar=False, want_tacc=False, out_rgba=None, out_flows=None,
-                   dparams=None, P=None):
+                   dparams=None, P=None, src_u8=None, obj_mask=None, quads=None, quads_complement=None):
     """Stage A + C.  homs_tgt_src: None or [P,S,3,3] CPU (P <= 2), or pass a pre-uploaded `dparams` + P.
-    Returns dict(rgba, rgb_planar, tacc, flows)."""
+    Fused by-products (preallocated outputs, optional): src_u8 [H,W,3] u8 BGR source frame; quads / quads_complement
+    [H,W,4] = mask_quads(obj_mask, False / True).  Returns dict(rgba, rgb_planar, tacc, flows)."""
     lib = _lib.load()
     mpi = _dev(mpi_S4HW, "mpi")
     S, C, H, W = mpi.shape
@@ -74,7 +75,9 @@ def src_blend_flow(mpi_S4HW, img_3HW, K_inv=None, depth_S=None, homs_tgt_src=Non
     tacc = torch.empty((S, H, W), dtype=_f32, device=mpi.device) if want_tacc else None
     flows = out_flows if out_flows is not None else (torch.empty((P, 2, H, W), dtype=_f32, device=mpi.device) if P else None)
     _lib.check(lib.mpf_src_blend_flow(_ptr(mpi), _ptr(img), _ptr(dparams), P, S, H, W, float(flow_clip), _ptr(rgba),
-                                      _ptr(planar), _ptr(tacc), _ptr(flows), _stream()), "mpf_src_blend_flow")
+                                      _ptr(planar), _ptr(tacc), _ptr(flows), _ptr(src_u8),
+                                      _ptr(_dev(obj_mask, "obj_mask").reshape(H, W)) if obj_mask is not None else None,
+                                      _ptr(quads), _ptr(quads_complement), _stream()), "mpf_src_blend_flow")
     return dict(rgba=rgba, rgb_planar=planar, tacc=tacc, flows=flows)
 
 
@@ -113,6 +116,7 @@ def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None
     if dparams is None:
         dparams = upload_params(warp_params(H_src_tgt, K_inv, G, depth_S), a.device)
     q = _dev(quads, "mask quads") if quads is not None else None
+    u8 = out.get("rgb_u8") if out is not None else None
     if out is not None:
         rgb, depth, om, tm = out["rgb"], out.get("depth"), out.get("objmask"), out.get("tgt_mask")
     else:
@@ -121,8 +125,8 @@ def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None
         om = torch.empty((H, W), dtype=_f32, device=a.device) if q is not None else None
         tm = torch.empty((H, W), dtype=_f32, device=a.device) if want_tgt_mask else None
     _lib.check(lib.mpf_warp_composite(_ptr(a), int(interleaved), _ptr(q), _ptr(dparams), S, H, W, _ptr(rgb),
-                                      _ptr(depth), _ptr(om), _ptr(tm), _stream()), "mpf_warp_composite")
-    return dict(rgb=rgb, depth=depth, objmask=om, tgt_mask=tm)
+                                      _ptr(depth), _ptr(om), _ptr(tm), _ptr(u8), _stream()), "mpf_warp_composite")
+    return dict(rgb=rgb, depth=depth, objmask=om, tgt_mask=tm, rgb_u8=u8)
 
 
 def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.99):

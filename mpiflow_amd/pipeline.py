@@ -3,7 +3,8 @@
 `PairRenderer` is the fast path behind `utils.utils.render_3dphoto_dynamic`:
 
     Stage A+C  mpf_src_blend_flow   planar [S,4,H,W] stack + image -> interleaved blended RGBA stack + 1-2 flows
-    Stage B    mpf_warp_composite   x1 (camera-only) or x2 (object + background poses)
+                                    (+ fused by-products: source frame as u8 BGR, mask quads of obj_mask / 1 - obj_mask)
+    Stage B    mpf_warp_composite   x1 (camera-only) or x2 (object + background poses)  (+ rendered frame as u8 BGR)
     Stage D    mpf_merge            threshold / select / uint8 BGR / fill mask
 
 All buffers are allocated once per (S,H,W) and reused; per pair only ~10 KB of small matrices are uploaded.  With
@@ -30,9 +31,12 @@ class PairRenderer:
         dev = self.device
         self.rgba = ops.alloc_rgba_stack(S, H, W, dev)                            # blended interleaved stack (+ tail padding)
         self.flows = torch.empty((n_views, 2, H, W), dtype=f32, device=dev)
-        self.views = [dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), depth=torch.empty((H, W), dtype=f32, device=dev),
-                           objmask=torch.empty((H, W), dtype=f32, device=dev), tgt_mask=torch.empty((H, W), dtype=f32, device=dev))
-                      for _ in range(n_views)]
+        # the fused pipeline never reads depth / tgt_mask (the reference discards them too, utils/utils.py:210, :330):
+        # leaving them out selects the leaner Stage B body
+        self.views = [dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), objmask=torch.empty((H, W), dtype=f32, device=dev),
+                           rgb_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev)) for _ in range(n_views)]
+        self.quads = [torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)]    # obj_mask, 1 - obj_mask
+        self.src_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         self.n_views = n_views
 
     # -- host side: small matrices ---------------------------------------------------------------------------------
@@ -50,15 +54,19 @@ class PairRenderer:
         return dict(P=P, blend=ops.upload_params(bf, self.device), warp=wp)
 
     # -- device side: launches only ------------------------------------------------------------------------------------
-    def run(self, mpi, image, prep, quads):
-        """mpi [S,4,H,W], image [3,H,W] on device; quads: list (per view) of mask-quad tensors or None.
-        Launches A+C then one B per view; returns (flows [P,2,H,W], views)."""
-        ops.src_blend_flow(mpi, image, out_rgba=self.rgba, out_flows=self.flows[: prep["P"]], dparams=prep["blend"], P=prep["P"])
-        for v in range(prep["P"]):
-            q = quads[v] if quads is not None else None
-            out = self.views[v] if q is not None else dict(rgb=self.views[v]["rgb"], depth=self.views[v]["depth"],
-                                                           tgt_mask=self.views[v]["tgt_mask"])
-            ops.warp_composite(self.rgba, q, dparams=prep["warp"][v], out=out, interleaved=2)
+    def run(self, mpi, image, prep, obj_mask, complement=(False, True)):
+        """mpi [S,4,H,W], image [3,H,W], obj_mask [H,W] on device.  Two or three launches:
+          Stage A+C (+ source frame as u8, + mask quads of obj_mask and 1 - obj_mask), then one Stage B per view
+          (view v samples 1 - obj_mask when complement[v]; + its frame as u8).  Returns (flows [P,2,H,W], views)."""
+        P = prep["P"]
+        need_c = any(complement[:P])
+        need_p = not all(complement[:P])
+        ops.src_blend_flow(mpi, image, out_rgba=self.rgba, out_flows=self.flows[:P], dparams=prep["blend"], P=P,
+                           src_u8=self.src_u8, obj_mask=obj_mask, quads=self.quads[0] if need_p else None,
+                           quads_complement=self.quads[1] if need_c else None)
+        for v in range(P):
+            ops.warp_composite(self.rgba, self.quads[1 if complement[v] else 0], dparams=prep["warp"][v], out=self.views[v],
+                               interleaved=2)
         return self.flows, self.views
 
 
@@ -70,11 +78,10 @@ def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, 
     r = renderer or PairRenderer(S, H, W, mpi.device)
     om = obj_mask_HW.reshape(H, W).to(torch.float32)
     prep = r.prepare(K, disparity_S, [G_cam, G_dyn])
-    quads = [ops.mask_quads(om, False), ops.mask_quads(om, True)]
-    flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, quads)
+    flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, om)
     flow_mix, frame_mix, fill = ops.merge(views[0]["rgb"], views[1]["rgb"], views[0]["objmask"], views[1]["objmask"],
                                           flows[0], flows[1], om, thresh)
-    return dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill, src_np=ops.to_u8_bgr(image_3HW.reshape(3, H, W)),
+    return dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill, src_np=r.src_u8,
                 view_cam=views[0], view_dyn=views[1], flows=flows, rgba=r.rgba)
 
 

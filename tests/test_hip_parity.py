@@ -356,3 +356,26 @@ def test_moving_object_chain_vs_reference_golden(dev, oracle, name):
     om = oracle.warp_masks(N(warped))
     for k in om:
         assert bits_equal(N(masks[k]), om[k]) == 0, k
+
+
+def test_fused_byproducts_equal_standalone_kernels(dev):
+    """Stage A+C's fused source-u8 / mask-quad outputs and Stage B's fused u8 frame must equal the stand-alone kernels."""
+    from mpiflow_amd import host_math, ops
+    S, H, W = 12, 37, 50
+    inp = _inputs(S, H, W, seed=9)
+    mpi, img, om = T(inp["mpi"], dev), T(inp["image"], dev), T(inp["obj_mask"], dev)
+    k_inv = host_math.k_inverse(inp["K"])
+    d = host_math.plane_depths(inp["disparity"])
+    G = host_math.generate_random_pose(0.15, rng=__import__("random").Random(3))
+    H_ts, H_st = host_math.homographies(G, k_inv, inp["K"], d)
+    src_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    q0, q1 = torch.empty((H, W, 4), device=dev), torch.empty((H, W, 4), device=dev)
+    a = ops.src_blend_flow(mpi, img, k_inv, d, H_ts[None], src_u8=src_u8, obj_mask=om, quads=q0, quads_complement=q1)
+    assert torch.equal(src_u8, ops.to_u8_bgr(img))
+    assert torch.equal(q0, ops.mask_quads(om, False)) and torch.equal(q1, ops.mask_quads(om, True))
+    out = dict(rgb=torch.empty((3, H, W), device=dev), objmask=torch.empty((H, W), device=dev),
+               rgb_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev))
+    v = ops.warp_composite(a["rgba"], q1, H_st, k_inv, G, d, out=out)
+    assert torch.equal(v["rgb_u8"], ops.to_u8_bgr(v["rgb"]))
+    full = ops.warp_composite(a["rgba"], q1, H_st, k_inv, G, d)          # with depth / tgt_mask: the other kernel body
+    assert torch.equal(full["rgb"], v["rgb"]) and torch.equal(full["objmask"], v["objmask"])

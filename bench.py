@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-pairs", type=int, default=6, help="pairs the CPU oracle renders for cpu_baseline")
     p.add_argument("--sbf-px", type=int, default=0, help="tuning: pixels/thread of Stage A+C (0 = library default)")
+    p.add_argument("--streams", type=int, default=1, help="HIP streams the pairs of a step are spread over (each with its own blended stack)")
     return p.parse_args()
 
 
@@ -119,27 +120,38 @@ def main():
     import random
     rng = random.Random(114514 + rank)
     images, preps = [], []
-    renderer = pipeline.PairRenderer(S, H, W, dev, n_views=1)
+    NS = max(1, a.streams)
+    renderers = [pipeline.PairRenderer(S, H, W, dev, n_views=1) for _ in range(NS)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else [torch.cuda.current_stream()]
     for i in range(B):
         images.append(make_image(S, H, W, dev, seed=rank * 1000 + i))
         G = host_math.generate_random_pose(0.15, rng=rng)
-        preps.append(renderer.prepare(K, disp, [G]))
+        preps.append(renderers[0].prepare(K, disp, [G]))
     ones = torch.ones((H, W), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     ev = []
 
     def step(timed):
-        for (mpi, img), prep in zip(images, preps):
-            ops.src_blend_flow(mpi, img, out_rgba=renderer.rgba, out_flows=renderer.flows[:1], dparams=prep["blend"], P=1,
-                               src_u8=renderer.src_u8, obj_mask=ones, quads=renderer.quads[0])
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            ops.warp_composite(renderer.rgba, renderer.quads[0], dparams=prep["warp"][0], out=renderer.views[0], interleaved=2)
-            if timed:
-                e1.record()
-                ev.append((e0, e1))
+        main = torch.cuda.current_stream()
+        if NS > 1:
+            for s_ in streams:
+                s_.wait_stream(main)
+        for i, ((mpi, img), prep) in enumerate(zip(images, preps)):
+            r = renderers[i % NS]
+            with torch.cuda.stream(streams[i % NS]):
+                ops.src_blend_flow(mpi, img, out_rgba=r.rgba, out_flows=r.flows[:1], dparams=prep["blend"], P=1,
+                                   src_u8=r.src_u8, obj_mask=ones, quads=r.quads[0])
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                ops.warp_composite(r.rgba, r.quads[0], dparams=prep["warp"][0], out=r.views[0], interleaved=2)
+                if timed:
+                    e1.record()
+                    ev.append((e0, e1))
+        if NS > 1:
+            for s_ in streams:
+                main.wait_stream(s_)
         st = pipeline.empty_stats()
         st["pairs"] = B
         return pipeline.reduce_stats(st)

@@ -543,7 +543,10 @@ extern "C" int mpf_build_mask_quads(const float *d_obj_mask, int complement, int
 //                                                                                                 homography_sampler.py:208-218)
 // PX = 2 halves the workgroup count so that all of them are resident at once on 256 CUs at 640x960 (2400 workgroups of
 // one-pixel threads are 1.17 residency rounds: the second round runs at a fraction of the bandwidth).
-template <int PX, int P, int NL>
+#ifndef MPF_NT_STORE
+#define MPF_NT_STORE 1   // stream the 629 MB blended stack past the caches: Stage B re-reads it from HBM anyway, and dirty lines left in L2/MALL only delay it
+#endif
+template <int PX, int P, int NL, bool NT_STORE = (MPF_NT_STORE != 0)>
 __global__ void __launch_bounds__(256)
 k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, const float *__restrict__ params, int S,
                  int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
@@ -628,7 +631,13 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
                 o[c] = a + bb;
             }
             if (live[i]) {
-                if (out_rgba) reinterpret_cast<float4 *>(out_rgba)[(int64_t)s * N + n[i]] = make_float4(o[0], o[1], o[2], sg);
+                if (out_rgba) {
+                    typedef float mpf_v4f __attribute__((ext_vector_type(4)));
+                    mpf_v4f *dst = reinterpret_cast<mpf_v4f *>(out_rgba) + ((int64_t)s * N + n[i]);
+                    const mpf_v4f val = { o[0], o[1], o[2], sg };
+                    if (NT_STORE) __builtin_nontemporal_store(val, dst);
+                    else *dst = val;
+                }
                 if (out_planar) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) out_planar[((int64_t)s * 3 + c) * N + n[i]] = o[c];

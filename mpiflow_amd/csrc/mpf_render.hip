@@ -343,6 +343,23 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
             A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
             ga = gb;
         }
+    } else if (DBG == 5 || DBG == 6) {   // t00, t10, quad for all lanes; t01, t11 only for every 10th lane + row ends (5) / never (6)
+        float acc4 = 0.0f;
+        const unsigned lane = threadIdx.x & 63u;
+        const bool needy = (DBG == 5) && ((lane % 10u) == 0u || (lane & 31u) == 31u);
+        for (int s = 0; s < S; ++s) {
+            const char *pl = pbase + (size_t)s * plane_bytes;
+            float4 a = *reinterpret_cast<const float4 *>(pl + ga.b00);
+            float4 b = *reinterpret_cast<const float4 *>(pl + ga.b10);
+            float4 q = *reinterpret_cast<const float4 *>(qbase + ga.b00);
+            acc4 += a.x * ga.nw + a.y * ga.ne + a.z * ga.sw + a.w * ga.se + b.x * ga.nw + b.y * ga.ne + b.z * ga.sw + b.w * ga.se + q.x + q.y + q.z + q.w;
+            if (needy) {
+                float4 c2 = *reinterpret_cast<const float4 *>(pl + ga.b01);
+                float4 d2 = *reinterpret_cast<const float4 *>(pl + ga.b11);
+                acc4 += c2.x * ga.nw + c2.y * ga.ne + c2.z * ga.sw + c2.w * ga.se + d2.x + d2.y + d2.z + d2.w;
+            }
+        }
+        A.c0.a[0] = acc4;
     } else if (DBG == 3 || DBG == 4) {   // 3: one 16-byte gather per plane (t00 only); 4: two (t00, t10)
         float acc4 = 0.0f;
         for (int s = 0; s < S; ++s) {
@@ -443,10 +460,12 @@ template <bool HAS_MASK>
 static int dispatch_wc2(int variant, bool tp, const float *rgba, const float *quads, const float *params, int S, int H, int W,
                         float *rgb, float *depth, float *om, float *tm, uint8_t *u8, hipStream_t st)
 {
-    if (variant >= 101 && variant <= 104) {   // bench-only ablations (invalid results)
+    if (variant >= 101 && variant <= 106) {   // bench-only ablations (invalid results)
         dim3 grid(((W + 63) / 64) * ((H + 3) / 4)), block(256);
         if (variant == 101) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 1>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
         else if (variant == 103) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 3>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+        else if (variant == 105) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 5>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
+        else if (variant == 106) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 6>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
         else if (variant == 104) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 4>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
         else hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 2>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
         return mpf_launch_status("k_warp_composite_dbg");
@@ -601,16 +620,20 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
         }
     }
 
-    for (int s = 0; s < S; ++s) {
-        const float *rec = params + MPF_PARAMS_HEADER + RS * s;
-        const bool last = (s + 1 == S);
-        const float dn = last ? 0.0f : rec[RS + 9];
-        float ch[PX][4];
+    // Software pipeline: the 4 channel loads of plane s+1 are issued before plane s is processed (two register sets, x2
+    // unrolled), doubling the bytes each wave keeps in flight - the kernel is pure streaming and latency x bandwidth decides.
+    float chA[PX][4], chB[PX][4];
+    auto load_plane = [&](int s, float (&ch)[PX][4]) {
         const float *pl = mpi + (int64_t)s * 4 * N;
 #pragma unroll
         for (int i = 0; i < PX; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) ch[i][c] = pl[c * N + n[i]];
+    };
+    auto do_plane = [&](int s, const float (&ch)[PX][4]) {
+        const float *rec = params + MPF_PARAMS_HEADER + RS * s;
+        const bool last = (s + 1 == S);
+        const float dn = last ? 0.0f : rec[RS + 9];
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             float nx = ray[i][0] * dn, ny = ray[i][1] * dn, nz = ray[i][2] * dn;
@@ -663,6 +686,21 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { cf[i][p][0].fold(s + 1); cf[i][p][1].fold(s + 1); }
         }
+    };
+    load_plane(0, chA);
+    int s = 0;
+    for (; s + 2 <= S - 1; s += 2) {
+        load_plane(s + 1, chB);
+        do_plane(s, chA);
+        load_plane(s + 2, chA);
+        do_plane(s + 1, chB);
+    }
+    if (s + 1 < S) {
+        load_plane(s + 1, chB);
+        do_plane(s, chA);
+        do_plane(s + 1, chB);
+    } else {
+        do_plane(s, chA);
     }
     if (P > 0) {
 #pragma unroll

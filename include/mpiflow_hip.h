@@ -150,6 +150,12 @@ int mpf_project3d(const float *d_points_4N, const float *h_P12, float eps, int H
 int mpf_select_truncate(const float *d_p_static, const float *d_z_static, const float *d_p_obj, const float *d_z_obj,
                         const float *d_inst, int H, int W, float *d_p1, float *d_z1, int64_t *d_safe_x,
                         int64_t *d_safe_y, float *d_flow01, void *stream);
+/* moving_obj.py:29-124 and :153 fused into one pass: depth from disparity, back-projection, the static and the object
+ * projection (selected per pixel by the instance mask), pixel units, truncation + clamp, flow = p1 - p0.
+ * inv_K 3x3, P_static = (K.T1)[:3,:], P_obj = (K.Ti)[:3,:] by value from host pointers. */
+int mpf_moving_object_project(const float *d_disp, const float *h_inv_k9, const float *h_P_static12, const float *h_P_obj12,
+                              const float *d_inst, int H, int W, float *d_p1, float *d_z1, int64_t *d_safe_x,
+                              int64_t *d_safe_y, float *d_flow01, void *stream);
 /* Order-preserving parallel equivalent of warping.c:6-33 on device buffers.  d_warped u8 [h,w,5] is fully written
  * (no need to zero it).  d_workspace: mpf_forward_warp_workspace(h,w) bytes of scratch. */
 size_t mpf_forward_warp_workspace(int h, int w);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mpf_backproject": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "mpf_project3d": (c_i, [c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p]),
     "mpf_select_truncate": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "mpf_moving_object_project": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpf_forward_warp_workspace": (c_sz, [c_i, c_i]),
     "mpf_forward_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_sz, c_p]),
     "mpf_warp_masks": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -80,6 +80,70 @@ extern "C" int mpf_select_truncate(const float *d_p_static, const float *d_z_sta
     return mpf_launch_status("k_select_truncate");
 }
 
+// ---- moving_obj.py:29-124 in one pass: depth from disparity, both projections, instance select, truncation -----------
+
+struct MpfMoProj { float ik[9]; float Ps[12]; float Po[12]; };
+
+MPF_DEV void mpf_project_point(const float *P, float X, float Y, float Z, int H, int W, float &nx, float &ny, float &z)
+{
+    float q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = mpf_row4_xyz1(P[4 * c], P[4 * c + 1], P[4 * c + 2], P[4 * c + 3], X, Y, Z);
+    const float den = q[2] + 1e-7f;                                     // geometry.py:70
+    float px = q[0] / den, py = q[1] / den;
+    px = px / (float)(W - 1);                                           // geometry.py:73-74
+    py = py / (float)(H - 1);
+    nx = (px - 0.5f) * 2.0f;                                            // geometry.py:75
+    ny = (py - 0.5f) * 2.0f;
+    z = q[2];
+}
+
+__global__ void __launch_bounds__(256)
+k_moving_object_project(const float *__restrict__ disp, MpfMoProj m, const float *__restrict__ inst, int H, int W,
+                        float *__restrict__ p1, float *__restrict__ z1, int64_t *__restrict__ safe_x, int64_t *__restrict__ safe_y,
+                        float *__restrict__ flow01)
+{
+    const int64_t N = (int64_t)H * W;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float fx = (float)(n % W), fy = (float)(n / W);
+    float dep = 1.0f / (disp[n] + 0.005f);                              // moving_obj.py:29-30
+    dep = (dep > 100.0f) ? 100.0f : dep;
+    float cam[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cam[c] = dep * mpf_row3_xy1(m.ik[3 * c], m.ik[3 * c + 1], m.ik[3 * c + 2], fx, fy);   // geometry.py:42-43
+    const bool sel = inst[n] > 0.0f;                                    // moving_obj.py:108-112
+    float nx, ny, z;
+    if (sel) mpf_project_point(m.Po, cam[0], cam[1], cam[2], H, W, nx, ny, z);
+    else     mpf_project_point(m.Ps, cam[0], cam[1], cam[2], H, W, nx, ny, z);
+    z1[n] = z;
+    const float px = (nx + 1.0f) / 2.0f * (float)(W - 1);               // :115-117
+    const float py = (ny + 1.0f) / 2.0f * (float)(H - 1);
+    p1[2 * n] = px; p1[2 * n + 1] = py;
+    int64_t tx = (int64_t)px, ty = (int64_t)py;                         // :121-122
+    tx = tx > W - 1 ? W - 1 : tx; tx = tx < 0 ? 0 : tx;
+    ty = ty > H - 1 ? H - 1 : ty; ty = ty < 0 ? 0 : ty;
+    safe_x[n] = tx; safe_y[n] = ty;
+    flow01[2 * n] = px - fx;                                            // :153
+    flow01[2 * n + 1] = py - fy;
+}
+
+extern "C" int mpf_moving_object_project(const float *d_disp, const float *h_inv_k9, const float *h_P_static12, const float *h_P_obj12,
+                                         const float *d_inst, int H, int W, float *d_p1, float *d_z1, int64_t *d_safe_x,
+                                         int64_t *d_safe_y, float *d_flow01, void *stream)
+{
+    MPF_REQUIRE(d_disp && h_inv_k9 && h_P_static12 && h_P_obj12 && d_inst && d_p1 && d_z1 && d_safe_x && d_safe_y && d_flow01 &&
+                    H >= 1 && W >= 1, "mpf_moving_object_project: bad argument");
+    MpfMoProj m;
+    memcpy(m.ik, h_inv_k9, sizeof(m.ik));
+    memcpy(m.Ps, h_P_static12, sizeof(m.Ps));
+    memcpy(m.Po, h_P_obj12, sizeof(m.Po));
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_moving_object_project, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_disp, m, d_inst, H, W,
+                       d_p1, d_z1, d_safe_x, d_safe_y, d_flow01);
+    return mpf_launch_status("k_moving_object_project");
+}
+
 // ---- sort -------------------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256)
@@ -113,28 +177,62 @@ k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t 
     hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];      // digit-major, so one linear scan orders the scatter
 }
 
-// exclusive scan of M = RADIX*nb counters by one 1024-thread workgroup (M is ~1e5 at most)
+// exclusive scan of M = RADIX*nb counters by one 1024-thread workgroup, in chunks of 16384 staged through LDS:
+// coalesced global reads/writes, each thread scans 16 consecutive counters in LDS (row pitch 17 words: conflict-free),
+// the 1024 partial sums are scanned with wave shuffles, a running carry links the chunks.
+#define SCAN_PER 16
+#define SCAN_CHUNK (1024 * SCAN_PER)
 __global__ void __launch_bounds__(1024)
 k_scan_exclusive(uint32_t *__restrict__ data, uint32_t M)
 {
-    __shared__ uint32_t part[1024];
-    const uint32_t chunk = (M + 1023) / 1024;
-    const uint32_t b = threadIdx.x * chunk, e = min(b + chunk, M);
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; ++i) s += data[i];
-    part[threadIdx.x] = s;
+    __shared__ uint32_t buf[1024 * (SCAN_PER + 1)];
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    if (t == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {              // Hillis-Steele inclusive scan of the partials
-        uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+    for (uint32_t base = 0; base < M; base += SCAN_CHUNK) {
+        const uint32_t n = min((uint32_t)SCAN_CHUNK, M - base);
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) {
+            const uint32_t i = k * 1024u + t;
+            buf[(i / SCAN_PER) * (SCAN_PER + 1) + (i % SCAN_PER)] = (i < n) ? data[base + i] : 0u;
+        }
         __syncthreads();
-        part[threadIdx.x] += v;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) {
+            const uint32_t v = buf[t * (SCAN_PER + 1) + k];
+            buf[t * (SCAN_PER + 1) + k] = sum;
+            sum += v;
+        }
+        // exclusive scan of `sum` over the 1024 threads: inclusive scan inside each wave, then across the 16 waves
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= (uint32_t)off) inc += o;
+        }
+        if (lane == 63) wave_tot[wv] = inc;
         __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t i = b; i < e; ++i) {
-        uint32_t v = data[i];
-        data[i] = run;
-        run += v;
+        uint32_t wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t v = wave_tot[w];
+            if ((uint32_t)w < wv) wave_off += v;
+            total += v;
+        }
+        const uint32_t off = carry_s + wave_off + (inc - sum);
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) buf[t * (SCAN_PER + 1) + k] += off;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) {
+            const uint32_t i = k * 1024u + t;
+            if (i < n) data[base + i] = buf[(i / SCAN_PER) * (SCAN_PER + 1) + (i % SCAN_PER)];
+        }
+        if (t == 0) carry_s += total;
+        __syncthreads();
     }
 }
 

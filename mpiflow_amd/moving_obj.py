@@ -42,7 +42,6 @@ def moveing_object_with_mask(depth_path, disp, rgb, K, inv_K, instance_mask, i, 
     h, w = rgb.shape[:2]
     dev = disp.device if disp.is_cuda else torch.device("cuda")
     disp_d = disp.to(dev, torch.float32).reshape(h, w)
-    depth = ops.disp_to_depth(disp_d)                                            # :29-30
     K = host_math._cpu32(K).reshape(3, 3)
     inv_K = host_math._cpu32(inv_K).reshape(3, 3)
     K4 = torch.zeros((1, 4, 4)); K4[0, -1, -1] = 1.0; K4[:, :3, :3] = K          # :49-52
@@ -52,10 +51,9 @@ def moveing_object_with_mask(depth_path, disp, rgb, K, inv_K, instance_mask, i, 
     Ti = host_math._cpu32(T_obj).reshape(1, 4, 4)
     P1 = torch.matmul(K4, T1)[:, :3, :][0]                                       # geometry.py:65
     Pi = torch.matmul(K4, Ti)[:, :3, :][0]
-    p_s, z_s = ops.backproject_project(depth, inv_K, P1)                         # :63-66
-    p_o, z_o = ops.backproject_project(depth, inv_K, Pi)                         # :101-105
     inst = instance_mask.to(dev, torch.float32).reshape(h, w)
-    p1, z1, safe_x, safe_y, flow_01 = ops.select_truncate(p_s, z_s, p_o, z_o, inst)      # :108-124, :153
+    # :29-30 depth, :63-66 / :101-105 the two projections, :108-124 select + truncate, :153 flow - one fused kernel
+    p1, z1, safe_x, safe_y, flow_01 = ops.moving_object_project(disp_d, inv_K, P1, Pi, inst)
     img = torch.from_numpy(np.ascontiguousarray(rgb)).to(dev).float().reshape(-1).to(torch.uint8)   # :20, :124
     warped = ops.forward_warp(img, safe_x, safe_y, z1, h, w)                     # :127-129
     masks = ops.warp_masks(warped)                                               # :133-150

@@ -318,6 +318,27 @@ def select_truncate(p_static, z_static, p_obj, z_obj, inst_HW):
     return p1, z1, sx, sy, fl
 
 
+def moving_object_project(disp_HW, inv_K33, P_static34, P_obj34, inst_HW):
+    """Fused moving_obj.py:29-124: -> (p1 [H,W,2], z1 [H,W], safe_x, safe_y int64 [H,W], flow01 [H,W,2])"""
+    lib = _lib.load()
+    disp = _dev(disp_HW, "disp")
+    H, W = disp.shape[-2:]
+    dev = disp.device
+    inst = _dev(inst_HW, "instance mask").reshape(H, W)
+    ik = host_math._cpu32(inv_K33).reshape(9).contiguous()
+    Ps = host_math._cpu32(P_static34).reshape(12).contiguous()
+    Po = host_math._cpu32(P_obj34).reshape(12).contiguous()
+    p1 = torch.empty((H, W, 2), dtype=_f32, device=dev)
+    z1 = torch.empty((H, W), dtype=_f32, device=dev)
+    sx = torch.empty((H, W), dtype=torch.int64, device=dev)
+    sy = torch.empty((H, W), dtype=torch.int64, device=dev)
+    fl = torch.empty((H, W, 2), dtype=_f32, device=dev)
+    _lib.check(lib.mpf_moving_object_project(_ptr(disp.reshape(H, W)), ctypes.c_void_p(ik.data_ptr()), ctypes.c_void_p(Ps.data_ptr()),
+                                             ctypes.c_void_p(Po.data_ptr()), _ptr(inst), H, W, _ptr(p1), _ptr(z1), _ptr(sx), _ptr(sy),
+                                             _ptr(fl), _stream()), "mpf_moving_object_project")
+    return p1, z1, sx, sy, fl
+
+
 def forward_warp(src_u8, idx_i64, idy_i64, z_f32, h, w):
     """Device-resident forward splat, byte-identical to the reference's serial C.  -> warped u8 [h,w,5]"""
     lib = _lib.load()

@@ -379,3 +379,22 @@ def test_fused_byproducts_equal_standalone_kernels(dev):
     assert torch.equal(v["rgb_u8"], ops.to_u8_bgr(v["rgb"]))
     full = ops.warp_composite(a["rgba"], q1, H_st, k_inv, G, d)          # with depth / tgt_mask: the other kernel body
     assert torch.equal(full["rgb"], v["rgb"]) and torch.equal(full["objmask"], v["objmask"])
+
+
+def test_fused_moving_object_projection_equals_separate_kernels(dev):
+    from mpiflow_amd import host_math, ops
+    g = load_golden("fwarp_small")
+    H, W = int(g["H"]), int(g["W"])
+    K4 = torch.zeros(1, 4, 4); K4[0, 3, 3] = 1; K4[0, :3, :3] = torch.from_numpy(g["K"])
+    T1 = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.zeros(1, 3))
+    P1 = torch.matmul(K4, T1)[0, :3]
+    Pi = torch.matmul(K4, torch.from_numpy(g["T_obj"])[None])[0, :3]
+    disp, inst = T(g["disp"], dev), T(g["inst"], dev)
+    depth = ops.disp_to_depth(disp)
+    ps, zs = ops.backproject_project(depth, g["inv_K"], P1)
+    po, zo = ops.backproject_project(depth, g["inv_K"], Pi)
+    want = ops.select_truncate(ps, zs, po, zo, inst)
+    got = ops.moving_object_project(disp, g["inv_K"], P1, Pi, inst)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert bits_equal(N(got[2]), g["safe_x"]) == 0 and bits_equal(N(got[3]), g["safe_y"]) == 0 and bits_equal(N(got[1]), g["z1"]) == 0

@@ -100,10 +100,7 @@ def moving_object(H, W):
     state = {}
 
     def project():
-        depth = ops.disp_to_depth(disp)
-        ps, zs = ops.backproject_project(depth, iK, P1)
-        po, zo = ops.backproject_project(depth, iK, Pi)
-        state["p"] = ops.select_truncate(ps, zs, po, zo, instd)
+        state["p"] = ops.moving_object_project(disp, iK, P1, Pi, instd)
 
     def warp():
         p1, z1, sx, sy, fl = state["p"]

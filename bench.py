@@ -12,8 +12,8 @@ emits; random poses are fixed per image).  Per pair, two launches:
                           reference's camera-only call passes an all-ones mask through the same 8-channel warp)
     mpf_warp_composite   Stage B  : 64-plane homography warp + front-to-back composite  <- dominant / roofline kernel
                          (+ fused: rendered frame as uint8 BGR; rendered object mask)
-Images are independent, so ranks share nothing; the only collective is the end-of-step statistics all-reduce
-(RCCL over xGMI under torchrun).  `value` = pairs rendered by all ranks / max-over-ranks wall time.
+Images are independent, so ranks share nothing; the only collective is the end-of-batch statistics all-reduce
+(RCCL over xGMI under torchrun), issued once after the K timed steps, inside the timed region.  `value` = pairs rendered by all ranks / max-over-ranks wall time.
 
 `roofline`: Stage B's algorithmic bytes (16*S*N) over its mean launch duration, measured with HIP
 events recorded on the launch stream around every Stage B launch inside the timed region; peak 8.0 TB/s.
@@ -25,6 +25,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required for RCCL between processes on this driver
 
 import numpy as np
 import torch
@@ -57,13 +59,18 @@ def init_dist(n):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (CPU-less CI of the multi-process path on a 1-GPU box): MPIFLOW_DIST_BACKEND=gloo, MPIFLOW_FORCE_DEVICE=0
+    backend = os.environ.get("MPIFLOW_DIST_BACKEND", "nccl")
+    if "MPIFLOW_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["MPIFLOW_FORCE_DEVICE"])
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     return rank, world, local
 
 
@@ -152,9 +159,7 @@ def main():
         if NS > 1:
             for s_ in streams:
                 main.wait_stream(s_)
-        st = pipeline.empty_stats()
-        st["pairs"] = B
-        return pipeline.reduce_stats(st)
+        return B
 
     def barrier():
         if world > 1:
@@ -167,17 +172,18 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    total_pairs = 0
+    st = pipeline.empty_stats()
     for _ in range(a.steps):
-        st = step(True)
-        total_pairs += int(st["pairs"])
+        st["pairs"] += step(True)
+    # end-of-batch statistics: the ONE collective of the path (SUM / MAX all-reduce of a 7-float vector, RCCL over xGMI)
+    total_pairs = int(pipeline.reduce_stats(st)["pairs"])
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     else:

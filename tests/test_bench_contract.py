@@ -1,0 +1,49 @@
+"""bench.py contract on a GPU box: one JSON line with the required keys (N=1), and the multi-process code path
+(rendezvous, barrier, end-of-batch all-reduce, max-over-ranks timing, rank-0 print) with two ranks sharing GPU 0 over gloo -
+the real N>1 runs use RCCL, which refuses two ranks on one device."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--planes", "16", "--height", "64", "--width", "96", "--images", "2", "--steps", "3", "--warmup", "1", "--cpu-pairs", "2"]
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline"}
+
+
+def _last_json(out):
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+def test_single_gpu_line():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+
+
+def test_two_rank_path_over_gloo():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6     # all ranks' pairs / max time

@@ -12,11 +12,13 @@ What is different:
   * images are sharded over ranks when launched under torchrun (rank r takes images i = r mod world); every rank
     replays the whole RNG schedule, so an N-GPU run produces exactly the files of a 1-GPU run; one all-reduce of a
     7-float statistics vector (RCCL over xGMI) closes the batch;
-  * the MPI producer: the AdaMPI network (reference model/) is outside this build and its weights
-    are not in the reference tree.  `--mpi-from npz` reads precomputed stacks from base/mpis/NAME.npz
-    (arrays `mpi` [S,4,H,W], `disparity` [S]); `--mpi-from disparity` (default) builds a hard-assignment MPI from the
-    monocular disparity map: every plane carries the image colours, the plane nearest to the pixel's disparity is
-    opaque.  Both feed the identical render path.
+  * the MPI producer: `--mpi-from model` runs the AdaMPI network (mpiflow_amd.model, state-dict compatible with the
+    reference's checkpoints: `--ckpt_path adampi_64p.pth`, or `--ckpt_path random:SEED` for deterministic random weights -
+    the published weights are not in the reference tree); its raw last-layer output is handed to Stage A+C, which applies
+    the activation epilogue in registers.  `--mpi-from npz` reads precomputed stacks from base/mpis/NAME.npz (arrays `mpi`
+    [S,4,H,W], `disparity` [S]); `--mpi-from disparity` (default) builds a hard-assignment MPI from the monocular disparity
+    map: every plane carries the image colours, the plane nearest to the pixel's disparity is opaque.  All three feed the
+    identical render path.
 """
 import argparse
 import os
@@ -45,7 +47,8 @@ def parse(argv=None):
     p.add_argument("--base", type=str, required=True)
     p.add_argument("--out", type=str, required=True)
     p.add_argument("--planes", type=int, default=64)
-    p.add_argument("--mpi-from", choices=["disparity", "npz"], default="disparity")
+    p.add_argument("--mpi-from", choices=["disparity", "npz", "model"], default="disparity")
+    p.add_argument("--model-dtype", choices=["fp32", "fp16", "bf16"], default="fp32", help="autocast dtype of the network's convolutions")
     p.add_argument("--inpaint", choices=["auto", "cv2", "hip", "none"], default="auto")
     opt, _ = p.parse_known_args(argv)
     return opt
@@ -92,6 +95,15 @@ def main(argv=None):
 
     img_base, disp_base, mask_base = (os.path.join(opt.base, d) for d in ("images", "disps", "masks"))
     names = sorted(os.listdir(img_base))
+    model = None
+    if opt.mpi_from == "model":
+        from mpiflow_amd.model import MPIPredictor
+        if opt.ckpt_path.startswith("random:"):
+            model = MPIPredictor(opt.width, opt.height, opt.planes).randomize_(int(opt.ckpt_path.split(":")[1])).eval().to(dev)
+        else:
+            model = MPIPredictor.from_checkpoint(opt.ckpt_path, opt.width, opt.height).to(dev)      # :52-60
+            opt.planes = model.num_planes
+    amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype)
     renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
     stats = pipeline.empty_stats()
     t_start = time.perf_counter()
@@ -106,9 +118,14 @@ def main(argv=None):
             disp = U.disparity_to_tensor(os.path.join(disp_base, img)).to(dev)
             image = F.interpolate(image, size=(opt.height, opt.width), mode="bilinear", align_corners=True)   # :86-89
             disp = F.interpolate(disp, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
+            cum_mask = None
             if opt.mpi_from == "npz":
                 z = np.load(os.path.join(opt.base, "mpis", name + ".npz"))
                 mpi, planes = torch.from_numpy(z["mpi"]).to(dev), torch.from_numpy(z["disparity"]).to(dev)
+            elif opt.mpi_from == "model":
+                with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):      # :92-93
+                    raw, cm, pd = model(image, disp, raw=True)
+                mpi, cum_mask, planes = raw[0].float().contiguous(), cm[0].float().contiguous(), pd[0].float()
             else:
                 mpi, planes = mpi_from_disparity(image[0], disp[0, 0], opt.planes)
         for r in range(opt.repeat):
@@ -121,7 +138,8 @@ def main(argv=None):
             obj_mask = torch.from_numpy((obj_mask_np == obj_index).astype(np.float32)).to(dev)[None, None]    # :102-105
             obj_mask = F.interpolate(obj_mask, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
             t0 = time.perf_counter()
-            res = pipeline.render_pair(image[0], obj_mask[0, 0], mpi, planes, K, cam_ext, cam_ext_dynamic, renderer=renderer)
+            res = pipeline.render_pair(image[0], obj_mask[0, 0], mpi, planes, K, cam_ext, cam_ext_dynamic, renderer=renderer,
+                                       cum_mask=cum_mask)
             inpainted = U._inpaint(res["frame_mix"], res["fill_mask"], opt.inpaint)
             torch.cuda.synchronize()
             st = pipeline.pair_stats(res["flow_mix"], res["fill_mask"])

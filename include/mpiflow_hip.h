@@ -66,11 +66,14 @@ int mpf_tune(const char *key, int value);
  *   d_out_rgb_planar [S,3,H,W];  d_out_tacc [S,H,W] (= "blend_weights");  d_flows [P,2,H,W], clipped to
  *   +-flow_clip when flow_clip > 0 (utils/utils.py:348).
  *   Per-pixel by-products fused into the same pass (each NULL to skip): d_src_u8_bgr [H,W,3] = the source frame as uint8
- *   BGR (utils/utils.py:174-177);  d_quads / d_quads_complement = mpf_build_mask_quads(d_obj_mask, 0 / 1). */
+ *   BGR (utils/utils.py:174-177);  d_quads / d_quads_complement = mpf_build_mask_quads(d_obj_mask, 0 / 1).
+ *   d_cum_mask [S,H,W] (NULL = d_mpi is already activated): d_mpi then holds the RAW last-layer output of the AdaMPI
+ *   decoder and the network's activation epilogue (model/CPN/decoder.py:166-173: rgb = sigmoid(x), sigma = relu(x * cum_mask)
+ *   + 1e-4) is applied in registers while the stack is streamed. */
 int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const float *d_params, int P, int S, int H, int W,
                        float flow_clip, float *d_out_rgba, float *d_out_rgb_planar, float *d_out_tacc,
                        float *d_flows, uint8_t *d_src_u8_bgr, const float *d_obj_mask, float *d_quads,
-                       float *d_quads_complement, void *stream);
+                       float *d_quads_complement, const float *d_cum_mask, void *stream);
 
 /* obj_mask [H,W] -> per-texel quads (m[y,x], m[y,x+1], m[y+1,x], m[y+1,x+1]) as float4 [H,W,4], out-of-range
  * neighbours 0, of (complement ? 1 - m : m): the four bilinear taps of the mask channel in one 16-byte load.

@@ -27,7 +27,7 @@ SIGNATURES = {
     "mpf_version": (c_i, []),
     "mpf_last_error": (ctypes.c_char_p, []),
     "mpf_device_info": (c_i, [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_sz), ctypes.c_char_p, c_sz]),
-    "mpf_src_blend_flow": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "mpf_src_blend_flow": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpf_build_mask_quads": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "mpf_warp_composite": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpf_merge": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),

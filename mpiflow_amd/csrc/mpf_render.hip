@@ -565,12 +565,16 @@ extern "C" int mpf_build_mask_quads(const float *d_obj_mask, int complement, int
 #ifndef MPF_NT_STORE
 #define MPF_NT_STORE 1   // stream the 629 MB blended stack past the caches: Stage B re-reads it from HBM anyway, and dirty lines left in L2/MALL only delay it
 #endif
-template <int PX, int P, int NL, bool NT_STORE = (MPF_NT_STORE != 0)>
+// ACT: d_mpi holds the RAW last-layer output of the AdaMPI decoder and cum_mask [S,H,W] its cumulative feature mask; the
+// activation epilogue of the network (reference model/CPN/decoder.py:166-173: rgb = sigmoid(x), sigma = relu(x * cum_mask) + 1e-4)
+// is applied here in registers, so the producer never writes / re-reads an activated copy of the 629 MB stack.
+template <int PX, int P, int NL, bool ACT = false, bool NT_STORE = (MPF_NT_STORE != 0)>
 __global__ void __launch_bounds__(256)
 k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, const float *__restrict__ params, int S,
                  int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
                  float *__restrict__ out_tacc, float *__restrict__ flows, int64_t T, uint8_t *__restrict__ src_u8,
-                 const float *__restrict__ obj_mask, float4 *__restrict__ quads, float4 *__restrict__ quads_c)
+                 const float *__restrict__ obj_mask, float4 *__restrict__ quads, float4 *__restrict__ quads_c,
+                 const float *__restrict__ cum_mask)
 {
     const int64_t N = (int64_t)H * W;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -626,9 +630,16 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
     auto load_plane = [&](int s, float (&ch)[PX][4]) {
         const float *pl = mpi + (int64_t)s * 4 * N;
 #pragma unroll
-        for (int i = 0; i < PX; ++i)
+        for (int i = 0; i < PX; ++i) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) ch[i][c] = pl[c * N + n[i]];
+            if (ACT) {
+                const float cm = cum_mask[(int64_t)s * N + n[i]];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ch[i][c] = 1.0f / (1.0f + mpf_expf_fast(-ch[i][c]));
+                ch[i][3] = fmaxf(ch[i][3] * cm, 0.0f) + 1e-4f;
+            }
+        }
     };
     auto do_plane = [&](int s, const float (&ch)[PX][4]) {
         const float *rec = params + MPF_PARAMS_HEADER + RS * s;
@@ -719,17 +730,16 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
 template <int PX, int P>
 static int launch_sbf(const float *mpi, const float *img, const float *params, int S, int H, int W, float clip,
                       float *rgba, float *planar, float *tacc, float *flows, uint8_t *src_u8, const float *om, float *q0, float *q1,
-                      hipStream_t st)
+                      const float *cum_mask, hipStream_t st)
 {
     const int64_t N = (int64_t)H * W;
     const int64_t T = (N + PX - 1) / PX;
     dim3 grid((unsigned)((T + 255) / 256)), block(256);
-    if (S < 256)
-        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 2>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows, T, src_u8, om,
-                           reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1));
-    else
-        hipLaunchKernelGGL((k_src_blend_flow<PX, P, 3>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, tacc, flows, T, src_u8, om,
-                           reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1));
+#define MPF_SBF_GO(NLv, ACTv) hipLaunchKernelGGL((k_src_blend_flow<PX, P, NLv, ACTv>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, \
+                                              tacc, flows, T, src_u8, om, reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1), cum_mask)
+    if (S < 256) { if (cum_mask) MPF_SBF_GO(2, true); else MPF_SBF_GO(2, false); }
+    else         { if (cum_mask) MPF_SBF_GO(3, true); else MPF_SBF_GO(3, false); }
+#undef MPF_SBF_GO
     return mpf_launch_status("k_src_blend_flow");
 }
 
@@ -738,7 +748,7 @@ static int g_sbf_px = 0;   // 0 = auto; tuning knob for benches (mpf_tune)
 extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const float *d_params, int P, int S, int H, int W,
                                   float flow_clip, float *d_out_rgba, float *d_out_rgb_planar, float *d_out_tacc,
                                   float *d_flows, uint8_t *d_src_u8_bgr, const float *d_obj_mask, float *d_quads,
-                                  float *d_quads_complement, void *stream)
+                                  float *d_quads_complement, const float *d_cum_mask, void *stream)
 {
     MPF_REQUIRE(d_mpi && d_img && d_params, "mpf_src_blend_flow: null pointer");
     MPF_REQUIRE((d_quads == nullptr && d_quads_complement == nullptr) || d_obj_mask, "mpf_src_blend_flow: quads need d_obj_mask");
@@ -756,9 +766,9 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
     }
 #define MPF_SBF(PXv)                                                                                                     \
     switch (P) {                                                                                                         \
-    case 0: return launch_sbf<PXv, 0>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, st); \
-    case 1: return launch_sbf<PXv, 1>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, st); \
-    default: return launch_sbf<PXv, 2>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, st); \
+    case 0: return launch_sbf<PXv, 0>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, d_cum_mask, st); \
+    case 1: return launch_sbf<PXv, 1>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, d_cum_mask, st); \
+    default: return launch_sbf<PXv, 2>(d_mpi, d_img, d_params, S, H, W, flow_clip, d_out_rgba, d_out_rgb_planar, d_out_tacc, d_flows, d_src_u8_bgr, (d_quads || d_quads_complement) ? d_obj_mask : nullptr, d_quads, d_quads_complement, d_cum_mask, st); \
     }
     if (px == 2) { MPF_SBF(2) }
     MPF_SBF(1)

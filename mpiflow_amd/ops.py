@@ -58,10 +58,11 @@ def warp_params(H_src_tgt, K_inv, G, depth_S):
 
 def src_blend_flow(mpi_S4HW, img_3HW, K_inv=None, depth_S=None, homs_tgt_src=None, flow_clip=200.0,
                    want_rgba=True, want_planar=False, want_tacc=False, out_rgba=None, out_flows=None,
-                   dparams=None, P=None, src_u8=None, obj_mask=None, quads=None, quads_complement=None):
+                   dparams=None, P=None, src_u8=None, obj_mask=None, quads=None, quads_complement=None, cum_mask=None):
     """Stage A + C.  homs_tgt_src: None or [P,S,3,3] CPU (P <= 2), or pass a pre-uploaded `dparams` + P.
     Fused by-products (preallocated outputs, optional): src_u8 [H,W,3] u8 BGR source frame; quads / quads_complement
-    [H,W,4] = mask_quads(obj_mask, False / True).  Returns dict(rgba, rgb_planar, tacc, flows)."""
+    [H,W,4] = mask_quads(obj_mask, False / True).  cum_mask [S,H,W]: `mpi` is the RAW decoder output and the network's
+    activation epilogue (sigmoid / relu(x*cum_mask)+1e-4) is fused into this pass.  Returns dict(rgba, rgb_planar, tacc, flows)."""
     lib = _lib.load()
     mpi = _dev(mpi_S4HW, "mpi")
     S, C, H, W = mpi.shape
@@ -77,7 +78,8 @@ def src_blend_flow(mpi_S4HW, img_3HW, K_inv=None, depth_S=None, homs_tgt_src=Non
     _lib.check(lib.mpf_src_blend_flow(_ptr(mpi), _ptr(img), _ptr(dparams), P, S, H, W, float(flow_clip), _ptr(rgba),
                                       _ptr(planar), _ptr(tacc), _ptr(flows), _ptr(src_u8),
                                       _ptr(_dev(obj_mask, "obj_mask").reshape(H, W)) if obj_mask is not None else None,
-                                      _ptr(quads), _ptr(quads_complement), _stream()), "mpf_src_blend_flow")
+                                      _ptr(quads), _ptr(quads_complement),
+                                      _ptr(_dev(cum_mask, "cum_mask")) if cum_mask is not None else None, _stream()), "mpf_src_blend_flow")
     return dict(rgba=rgba, rgb_planar=planar, tacc=tacc, flows=flows)
 
 

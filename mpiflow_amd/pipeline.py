@@ -54,23 +54,24 @@ class PairRenderer:
         return dict(P=P, blend=ops.upload_params(bf, self.device), warp=wp)
 
     # -- device side: launches only ------------------------------------------------------------------------------------
-    def run(self, mpi, image, prep, obj_mask, complement=(False, True)):
+    def run(self, mpi, image, prep, obj_mask, complement=(False, True), cum_mask=None):
         """mpi [S,4,H,W], image [3,H,W], obj_mask [H,W] on device.  Two or three launches:
           Stage A+C (+ source frame as u8, + mask quads of obj_mask and 1 - obj_mask), then one Stage B per view
-          (view v samples 1 - obj_mask when complement[v]; + its frame as u8).  Returns (flows [P,2,H,W], views)."""
+          (view v samples 1 - obj_mask when complement[v]; + its frame as u8).  cum_mask [S,H,W]: `mpi` is the raw decoder
+          output of the AdaMPI network and its activation epilogue is fused into Stage A+C.  Returns (flows [P,2,H,W], views)."""
         P = prep["P"]
         need_c = any(complement[:P])
         need_p = not all(complement[:P])
         ops.src_blend_flow(mpi, image, out_rgba=self.rgba, out_flows=self.flows[:P], dparams=prep["blend"], P=P,
                            src_u8=self.src_u8, obj_mask=obj_mask, quads=self.quads[0] if need_p else None,
-                           quads_complement=self.quads[1] if need_c else None)
+                           quads_complement=self.quads[1] if need_c else None, cum_mask=cum_mask)
         for v in range(P):
             ops.warp_composite(self.rgba, self.quads[1 if complement[v] else 0], dparams=prep["warp"][v], out=self.views[v],
                                interleaved=2)
         return self.flows, self.views
 
 
-def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, thresh=MASK_THRESH, renderer=None):
+def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, thresh=MASK_THRESH, renderer=None, cum_mask=None):
     """Everything render_3dphoto_dynamic does up to the inputs of cv2.inpaint (reference utils/utils.py:159-283), for
     explicit poses: G_cam renders with obj_mask, G_dyn with 1 - obj_mask (sic - SURVEY §3.2).  Device tensors in/out."""
     mpi = mpi_S4HW
@@ -78,7 +79,7 @@ def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, 
     r = renderer or PairRenderer(S, H, W, mpi.device)
     om = obj_mask_HW.reshape(H, W).to(torch.float32)
     prep = r.prepare(K, disparity_S, [G_cam, G_dyn])
-    flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, om)
+    flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, om, cum_mask=cum_mask)
     flow_mix, frame_mix, fill = ops.merge(views[0]["rgb"], views[1]["rgb"], views[0]["objmask"], views[1]["objmask"],
                                           flows[0], flows[1], om, thresh)
     return dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill, src_np=r.src_u8,

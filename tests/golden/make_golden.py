@@ -330,6 +330,24 @@ def gen_geometry(seed=11):
          cam_points=cam.detach().numpy(), pix=pix.detach().numpy(), z=z.detach().numpy(), T=M[0])
 
 
+def gen_model(S=4, H=128, W=128, seed=0):
+    """AdaMPI network (N1): the REFERENCE model/AdaMPI.py, loaded (strict) with the deterministic parameters that
+    mpiflow_amd.model.MPIPredictor.randomize_(seed) produces, run on CPU fp32."""
+    from model.AdaMPI import MPIPredictor as RefModel
+    from mpiflow_amd.model import MPIPredictor
+    mine = MPIPredictor(W, H, S).randomize_(seed)
+    ref = RefModel(width=W, height=H, num_planes=S)
+    ref.load_state_dict(mine.state_dict(), strict=True)
+    ref.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    img, dsp = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 1, H, W, generator=g)
+    with torch.no_grad():
+        mpi, disp = ref(img, dsp)
+    save("model_adampi", S=S, H=H, W=W, seed=seed, image=img.numpy(), disp=dsp.numpy(), plane_disp=disp.numpy(),
+         mpi_sub=mpi[0, :, :, ::2, ::2].numpy(), mpi_sum=np.array(mpi.double().sum().item()),
+         n_state=len(ref.state_dict()), sha_keys=np.array(sha(np.frombuffer("|".join(sorted(ref.state_dict())).encode(), np.uint8))))
+
+
 JOBS = {
     "tiny": lambda: (gen_small("tiny_white", 8, 32, 48, "white", 1, 7, True),
                      gen_small("tiny_smooth", 8, 32, 48, "smooth", 2, 8, True)),
@@ -343,6 +361,7 @@ JOBS = {
     "exp": gen_exp,
     "pose": gen_pose_schedule,
     "geometry": gen_geometry,
+    "model": gen_model,
 }
 
 if __name__ == "__main__":

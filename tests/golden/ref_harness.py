@@ -69,14 +69,82 @@ def _install_cv2_stub():
     sys.modules["cv2"] = cv2
 
 
+def _torchvision_models_stub():
+    """Stand-in for the absent third-party `torchvision.models` - only what model/CPN/encoder.py touches: the `ResNet`
+    base class (constructor signature, `_make_layer`, module names conv1/bn1/relu/maxpool/layer1-4/avgpool/fc) and
+    `resnet.BasicBlock` / `resnet.Bottleneck`, following torchvision's published layout so that state-dict keys match."""
+    import torch.nn as nn
+    mod = types.ModuleType("torchvision.models")
+    res = types.ModuleType("torchvision.models.resnet")
+
+    class BasicBlock(nn.Module):
+        expansion = 1
+
+        def __init__(self, inplanes, planes, stride=1, downsample=None):
+            super().__init__()
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.downsample = downsample
+            self.stride = stride
+
+        def forward(self, x):
+            identity = x
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            if self.downsample is not None:
+                identity = self.downsample(x)
+            out += identity
+            return self.relu(out)
+
+    class Bottleneck(nn.Module):
+        expansion = 4
+
+    class ResNet(nn.Module):
+        def __init__(self, block, layers, num_classes=1000):
+            super().__init__()
+            self.inplanes = 64
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            self.layer1 = self._make_layer(block, 64, layers[0])
+            self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+            self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+            self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(512 * block.expansion, num_classes)
+
+        def _make_layer(self, block, planes, blocks, stride=1):
+            downsample = None
+            if stride != 1 or self.inplanes != planes * block.expansion:
+                downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                           nn.BatchNorm2d(planes * block.expansion))
+            layers = [block(self.inplanes, planes, stride, downsample)]
+            self.inplanes = planes * block.expansion
+            for _ in range(1, blocks):
+                layers.append(block(self.inplanes, planes))
+            return nn.Sequential(*layers)
+
+    res.BasicBlock, res.Bottleneck, res.ResNet = BasicBlock, Bottleneck, ResNet
+    mod.ResNet, mod.resnet = ResNet, res
+    for n in ("resnet18", "resnet34", "resnet50", "resnet101", "resnet152"):
+        setattr(mod, n, None)            # only used as dictionary values in ResnetEncoder.__init__
+    return mod, res
+
+
 def _install_torchvision_stub():
     tv = types.ModuleType("torchvision")
     tr = types.ModuleType("torchvision.transforms")
     ut = types.ModuleType("torchvision.utils")
     tr.ToTensor = lambda: (lambda im: torch.from_numpy(np.asarray(im)).permute(2, 0, 1).float() / 255)
     ut.save_image = lambda *a, **k: None
-    tv.transforms, tv.utils = tr, ut
-    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.utils": ut})
+    mod, res = _torchvision_models_stub()
+    tv.transforms, tv.utils, tv.models = tr, ut, mod
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.utils": ut,
+                        "torchvision.models": mod, "torchvision.models.resnet": res})
 
 
 _installed = False

@@ -43,7 +43,7 @@ def test_bad_arguments_return_error_codes(built):
     rc = lib.mpf_warp_composite(None, 1, None, None, 4, 8, 8, None, None, None, None, None, None)
     assert rc == 10001 and b"null pointer" in lib.mpf_last_error()
     one = ctypes.c_void_p(256)
-    rc = lib.mpf_src_blend_flow(one, one, one, 3, 4, 8, 8, 0.0, None, None, None, None, None, None, None, None, None)
+    rc = lib.mpf_src_blend_flow(one, one, one, 3, 4, 8, 8, 0.0, None, None, None, None, None, None, None, None, None, None)
     assert rc == 10001 and b"P must be" in lib.mpf_last_error()
     rc = lib.mpf_warp_composite(one, 1, None, one, 5000, 8, 8, one, None, None, None, None, None)
     assert rc == 10001 and b"bad shape" in lib.mpf_last_error()

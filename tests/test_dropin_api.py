@@ -213,3 +213,27 @@ def test_cli_end_to_end(dev, tmp_path):
     flow = io_formats.read_flo(str(outs[0] / "flows" / "im0_0.flo"))
     assert flow.shape == (48, 64, 2) and np.isfinite(flow).all() and float(np.abs(flow).max()) > 0.1
     assert Image.open(outs[0] / "dst_images" / "im0_0.png").size == (64, 48)
+
+
+def test_cli_with_network_producer(dev, tmp_path):
+    """--mpi-from model with deterministic random weights: the network's raw output goes through the fused epilogue."""
+    import subprocess, sys, os
+    from PIL import Image
+    from mpiflow_amd import io_formats
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = tmp_path / "data"
+    for d in ("images", "disps", "masks"):
+        (base / d).mkdir(parents=True)
+    rs = np.random.RandomState(1)
+    Image.fromarray((rs.rand(100, 140, 3) * 255).astype(np.uint8)).save(base / "images" / "a.png")
+    Image.fromarray((rs.rand(100, 140) * 255).astype(np.uint8)).save(base / "disps" / "a.png")
+    m = np.zeros((100, 140), np.uint8); m[30:60, 40:90] = 1
+    Image.fromarray(m).save(base / "masks" / "a.png")
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--base", str(base), "--out", str(out), "--width", "128",
+                        "--height", "128", "--repeat", "1", "--planes", "8", "--inpaint", "hip", "--mpi-from", "model", "--ckpt_path", "random:3"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    flow = io_formats.read_flo(str(out / "flows" / "a_0.flo"))
+    assert flow.shape == (128, 128, 2) and np.isfinite(flow).all()
+    assert Image.open(out / "dst_images" / "a_0.png").size == (128, 128)

@@ -237,14 +237,14 @@ def src_blend_flow(mpi_S4HW, img_3HW, K_inv, depth_S, hom_tgt_src_PS33, flow_cli
     mpi = _c(mpi_S4HW)
     S, _, H, W = mpi.shape
     img = _c(img_3HW).reshape(3, H, W)
-    hom = _c(hom_tgt_src_PS33).reshape(-1, S, 9)
+    hom = np.zeros((0, S, 9), np.float32) if hom_tgt_src_PS33 is None else _c(hom_tgt_src_PS33).reshape(-1, S, 9)
     P = hom.shape[0]
     k = _c(K_inv).reshape(9)
     d = _c(depth_S).reshape(S)
     rgba = np.empty((S, H, W, 4), np.float32) if want_rgba else None
     planar = np.empty((S, 3, H, W), np.float32) if want_planar else None
     tacc = np.empty((S, H, W), np.float32) if want_tacc else None
-    flows = np.empty((P, 2, H, W), np.float32)
+    flows = np.empty((max(P, 1), 2, H, W), np.float32)[:P]
     lib().orc_src_blend_flow(_p(mpi), _p(img), _p(k), _p(d), _p(hom), P, S, H, W, ctypes.c_float(flow_clip),
                              _p(rgba), _p(planar), _p(tacc), _p(flows))
     return dict(rgba=rgba, rgb_planar=planar, tacc=tacc, flows=flows)

@@ -398,3 +398,66 @@ def test_fused_moving_object_projection_equals_separate_kernels(dev):
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert bits_equal(N(got[2]), g["safe_x"]) == 0 and bits_equal(N(got[3]), g["safe_y"]) == 0 and bits_equal(N(got[1]), g["z1"]) == 0
+
+
+@pytest.mark.parametrize("S,H,W", [(2, 9, 70), (3, 5, 33), (4, 1, 64), (6, 64, 1)])
+def test_short_stacks_and_degenerate_shapes(dev, kernel_exp, S, H, W):
+    """S = 2, 3, 4 exercise every exit of the x2-unrolled ping-pong plane loop; 1-pixel-high / 1-pixel-wide images the clamps."""
+    from mpiflow_amd import pipeline
+    o = kernel_exp
+    inp = _inputs(S, H, W, seed=S * 31 + W)
+    G_cam, G_dyn = _poses(o, S * 5 + H)
+    out = pipeline.render_pair(T(inp["image"], dev), T(inp["obj_mask"], dev), T(inp["mpi"], dev), inp["disparity"], inp["K"], G_cam, G_dyn)
+    ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
+    for k in ("flow_mix", "frame_mix", "fill_mask", "src_np"):
+        assert bits_equal(N(out[k]), ref[k]) == 0, k
+    assert bits_equal(N(out["view_cam"]["rgb"]), ref["view_cam"]["rgb"]) == 0
+    assert bits_equal(N(out["view_dyn"]["objmask"]), ref["view_dyn"]["objmask"]) == 0
+
+
+def test_general_intrinsics_take_the_dense_k_inverse_path(dev, kernel_exp):
+    """A skewed K (K[0,1] != 0) disables the pinhole shortcut in Stage B: the dense 3x3 chain must still match the oracle."""
+    from mpiflow_amd import ops
+    o = kernel_exp
+    S, H, W = 12, 40, 56
+    inp = _inputs(S, H, W, seed=77)
+    K = inp["K"].copy()
+    K[0, 1] = 3.5
+    K[1, 0] = 0.25
+    G_cam, G_dyn = _poses(o, 41)
+    d = o.plane_depths(inp["disparity"])
+    k_inv = o.k_inverse(K)
+    assert k_inv[0, 1] != 0
+    Hts, Hst = o.homographies(G_dyn, k_inv, K, d)
+    ref = o.src_blend_flow(inp["mpi"], inp["image"], k_inv, d, Hts[None])
+    got = ops.src_blend_flow(T(inp["mpi"], dev), T(inp["image"], dev), k_inv, d, Hts[None])
+    assert bits_equal(N(got["rgba"]), ref["rgba"]) == 0 and bits_equal(N(got["flows"]), ref["flows"]) == 0
+    want = o.warp_composite(ref["rgba"], inp["obj_mask"], Hst, k_inv, G_dyn, d)
+    q = ops.mask_quads(T(inp["obj_mask"], dev))
+    for layout, rgba in ((1, got["rgba"]), (2, None)):
+        if layout == 2:
+            rgba = ops.alloc_rgba_stack(S, H, W, dev)
+            rgba.copy_(got["rgba"])
+        have = ops.warp_composite(rgba, q, Hst, k_inv, G_dyn, d, interleaved=layout)
+        for k in ("rgb", "depth", "objmask", "tgt_mask"):
+            assert bits_equal(N(have[k]), want[k]) == 0, (k, layout)
+
+
+def test_inputs_of_other_dtypes_and_strides_are_promoted(dev, kernel_exp):
+    """The reference's GPU run hands .half() tensors and strided views to the path; the wrappers promote to contiguous fp32."""
+    from mpiflow_amd import ops
+    o = kernel_exp
+    S, H, W = 6, 24, 40
+    inp = _inputs(S, H, W, seed=5)
+    mpi16 = T(inp["mpi"], dev).half()
+    img16 = T(inp["image"], dev).half()
+    d = o.plane_depths(inp["disparity"])
+    k_inv = o.k_inverse(inp["K"])
+    ref = o.src_blend_flow(mpi16.float().cpu().numpy(), img16.float().cpu().numpy(), k_inv, d, None)
+    got = ops.src_blend_flow(mpi16, img16, k_inv, d, None)
+    assert bits_equal(N(got["rgba"]), ref["rgba"]) == 0
+    big = torch.zeros((S, 6, H, W), device=dev)
+    big[:, 1:5] = T(inp["mpi"], dev)
+    got2 = ops.src_blend_flow(big[:, 1:5], T(inp["image"], dev), k_inv, d, None)          # non-contiguous view
+    ref2 = o.src_blend_flow(inp["mpi"], inp["image"], k_inv, d, None)
+    assert bits_equal(N(got2["rgba"]), ref2["rgba"]) == 0

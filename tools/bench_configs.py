@@ -71,9 +71,23 @@ def config(name, S, H, W, dynamic):
             b(1)
             merge()
 
+    s2 = torch.cuda.Stream(device=dev)
+
+    def pair_two_streams():          # both views of a dynamic pair concurrently: plane s is fetched from HBM once, the other view finds it in L2/MALL
+        ac()
+        main = torch.cuda.current_stream()
+        s2.wait_stream(main)
+        b(0)
+        with torch.cuda.stream(s2):
+            b(1)
+        main.wait_stream(s2)
+        merge()
+
     ac(); b(0)
     t_ac, t_b = timed(ac), timed(lambda: b(0))
     t_pair = timed(pair)
+    if dynamic:
+        print("    dynamic pair with the two Stage B views on two streams: %.1f us" % timed(pair_two_streams), flush=True)
     line = "%-3s %3dx%4dx%4d %-11s A+C %7.1f us (%.2f TB/s r+w)  B %7.1f us (%.3f of 8 TB/s)  pair %8.1f us  %7.1f pairs/s" % (
         name, S, H, W, "dynamic" if dynamic else "camera-only", t_ac, (32.0 * S * N) / t_ac / 1e6, t_b, 16.0 * S * N / t_b / 1e6 / 8.0, t_pair, 1e6 / t_pair)
     if dynamic:

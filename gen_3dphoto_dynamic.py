@@ -50,6 +50,7 @@ def parse(argv=None):
     p.add_argument("--mpi-from", choices=["disparity", "npz", "model"], default="disparity")
     p.add_argument("--model-dtype", choices=["fp32", "fp16", "bf16"], default="fp32", help="autocast dtype of the network's convolutions")
     p.add_argument("--inpaint", choices=["auto", "cv2", "hip", "none"], default="auto")
+    p.add_argument("--writers", type=int, default=8, help="writer threads (PNG encode + file I/O overlap the GPU); 0 = synchronous")
     opt, _ = p.parse_known_args(argv)
     return opt
 
@@ -106,6 +107,7 @@ def main(argv=None):
     amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype)
     renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
     stats = pipeline.empty_stats()
+    writer = io_formats.AsyncWriter(threads=opt.writers) if opt.writers > 0 else None
     t_start = time.perf_counter()
     from PIL import Image
     import torch.nn.functional as F
@@ -145,9 +147,16 @@ def main(argv=None):
             st = pipeline.pair_stats(res["flow_mix"], res["fill_mask"])
             st["kernel_seconds"] = time.perf_counter() - t0
             stats = pipeline.merge_stats(stats, st)
-            io_formats.write_flo(os.path.join(out, "flows", f"{name}_{r}.flo"), res["flow_mix"].cpu().numpy())   # :120
-            io_formats.write_png_bgr(os.path.join(out, "dst_images", f"{name}_{r}.png"), inpainted)            # :121
-            io_formats.write_png_bgr(os.path.join(out, "src_images", f"{name}_{r}.png"), res["src_np"].cpu().numpy())
+            jobs = ((io_formats.write_flo, os.path.join(out, "flows", f"{name}_{r}.flo"), res["flow_mix"].cpu().numpy()),        # :120
+                    (io_formats.write_png_bgr, os.path.join(out, "dst_images", f"{name}_{r}.png"), np.array(inpainted)),         # :121
+                    (io_formats.write_png_bgr, os.path.join(out, "src_images", f"{name}_{r}.png"), res["src_np"].cpu().numpy()))  # :122
+            for fn, path, arr in jobs:
+                if writer is not None:
+                    writer.submit(fn, path, arr)
+                else:
+                    fn(path, arr)
+    if writer is not None:
+        writer.close()
     stats["wall_seconds"] = time.perf_counter() - t_start
     total = pipeline.reduce_stats(stats)
     if rank == 0:

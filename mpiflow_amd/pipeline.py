@@ -71,7 +71,25 @@ class PairRenderer:
         return self.flows, self.views
 
 
-def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, thresh=MASK_THRESH, renderer=None, cum_mask=None):
+def hard_flows(mpi_S4HW, disparity_S, K, poses):
+    """hard_flow=True (reference utils/mpi/mpi_rendering.py:126-130): the flow of the arg-max-weight plane instead of the
+    weighted sum.  Off the default path; computed with the generic kernels (per-plane flows are materialised)."""
+    S, _, H, W = mpi_S4HW.shape
+    dev = mpi_S4HW.device
+    k_inv = host_math.k_inverse(K)
+    d = host_math.plane_depths(disparity_S)
+    xyz = ops.src_xyz(k_inv, d, H, W, dev)
+    out = []
+    for G in poses:
+        H_ts, _ = host_math.homographies(G, k_inv, K, d)
+        per_plane = ops.homography_flow(H_ts, H, W, dev).permute(0, 3, 1, 2).contiguous()
+        r = ops.volume_render(None, mpi_S4HW[:, 3].contiguous(), xyz, extra_SEN=per_plane, hard=True, want_tacc=False, want_weights=False)
+        out.append(torch.clip(r["extra"], -200, 200))
+    return torch.stack(out)
+
+
+def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, thresh=MASK_THRESH, renderer=None, cum_mask=None,
+                hard_flow=False):
     """Everything render_3dphoto_dynamic does up to the inputs of cv2.inpaint (reference utils/utils.py:159-283), for
     explicit poses: G_cam renders with obj_mask, G_dyn with 1 - obj_mask (sic - SURVEY §3.2).  Device tensors in/out."""
     mpi = mpi_S4HW
@@ -80,6 +98,9 @@ def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, 
     om = obj_mask_HW.reshape(H, W).to(torch.float32)
     prep = r.prepare(K, disparity_S, [G_cam, G_dyn])
     flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, om, cum_mask=cum_mask)
+    if hard_flow:
+        assert cum_mask is None, "hard_flow needs the activated stack"
+        flows = hard_flows(mpi, disparity_S, K, [G_cam, G_dyn])
     flow_mix, frame_mix, fill = ops.merge(views[0]["rgb"], views[1]["rgb"], views[0]["objmask"], views[1]["objmask"],
                                           flows[0], flows[1], om, thresh)
     return dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill, src_np=r.src_u8,

@@ -76,8 +76,6 @@ def render_3dphoto_dynamic(opt, src_imgs, obj_mask, disp, mpi_all_src, disparity
     :return: (flow_mix [H,W,2] float32, src_np [H,W,3] uint8 BGR, inpainted [H,W,3] uint8 BGR, None) as numpy arrays
     """
     name = name.split(".")[0]
-    if hard_flow:
-        raise NotImplementedError("hard_flow=True is only available through utils.mpi.mpi_rendering (generic path)")
     dev = mpi_all_src.device
     S = mpi_all_src.shape[1]
     h, w = mpi_all_src.shape[-2:]
@@ -85,7 +83,7 @@ def render_3dphoto_dynamic(opt, src_imgs, obj_mask, disp, mpi_all_src, disparity
     cam_ext = generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0])
     out = pipeline.render_pair(src_imgs[0].to(dev, torch.float32), obj_mask.reshape(h, w).to(dev, torch.float32),
                                mpi_all_src[0].to(torch.float32), disparity_all_src[0], k_src, cam_ext, cam_ext_dynamic,
-                               thresh=mask_thresh)
+                               thresh=mask_thresh, hard_flow=hard_flow)
     inpainted = _inpaint(out["frame_mix"], out["fill_mask"], inpaint)
     flow_mix = out["flow_mix"].cpu().numpy()
     src_np = out["src_np"].cpu().numpy()

@@ -330,6 +330,17 @@ def gen_geometry(seed=11):
          cam_points=cam.detach().numpy(), pix=pix.detach().numpy(), z=z.detach().numpy(), T=M[0])
 
 
+def gen_hard_flow(name="hard_flow", S=8, H=24, W=40, seed=6, pose_seed=12):
+    """render_3dphoto_dynamic(..., hard_flow=True): flow of the arg-max-weight plane (mpi_rendering.py:126-130)."""
+    inp = synth.make_inputs(S, H, W, seed=seed, kind="white")
+    mpi = torch.from_numpy(inp["mpi"])[None]
+    random.seed(pose_seed)
+    flow_mix, src_np, _, _ = R.utils.render_3dphoto_dynamic(Opt, torch.from_numpy(inp["image"])[None], torch.from_numpy(inp["obj_mask"])[None, None],
+                                                            None, mpi, torch.from_numpy(inp["disparity"])[None], torch.from_numpy(inp["K"])[None],
+                                                            torch.from_numpy(inp["K"])[None], name="g", hard_flow=True)
+    save(name, S=S, H=H, W=W, seed=seed, pose_seed=pose_seed, flow_mix=flow_mix, obj_mask=inp["obj_mask"])
+
+
 def gen_model(S=4, H=128, W=128, seed=0):
     """AdaMPI network (N1): the REFERENCE model/AdaMPI.py, loaded (strict) with the deterministic parameters that
     mpiflow_amd.model.MPIPredictor.randomize_(seed) produces, run on CPU fp32."""
@@ -362,6 +373,7 @@ JOBS = {
     "pose": gen_pose_schedule,
     "geometry": gen_geometry,
     "model": gen_model,
+    "hard": gen_hard_flow,
 }
 
 if __name__ == "__main__":

@@ -124,3 +124,21 @@ def test_flo_round_trip_and_layout(tmp_path):
     assert tuple(np.frombuffer(raw[4:12], np.int32)) == (7, 5)            # width then height (write_flow.py:95-96)
     assert np.frombuffer(raw[12:20], np.float32).tolist() == flow[0, 0].tolist()   # u, v interleaved
     assert bits_equal(io_formats.read_flo(p), flow) == 0
+
+
+def test_async_writer_writes_everything_and_propagates_errors(tmp_path):
+    from mpiflow_amd import io_formats
+    w = io_formats.AsyncWriter(threads=4, max_pending=3)
+    rs = np.random.RandomState(1)
+    flows = [rs.randn(6, 9, 2).astype(np.float32) for _ in range(20)]
+    for i, f in enumerate(flows):
+        w.flo(str(tmp_path / ("f%d.flo" % i)), f)
+        w.png_bgr(str(tmp_path / ("i%d.png" % i)), (rs.rand(6, 9, 3) * 255).astype(np.uint8))
+    w.close()
+    for i, f in enumerate(flows):
+        assert bits_equal(io_formats.read_flo(str(tmp_path / ("f%d.flo" % i))), f) == 0
+        assert os.path.getsize(tmp_path / ("i%d.png" % i)) > 0
+    w2 = io_formats.AsyncWriter(threads=2)
+    w2.flo(str(tmp_path / "no_such_dir" / "x.flo"), flows[0])
+    with pytest.raises(Exception):
+        w2.close()

@@ -17,6 +17,28 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_device(fn):
+    """Run `fn` with the device of its first CUDA tensor (or torch.device) argument current, so that the HIP launch and
+    torch's "current stream" both refer to the GPU that owns the buffers, whatever device the caller had selected."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                dev = a.device
+                break
+            if isinstance(a, torch.device) and a.type == "cuda":
+                dev = a
+                break
+        if dev is None or dev.index is None:
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
+
+
 def _dev(t, name, dtype=_f32):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
@@ -56,6 +78,7 @@ def warp_params(H_src_tgt, K_inv, G, depth_S):
     return host_math.pack_params(K_inv=K_inv, G=G, homs=host_math._cpu32(H_src_tgt).reshape(d.numel(), 3, 3), depths=d)
 
 
+@_on_device
 def src_blend_flow(mpi_S4HW, img_3HW, K_inv=None, depth_S=None, homs_tgt_src=None, flow_clip=200.0,
                    want_rgba=True, want_planar=False, want_tacc=False, out_rgba=None, out_flows=None,
                    dparams=None, P=None, src_u8=None, obj_mask=None, quads=None, quads_complement=None, cum_mask=None):
@@ -83,6 +106,7 @@ def src_blend_flow(mpi_S4HW, img_3HW, K_inv=None, depth_S=None, homs_tgt_src=Non
     return dict(rgba=rgba, rgb_planar=planar, tacc=tacc, flows=flows)
 
 
+@_on_device
 def alloc_rgba_stack(S, H, W, device):
     """Interleaved [S,H,W,4] stack followed by (W+2) zeroed texels: lets Stage B read the east/south bilinear taps at fixed
     +16 / +row-byte offsets (`interleaved=2`); taps that fall outside the image carry weight exactly 0."""
@@ -91,6 +115,7 @@ def alloc_rgba_stack(S, H, W, device):
     return store[:n].view(S, H, W, 4)
 
 
+@_on_device
 def mask_quads(obj_mask_HW, complement=False):
     lib = _lib.load()
     m = _dev(obj_mask_HW, "obj_mask")
@@ -101,6 +126,7 @@ def mask_quads(obj_mask_HW, complement=False):
     return q
 
 
+@_on_device
 def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None, interleaved=True, want_depth=True,
                    want_tgt_mask=True, dparams=None, out=None):
     """Stage B.  rgba [S,H,W,4] (interleaved) or [S,4,H,W]; quads from mask_quads() or None.  Either pass the small
@@ -131,6 +157,7 @@ def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None
     return dict(rgb=rgb, depth=depth, objmask=om, tgt_mask=tm, rgb_u8=u8)
 
 
+@_on_device
 def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.99):
     lib = _lib.load()
     frame = _dev(frame, "frame")
@@ -148,6 +175,7 @@ def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.9
     return flow_mix, frame_mix, fill
 
 
+@_on_device
 def fill_holes(img_HW3_u8, hole_HW_u8, max_passes=None):
     """Built-in deterministic hole fill (onion peel; NOT OpenCV's algorithm - see DESIGN.md, row A13)."""
     lib = _lib.load()
@@ -166,6 +194,7 @@ def fill_holes(img_HW3_u8, hole_HW_u8, max_passes=None):
     return a
 
 
+@_on_device
 def to_u8_bgr(img_3HW):
     lib = _lib.load()
     img = _dev(img_3HW, "img")
@@ -177,6 +206,7 @@ def to_u8_bgr(img_3HW):
 
 # ---- generic ops ----------------------------------------------------------------------------------------------------
 
+@_on_device
 def src_xyz(K_inv, depth_S, H, W, device):
     lib = _lib.load()
     d = host_math._cpu32(depth_S).reshape(-1)
@@ -187,6 +217,7 @@ def src_xyz(K_inv, depth_S, H, W, device):
     return out
 
 
+@_on_device
 def transform_xyz(G, xyz_S3N):
     lib = _lib.load()
     xyz = _dev(xyz_S3N, "xyz")
@@ -198,6 +229,7 @@ def transform_xyz(G, xyz_S3N):
     return out
 
 
+@_on_device
 def homography_sample(src_SCHW, H_src_tgt, want_flow=True):
     lib = _lib.load()
     src = _dev(src_SCHW, "src")
@@ -211,6 +243,7 @@ def homography_sample(src_SCHW, H_src_tgt, want_flow=True):
     return tgt, valid.to(torch.bool), flow
 
 
+@_on_device
 def homography_flow(H_tgt_src, H, W, device):
     lib = _lib.load()
     hts = host_math._cpu32(H_tgt_src).reshape(-1, 3, 3)
@@ -221,6 +254,7 @@ def homography_flow(H_tgt_src, H, W, device):
     return flow
 
 
+@_on_device
 def volume_render(rgb_S3N, sigma_SN, xyz_S3N, extra_SEN=None, hard=False, want_tacc=True, want_weights=True):
     """Generic plane_volume_rendering on materialised tensors.  Trailing dims are flattened to N."""
     lib = _lib.load()
@@ -244,6 +278,7 @@ def volume_render(rgb_S3N, sigma_SN, xyz_S3N, extra_SEN=None, hard=False, want_t
     return out
 
 
+@_on_device
 def weighted_sum(weights_SN, values_SCN=None):
     """cascade-sum over S of weights (* values).  weights [S,*tail], values [S,C,*tail] -> [C,*tail] ([1,*tail] if None)"""
     lib = _lib.load()
@@ -260,6 +295,7 @@ def weighted_sum(weights_SN, values_SCN=None):
 
 # ---- depth -> flow, forward warp -----------------------------------------------------------------------------------
 
+@_on_device
 def disp_to_depth(disp):
     lib = _lib.load()
     d = _dev(disp, "disp")
@@ -268,6 +304,7 @@ def disp_to_depth(disp):
     return out
 
 
+@_on_device
 def backproject_project(depth_HW, inv_K33, P34):
     lib = _lib.load()
     depth = _dev(depth_HW, "depth")
@@ -282,6 +319,7 @@ def backproject_project(depth_HW, inv_K33, P34):
     return pix, z
 
 
+@_on_device
 def backproject(depth_HW, inv_K33):
     """BackprojectDepth.forward -> [4, H*W] camera points (rows X, Y, Z, 1)"""
     lib = _lib.load()
@@ -293,6 +331,7 @@ def backproject(depth_HW, inv_K33):
     return cam
 
 
+@_on_device
 def project3d(points_4N, P34, H, W, eps=1e-7):
     """Project3D.forward on homogeneous points [4, H*W] -> (pix [H,W,2] normalised, z [H*W])"""
     lib = _lib.load()
@@ -304,6 +343,7 @@ def project3d(points_4N, P34, H, W, eps=1e-7):
     return pix, z
 
 
+@_on_device
 def select_truncate(p_static, z_static, p_obj, z_obj, inst_HW):
     lib = _lib.load()
     inst = _dev(inst_HW, "instance mask")
@@ -320,6 +360,7 @@ def select_truncate(p_static, z_static, p_obj, z_obj, inst_HW):
     return p1, z1, sx, sy, fl
 
 
+@_on_device
 def moving_object_project(disp_HW, inv_K33, P_static34, P_obj34, inst_HW):
     """Fused moving_obj.py:29-124: -> (p1 [H,W,2], z1 [H,W], safe_x, safe_y int64 [H,W], flow01 [H,W,2])"""
     lib = _lib.load()
@@ -341,6 +382,7 @@ def moving_object_project(disp_HW, inv_K33, P_static34, P_obj34, inst_HW):
     return p1, z1, sx, sy, fl
 
 
+@_on_device
 def forward_warp(src_u8, idx_i64, idy_i64, z_f32, h, w):
     """Device-resident forward splat, byte-identical to the reference's serial C.  -> warped u8 [h,w,5]"""
     lib = _lib.load()
@@ -358,6 +400,7 @@ def forward_warp(src_u8, idx_i64, idy_i64, z_f32, h, w):
     return warped
 
 
+@_on_device
 def warp_masks(warped_HW5):
     lib = _lib.load()
     w5 = _dev(warped_HW5, "warped", torch.uint8)

@@ -568,7 +568,10 @@ extern "C" int mpf_build_mask_quads(const float *d_obj_mask, int complement, int
 // ACT: d_mpi holds the RAW last-layer output of the AdaMPI decoder and cum_mask [S,H,W] its cumulative feature mask; the
 // activation epilogue of the network (reference model/CPN/decoder.py:166-173: rgb = sigmoid(x), sigma = relu(x * cum_mask) + 1e-4)
 // is applied here in registers, so the producer never writes / re-reads an activated copy of the 629 MB stack.
-template <int PX, int P, int NL, bool ACT = false, bool NT_STORE = (MPF_NT_STORE != 0)>
+// BLEND = false: flow-only pass (no rgba / planar / tacc output requested): only the sigma channel is read - 4*S*N bytes
+// instead of 16*S*N.  The blended stack depends on the image alone, so a caller rendering several pairs of one image
+// (the reference's `repeat` loop) blends once and runs this variant per pair.
+template <int PX, int P, int NL, bool ACT = false, bool BLEND = true, bool NT_STORE = (MPF_NT_STORE != 0)>
 __global__ void __launch_bounds__(256)
 k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, const float *__restrict__ params, int S,
                  int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
@@ -632,11 +635,13 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ch[i][c] = pl[c * N + n[i]];
+            for (int c = BLEND ? 0 : 3; c < 4; ++c) ch[i][c] = pl[c * N + n[i]];
             if (ACT) {
                 const float cm = cum_mask[(int64_t)s * N + n[i]];
+                if (BLEND) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) ch[i][c] = 1.0f / (1.0f + mpf_expf_fast(-ch[i][c]));
+                    for (int c = 0; c < 3; ++c) ch[i][c] = 1.0f / (1.0f + mpf_expf_fast(-ch[i][c]));
+                }
                 ch[i][3] = fmaxf(ch[i][3] * cm, 0.0f) + 1e-4f;
             }
         }
@@ -657,14 +662,16 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
             float w = tacc * alpha;
             acc[i] *= (double)(Tr + 1e-6f);
             float one_m = 1.0f - tacc;
-            float o[3];
+            float o[3] = { 0.0f, 0.0f, 0.0f };
+            if (BLEND) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float a = tacc * im[i][c];                 // blend_weights * src_imgs          utils/utils.py:202-204
-                float bb = one_m * ch[i][c];               // (1 - blend_weights) * mpi_rgb
-                o[c] = a + bb;
+                for (int c = 0; c < 3; ++c) {
+                    float a = tacc * im[i][c];                 // blend_weights * src_imgs          utils/utils.py:202-204
+                    float bb = one_m * ch[i][c];               // (1 - blend_weights) * mpi_rgb
+                    o[c] = a + bb;
+                }
             }
-            if (live[i]) {
+            if (BLEND && live[i]) {
                 if (out_rgba) {
                     typedef float mpf_v4f __attribute__((ext_vector_type(4)));
                     mpf_v4f *dst = reinterpret_cast<mpf_v4f *>(out_rgba) + ((int64_t)s * N + n[i]);
@@ -735,10 +742,14 @@ static int launch_sbf(const float *mpi, const float *img, const float *params, i
     const int64_t N = (int64_t)H * W;
     const int64_t T = (N + PX - 1) / PX;
     dim3 grid((unsigned)((T + 255) / 256)), block(256);
-#define MPF_SBF_GO(NLv, ACTv) hipLaunchKernelGGL((k_src_blend_flow<PX, P, NLv, ACTv>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, planar, \
-                                              tacc, flows, T, src_u8, om, reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1), cum_mask)
-    if (S < 256) { if (cum_mask) MPF_SBF_GO(2, true); else MPF_SBF_GO(2, false); }
-    else         { if (cum_mask) MPF_SBF_GO(3, true); else MPF_SBF_GO(3, false); }
+    const bool blend = rgba || planar || tacc;
+#define MPF_SBF_GO(NLv, ACTv, BLv) hipLaunchKernelGGL((k_src_blend_flow<PX, P, NLv, ACTv, BLv>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, \
+                                              planar, tacc, flows, T, src_u8, om, reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1), cum_mask)
+#define MPF_SBF_NL(NLv)                                                                              \
+    if (cum_mask) { if (blend) MPF_SBF_GO(NLv, true, true); else MPF_SBF_GO(NLv, true, false); }    \
+    else          { if (blend) MPF_SBF_GO(NLv, false, true); else MPF_SBF_GO(NLv, false, false); }
+    if (S < 256) { MPF_SBF_NL(2) } else { MPF_SBF_NL(3) }
+#undef MPF_SBF_NL
 #undef MPF_SBF_GO
     return mpf_launch_status("k_src_blend_flow");
 }

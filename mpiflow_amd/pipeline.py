@@ -51,20 +51,31 @@ class PairRenderer:
             hts.append(H_ts)
             wp.append(ops.upload_params(ops.warp_params(H_st, k_inv, G, d), self.device))
         bf, P = ops.blend_flow_params(k_inv, d, torch.stack(hts))
-        return dict(P=P, blend=ops.upload_params(bf, self.device), warp=wp)
+        return dict(P=P, blend=ops.upload_params(bf, self.device), warp=wp, k_inv=k_inv, depths=d)
 
     # -- device side: launches only ------------------------------------------------------------------------------------
-    def run(self, mpi, image, prep, obj_mask, complement=(False, True), cum_mask=None):
+    def blend(self, mpi, image, K, disparity, cum_mask=None):
+        """Blend the source image into the stack once per IMAGE (the blended stack does not depend on the pose): the
+        reference re-blends inside every render_3dphoto_dynamic call, i.e. `repeat` times per image
+        (gen_3dphoto_dynamic_v2.py:99-118); with this, every further pair of the same image runs Stage A+C flow-only
+        (reads 4*S*N instead of 16*S*N, writes nothing but the flows)."""
+        ops.src_blend_flow(mpi, image, K_inv=host_math.k_inverse(K), depth_S=host_math.plane_depths(disparity), homs_tgt_src=None,
+                           out_rgba=self.rgba, src_u8=self.src_u8, cum_mask=cum_mask)
+
+    def run(self, mpi, image, prep, obj_mask, complement=(False, True), cum_mask=None, reuse_blend=False):
         """mpi [S,4,H,W], image [3,H,W], obj_mask [H,W] on device.  Two or three launches:
           Stage A+C (+ source frame as u8, + mask quads of obj_mask and 1 - obj_mask), then one Stage B per view
           (view v samples 1 - obj_mask when complement[v]; + its frame as u8).  cum_mask [S,H,W]: `mpi` is the raw decoder
-          output of the AdaMPI network and its activation epilogue is fused into Stage A+C.  Returns (flows [P,2,H,W], views)."""
+          output of the AdaMPI network and its activation epilogue is fused into Stage A+C.  reuse_blend: self.rgba / self.src_u8
+          already hold this image's blended stack (blend()), Stage A+C only computes flows and quads.
+          Returns (flows [P,2,H,W], views)."""
         P = prep["P"]
         need_c = any(complement[:P])
         need_p = not all(complement[:P])
-        ops.src_blend_flow(mpi, image, out_rgba=self.rgba, out_flows=self.flows[:P], dparams=prep["blend"], P=P,
-                           src_u8=self.src_u8, obj_mask=obj_mask, quads=self.quads[0] if need_p else None,
-                           quads_complement=self.quads[1] if need_c else None, cum_mask=cum_mask)
+        ops.src_blend_flow(mpi, image, out_rgba=None if reuse_blend else self.rgba, want_rgba=False, out_flows=self.flows[:P],
+                           dparams=prep["blend"], P=P, src_u8=None if reuse_blend else self.src_u8, obj_mask=obj_mask,
+                           quads=self.quads[0] if need_p else None, quads_complement=self.quads[1] if need_c else None,
+                           cum_mask=cum_mask)
         for v in range(P):
             ops.warp_composite(self.rgba, self.quads[1 if complement[v] else 0], dparams=prep["warp"][v], out=self.views[v],
                                interleaved=2)
@@ -89,7 +100,7 @@ def hard_flows(mpi_S4HW, disparity_S, K, poses):
 
 
 def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, thresh=MASK_THRESH, renderer=None, cum_mask=None,
-                hard_flow=False):
+                hard_flow=False, reuse_blend=False):
     """Everything render_3dphoto_dynamic does up to the inputs of cv2.inpaint (reference utils/utils.py:159-283), for
     explicit poses: G_cam renders with obj_mask, G_dyn with 1 - obj_mask (sic - SURVEY §3.2).  Device tensors in/out."""
     mpi = mpi_S4HW
@@ -97,7 +108,7 @@ def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, 
     r = renderer or PairRenderer(S, H, W, mpi.device)
     om = obj_mask_HW.reshape(H, W).to(torch.float32)
     prep = r.prepare(K, disparity_S, [G_cam, G_dyn])
-    flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, om, cum_mask=cum_mask)
+    flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, om, cum_mask=cum_mask, reuse_blend=reuse_blend)
     if hard_flow:
         assert cum_mask is None, "hard_flow needs the activated stack"
         flows = hard_flows(mpi, disparity_S, K, [G_cam, G_dyn])

@@ -461,3 +461,24 @@ def test_inputs_of_other_dtypes_and_strides_are_promoted(dev, kernel_exp):
     got2 = ops.src_blend_flow(big[:, 1:5], T(inp["image"], dev), k_inv, d, None)          # non-contiguous view
     ref2 = o.src_blend_flow(inp["mpi"], inp["image"], k_inv, d, None)
     assert bits_equal(N(got2["rgba"]), ref2["rgba"]) == 0
+
+
+def test_blend_once_then_flow_only_pairs(dev):
+    """PairRenderer.blend() once per image + reuse_blend pairs (flow-only Stage A+C) == re-blending for every pair."""
+    from mpiflow_amd import pipeline
+    S, H, W = 20, 33, 47
+    inp = _inputs(S, H, W, seed=3)
+    mpi, img, om = T(inp["mpi"], dev), T(inp["image"], dev), T(inp["obj_mask"], dev)
+    import random
+    rng = random.Random(8)
+    from mpiflow_amd import host_math
+    r1, r2 = pipeline.PairRenderer(S, H, W, dev), pipeline.PairRenderer(S, H, W, dev)
+    r2.blend(mpi, img, inp["K"], inp["disparity"])
+    for _ in range(3):
+        Gd = host_math.generate_random_pose(0.15, rng=rng)
+        Gc = host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng)
+        a = pipeline.render_pair(img, om, mpi, inp["disparity"], inp["K"], Gc, Gd, renderer=r1)
+        a = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
+        b = pipeline.render_pair(img, om, mpi, inp["disparity"], inp["K"], Gc, Gd, renderer=r2, reuse_blend=True)
+        for k in ("flow_mix", "frame_mix", "fill_mask", "src_np", "flows"):
+            assert torch.equal(a[k], b[k]), k

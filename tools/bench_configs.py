@@ -83,7 +83,16 @@ def config(name, S, H, W, dynamic):
         main.wait_stream(s2)
         merge()
 
+    def image_with_repeats(rep=5):   # the reference's `repeat` loop: blend once per image, then flow-only Stage A+C per pair
+        r.blend(mpi, img, K, disp)
+        for _ in range(rep):
+            r.run(mpi, img, prep, om, complement=(False, True) if dynamic else (False,), reuse_blend=True)
+            if dynamic:
+                merge()
+
     ac(); b(0)
+    t_rep = timed(image_with_repeats, rounds=5, inner=1)
+    print("    blend once + 5 pairs of one image (flow-only A+C): %.1f us per pair" % (t_rep / 5), flush=True)
     t_ac, t_b = timed(ac), timed(lambda: b(0))
     t_pair = timed(pair)
     if dynamic:

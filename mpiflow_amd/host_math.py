@@ -90,28 +90,23 @@ def pack_params(K_inv=None, G=None, homs=None, depths=None, records=None):
 # ---- poses (geometry.py:79-153, utils/utils.py:121-156) -----------------------------------------------------------
 
 def rot_from_axisangle(vec):
-    """Axis-angle [B,1,3] -> rotation [B,4,4] (geometry.py:114-153; Rodrigues with angle + 1e-7)."""
+    """Axis-angle [B,1,3] -> rotation [B,4,4]: Rodrigues with the reference's regularised axis (angle + 1e-7) and its exact
+    operand pairing (geometry.py:114-153): diagonal u_i*(u_i*C) + cos, off-diagonals u_i*(u_j*C) -/+ u_k*sin with the
+    products taken as x*(y*C), y*(z*C), z*(x*C) - the pairing decides the last ulp."""
     angle = torch.norm(vec, 2, 2, True)
     axis = vec / (angle + 1e-7)
-    ca = torch.cos(angle)
-    sa = torch.sin(angle)
-    C = 1 - ca
-    x = axis[..., 0].unsqueeze(1)
-    y = axis[..., 1].unsqueeze(1)
-    z = axis[..., 2].unsqueeze(1)
-    xs, ys, zs = x * sa, y * sa, z * sa
-    xC, yC, zC = x * C, y * C, z * C
-    xyC, yzC, zxC = x * yC, y * zC, z * xC
+    cos_a, sin_a = torch.cos(angle), torch.sin(angle)
+    C = 1 - cos_a
+    u = [axis[..., i].unsqueeze(1) for i in range(3)]
+    u_sin = [c * sin_a for c in u]
+    u_C = [c * C for c in u]
     rot = torch.zeros((vec.shape[0], 4, 4)).to(device=vec.device)
-    rot[:, 0, 0] = torch.squeeze(x * xC + ca)
-    rot[:, 0, 1] = torch.squeeze(xyC - zs)
-    rot[:, 0, 2] = torch.squeeze(zxC + ys)
-    rot[:, 1, 0] = torch.squeeze(xyC + zs)
-    rot[:, 1, 1] = torch.squeeze(y * yC + ca)
-    rot[:, 1, 2] = torch.squeeze(yzC - xs)
-    rot[:, 2, 0] = torch.squeeze(zxC - ys)
-    rot[:, 2, 1] = torch.squeeze(yzC + xs)
-    rot[:, 2, 2] = torch.squeeze(z * zC + ca)
+    for i in range(3):
+        rot[:, i, i] = torch.squeeze(u[i] * u_C[i] + cos_a)
+    for i, j, k in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):          # (i, j) off-diagonal pair, k the remaining axis
+        prod = u[i] * u_C[j]
+        rot[:, i, j] = torch.squeeze(prod - u_sin[k])
+        rot[:, j, i] = torch.squeeze(prod + u_sin[k])
     rot[:, 3, 3] = 1
     return rot
 

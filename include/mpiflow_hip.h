@@ -168,6 +168,43 @@ int mpf_forward_warp(const uint8_t *d_src, const int64_t *d_idx, const int64_t *
 int mpf_warp_masks(const uint8_t *d_warped, int H, int W, uint8_t *d_Hm, uint8_t *d_M, uint8_t *d_Md, uint8_t *d_P,
                    uint8_t *d_Hp, void *stream);
 
+/* ================= MPI producer network: 3x3 convolution engine ====================== */
+
+/* One launch = one 3x3 / pad 1 / stride 1|2 convolution over S plane-images with its surrounding plumbing fused:
+ * the LOADER synthesises the layer's (virtual) NHWC input, the EPILOGUE applies bias / BatchNorm / activation / gate.
+ * Replaces, for S planes at once: ConvBNReLU (model/CPN/unet.py:6-15), GatedConv + ELU + BatchNorm
+ * (model/CPN/decoder.py:10-71) and the expand / cat / ReflectionPad2d / upsample tensors around them
+ * (model/CPN/unet.py:44-66, model/CPN/decoder.py:131-163).  Activations: fp16 NHWC, channels padded to a multiple of 8.
+ * fp16 MFMA, fp32 accumulation, fp32 epilogue - the precision of the reference's own GPU run (.half(),
+ * gen_3dphoto_dynamic_v2.py:46,59,82-84). */
+#define MPF_CONV_LD_FMN_INPUT     0   /* (r,g,b,disparity,plane disparity,0,0,0): srcA = image f32 [3,H,W], srcB = disparity f32 [H,W], plane_vals f32 [S] */
+#define MPF_CONV_LD_DIRECT        1   /* srcA f16 [S,Hin,Win,CA] */
+#define MPF_CONV_LD_BILINEAR_CAT  2   /* x2 bilinear (align_corners) of srcA f16 [S,HA,WA,CA]  ++  srcB f16 [S,Hin,Win,CB]; fparams = {(HA-1)/(Hin-1), (WA-1)/(Win-1)} */
+#define MPF_CONV_LD_NEAREST_PLANE 3   /* x2 nearest (or same size) of srcA f16 [S,HA,WA,CA] (CA may be 0)  ++  per-plane skip: srcB f16 [Hin,Win,CB-8] shared
+                                         features * cm[s], then (cm[s], fm[s], 0 x6); cm, fm f32 [S,Hin,Win]; CB == 0: no skip */
+#define MPF_CONV_EP_AFFINE_RELU      0   /* out f16 [S,Hout,Wout,Cst] = relu(acc * ep[0][row] + ep[1][row]) */
+#define MPF_CONV_EP_AFFINE_RELU_F32  1   /* same, output channel 0 only, out f32 [S,Hout,Wout] */
+#define MPF_CONV_EP_GATED_ELU        2   /* g = (accF + ep[0][rowF]) * sigmoid(accM + ep[0][rowM]); out f16 NHWC = elu(g * ep[1][rowF] + ep[2][rowF]) */
+#define MPF_CONV_EP_GATED_PLANAR_F32 3   /* out f32 [S,Cst,Hout,Wout] = g (no BatchNorm / activation: the decoder's raw output layer) */
+
+typedef struct MpfConvArgs {
+    const void *srcA, *srcB;          /* see the loader */
+    const float *cm, *fm;             /* per-plane masks at the conv-input resolution (LD_NEAREST_PLANE with CB > 0) */
+    const float *plane_vals;          /* LD_FMN_INPUT */
+    const void *wpack;                /* f16 weights in MFMA-fragment order: [nchunk][ksteps][nblk][64 lanes][8]   (mpiflow_amd/model/engine.py: pack_weights) */
+    const float *ep;                  /* f32 [3][nblk*16] epilogue rows, in packed row order */
+    void *out;
+    int S, Hin, Win, Hout, Wout;      /* Hin x Win: the virtual conv input (after upsampling / concatenation) */
+    int CA, CB, HA, WA;               /* padded channels of the two sources; size of source A */
+    int ct, nchunk;                   /* channels staged per tap and chunk (8, 16, 32); number of chunks */
+    int nblk, ncg;                    /* 16-row output blocks in total; workgroup column groups (nblk % ncg == 0) */
+    int Cst;                          /* channels of the output tensor (NHWC pitch, or planes for the planar epilogue) */
+    int loader, epi, stride, pad_mode; /* pad_mode 0 zero, 1 reflection */
+    float fparams[4];
+} MpfConvArgs;
+
+int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream);
+
 /* THE REFERENCE'S FFI SYMBOL (external/forward_warping/warping.c:6; bound at moving_obj.py:12-13, called at :127-129).
  * Same name, same argument meaning, HOST pointers: src u8 [h*w*3], idx/idy int64 [h*w] (pre-clamped by the caller, as
  * in the reference), z f32 [h*w], warped u8 [h*w*5] (caller-owned).  Synchronous.  Runs the HIP kernels above on the

@@ -22,6 +22,19 @@ c_f = ctypes.c_float
 c_i64 = ctypes.c_int64
 c_sz = ctypes.c_size_t
 
+
+
+class MpfConvArgs(ctypes.Structure):
+    """struct MpfConvArgs of include/mpiflow_hip.h (field order and types must match)."""
+    _fields_ = [("srcA", c_p), ("srcB", c_p), ("cm", c_p), ("fm", c_p), ("plane_vals", c_p), ("wpack", c_p), ("ep", c_p),
+                ("out", c_p),
+                ("S", c_i), ("Hin", c_i), ("Win", c_i), ("Hout", c_i), ("Wout", c_i),
+                ("CA", c_i), ("CB", c_i), ("HA", c_i), ("WA", c_i),
+                ("ct", c_i), ("nchunk", c_i), ("nblk", c_i), ("ncg", c_i), ("Cst", c_i),
+                ("loader", c_i), ("epi", c_i), ("stride", c_i), ("pad_mode", c_i),
+                ("fparams", c_f * 4)]
+
+
 # name -> (restype, argtypes); must list every symbol include/mpiflow_hip.h declares (tests/test_capi.py checks)
 SIGNATURES = {
     "mpf_version": (c_i, []),
@@ -51,6 +64,7 @@ SIGNATURES = {
     "forward_warping": (None, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
     "mpf_forward_warping_host": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
     "mpf_tune": (c_i, [ctypes.c_char_p, c_i]),
+    "mpf_conv3x3_f16": (c_i, [ctypes.POINTER(MpfConvArgs), c_p]),
 }
 
 

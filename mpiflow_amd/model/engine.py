@@ -1,0 +1,298 @@
+"""HIP execution engine for the per-plane convolutions of the MPI producer network.
+
+The S-times-batched parts of the network - the feature-mask UNet (reference model/CPN/unet.py:18-69) and the gated
+decoder (model/CPN/decoder.py:74-174) - are run as 20 launches of `mpf_conv3x3_f16` (mpiflow_amd/csrc/mpf_conv.hip):
+every launch is one 3x3 convolution over all S planes whose loader synthesises the layer's input (the expand / cat /
+upsample / reflection-pad tensors of the reference are never written) and whose epilogue applies BatchNorm, activation and
+the gate.  The single-image parts (ResNet-18 encoder, the 1x1 / 3x3 bottleneck at 1/32 .. 1/128 resolution) stay on
+torch: they are batch-1 and a few percent of the work.
+
+Precision: fp16 storage and MFMA inputs, fp32 accumulation and epilogue - the reference's own GPU configuration
+(`.half()`, gen_3dphoto_dynamic_v2.py:46,59,82-84).  `MPIPredictor.forward` (fp32 torch) remains the bit-exact mirror of
+the reference model; this engine is the fast path of `gen_3dphoto_dynamic.py --model-engine hip`.
+
+This module only PACKS parameters (host side, torch CPU) and sequences launches; all arithmetic is in the HIP kernels.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+
+LD_FMN_INPUT, LD_DIRECT, LD_BILINEAR_CAT, LD_NEAREST_PLANE = 0, 1, 2, 3
+EP_AFFINE_RELU, EP_AFFINE_RELU_F32, EP_GATED_ELU, EP_GATED_PLANAR_F32 = 0, 1, 2, 3
+
+
+def pad8(c):
+    return (int(c) + 7) // 8 * 8
+
+
+def ksteps(ct):
+    return (9 * ct + 31) // 32
+
+
+def pack_weights(w_rows, vmap, ct):
+    """Weights in MFMA A-fragment order for mpf_conv3x3_f16.
+
+    w_rows [R, Cin, 3, 3] fp32 (R = 16 * nblk rows in packed order, zero rows for padding);  vmap: LongTensor [Cv], virtual
+    input channel -> real input channel or -1 (Cv = nchunk * ct).
+    Returns fp16 [nchunk, ksteps, nblk, 64, 8]: lane l of fragment (chunk, ks, blk) holds, for j = 0..7,
+    W[row = 16 blk + (l & 15)][tap = ks * (32/ct) + (l >> 4) // (ct/8)][virtual channel = chunk * ct + ((l >> 4) % (ct/8)) * 8 + j]
+    (zero when the tap index exceeds 8) - the operand layout of v_mfma_f32_16x16x32_f16.
+    """
+    R = w_rows.shape[0]
+    assert R % 16 == 0 and vmap.numel() % ct == 0
+    nblk, nchunk, KS, vpp, tps = R // 16, vmap.numel() // ct, ksteps(ct), ct // 8, 32 // ct
+    wv = torch.zeros(R, vmap.numel(), 10, dtype=torch.float32)          # tap 9 = the all-zero tap
+    valid = vmap >= 0
+    wv[:, valid, :9] = w_rows.float().reshape(R, w_rows.shape[1], 9)[:, vmap[valid], :]
+    q = torch.arange(4)
+    ks = torch.arange(KS)
+    slot = (ks[:, None] * tps + (q[None, :] // vpp)).clamp(max=9)       # [KS, 4]
+    ch = ((q % vpp) * 8)[:, None] + torch.arange(8)[None, :]             # [4, 8] channel inside the chunk
+    out = torch.empty(nchunk, KS, nblk, 4, 16, 8, dtype=torch.float32)
+    wv = wv.reshape(nblk, 16, nchunk, ct, 10)
+    for k in range(KS):
+        for qq in range(4):
+            out[:, k, :, qq] = wv[:, :, :, ch[qq], int(slot[k, qq])].permute(2, 0, 1, 3)
+    return out.reshape(nchunk, KS, nblk, 64, 8).to(torch.float16).contiguous()
+
+
+def _bn_affine(bn):
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    return scale, bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+
+
+class ConvLayer:
+    """One packed layer + its launch."""
+
+    def __init__(self, device, *, loader, epi, stride, pad_mode, ct, vmap, rows_w, ep, nblk, ncg, Cst, CA, CB):
+        self.loader, self.epi, self.stride, self.pad_mode, self.ct = loader, epi, stride, pad_mode, ct
+        self.nchunk = vmap.numel() // ct
+        self.nblk, self.ncg, self.Cst, self.CA, self.CB = nblk, ncg, Cst, CA, CB
+        self.wpack = pack_weights(rows_w, vmap, ct).to(device)
+        self.ep = ep.float().contiguous().to(device)
+        assert self.ep.shape == (3, nblk * 16)
+
+    # -- builders ---------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _vmap(segments, ct):
+        """segments: list of (padded, real) channel counts in concatenation order -> virtual->real map padded to ct."""
+        idx, real0 = [], 0
+        for padded, real in segments:
+            idx += list(range(real0, real0 + real)) + [-1] * (padded - real)
+            real0 += real
+        idx += [-1] * (-len(idx) % ct)
+        return torch.tensor(idx, dtype=torch.long)
+
+    @classmethod
+    def affine_relu(cls, device, cbr, segments, *, loader, stride, ct, f32_out=False):
+        """Conv2d(bias) + BatchNorm(eval) + ReLU (ConvBNReLU, model/CPN/unet.py:6-15), zero padding."""
+        conv, bn = cbr.layer[0], cbr.layer[1]
+        cout = conv.out_channels
+        nblk = (cout + 15) // 16
+        rows_w = torch.zeros(nblk * 16, conv.in_channels, 3, 3)
+        rows_w[:cout] = conv.weight.detach().float().cpu()
+        scale, shift = _bn_affine(bn)
+        ep = torch.zeros(3, nblk * 16)
+        ep[0, :cout] = scale.cpu()
+        ep[1, :cout] = (shift + conv.bias.detach().float() * scale).cpu()
+        nb = nblk if nblk <= 8 else 8
+        assert nblk % nb == 0
+        CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
+        return cls(device, loader=loader, epi=EP_AFFINE_RELU_F32 if f32_out else EP_AFFINE_RELU, stride=stride, pad_mode=0, ct=ct,
+                   vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep, nblk=nblk, ncg=nblk // nb, Cst=1 if f32_out else pad8(cout),
+                   CA=CA, CB=CB)
+
+    @classmethod
+    def gated(cls, device, gconv, bn, segments, *, loader, ct, planar=False):
+        """GatedConv (+ BatchNorm + ELU when bn is given), reflection padding (model/CPN/decoder.py:10-71)."""
+        cf, cmk = gconv.conv2d, gconv.mask_conv2d
+        cout = cf.out_channels
+        nf_total = (cout + 15) // 16
+        nf = max(d for d in (4, 3, 2, 1) if nf_total % d == 0)            # feature blocks per workgroup (NB = 2 nf in {2,4,6,8})
+        ncg = nf_total // nf
+        nblk = 2 * nf_total
+        rows_w = torch.zeros(nblk * 16, cf.in_channels, 3, 3)
+        ep = torch.zeros(3, nblk * 16)
+        if bn is not None:
+            scale, shift = _bn_affine(bn)
+        for cg in range(ncg):
+            for b in range(nf):
+                c0 = (cg * nf + b) * 16
+                n = max(0, min(16, cout - c0))
+                rf = (cg * 2 * nf + b) * 16
+                rm = (cg * 2 * nf + nf + b) * 16
+                rows_w[rf:rf + n] = cf.weight.detach().float().cpu()[c0:c0 + n]
+                rows_w[rm:rm + n] = cmk.weight.detach().float().cpu()[c0:c0 + n]
+                ep[0, rf:rf + n] = cf.bias.detach().float().cpu()[c0:c0 + n]
+                ep[0, rm:rm + n] = cmk.bias.detach().float().cpu()[c0:c0 + n]
+                if bn is not None:
+                    ep[1, rf:rf + n] = scale.cpu()[c0:c0 + n]
+                    ep[2, rf:rf + n] = shift.cpu()[c0:c0 + n]
+        CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
+        return cls(device, loader=loader, epi=EP_GATED_PLANAR_F32 if planar else EP_GATED_ELU, stride=1, pad_mode=1, ct=ct,
+                   vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep, nblk=nblk, ncg=ncg, Cst=cout if planar else nf_total * 16,
+                   CA=CA, CB=CB)
+
+    # -- launch -------------------------------------------------------------------------------------------------------
+    def __call__(self, S, Hin, Win, srcA=None, srcB=None, cm=None, fm=None, plane_vals=None, HA=None, WA=None, out=None):
+        Hout, Wout = (Hin - 1) // self.stride + 1, (Win - 1) // self.stride + 1
+        dev = self.wpack.device
+        if out is None:
+            if self.epi == EP_AFFINE_RELU_F32:
+                out = torch.empty(S, Hout, Wout, dtype=torch.float32, device=dev)
+            elif self.epi == EP_GATED_PLANAR_F32:
+                out = torch.empty(S, self.Cst, Hout, Wout, dtype=torch.float32, device=dev)
+            else:
+                out = torch.empty(S, Hout, Wout, self.Cst, dtype=torch.float16, device=dev)
+        a = _lib.MpfConvArgs()
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())      # noqa: E731
+        a.srcA, a.srcB, a.cm, a.fm, a.plane_vals = p(srcA), p(srcB), p(cm), p(fm), p(plane_vals)
+        a.wpack, a.ep, a.out = p(self.wpack), p(self.ep), p(out)
+        a.S, a.Hin, a.Win, a.Hout, a.Wout = S, Hin, Win, Hout, Wout
+        a.CA, a.CB = self.CA, self.CB
+        a.HA, a.WA = (HA if HA is not None else Hin), (WA if WA is not None else Win)
+        a.ct, a.nchunk, a.nblk, a.ncg, a.Cst = self.ct, self.nchunk, self.nblk, self.ncg, self.Cst
+        a.loader, a.epi, a.stride, a.pad_mode = self.loader, self.epi, self.stride, self.pad_mode
+        if self.loader == LD_BILINEAR_CAT:
+            a.fparams[0] = (a.HA - 1) / (Hin - 1) if Hin > 1 else 0.0
+            a.fparams[1] = (a.WA - 1) / (Win - 1) if Win > 1 else 0.0
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(_lib.load().mpf_conv3x3_f16(ctypes.byref(a), stream), "mpf_conv3x3_f16")
+        return out
+
+
+def _nhwc16(t_1CHW):
+    return t_1CHW[0].permute(1, 2, 0).contiguous().to(torch.float16)
+
+
+class FeatMaskEngine:
+    """FeatMaskNetwork.forward (model/CPN/unet.py:44-69) in 9 launches + one softmax over the planes."""
+
+    def __init__(self, fmn, device):
+        A = ConvLayer.affine_relu
+        self.l1 = A(device, fmn.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8)
+        self.l2 = A(device, fmn.conv2, [(16, 16)], loader=LD_DIRECT, stride=2, ct=16)
+        self.l3 = A(device, fmn.conv3, [(32, 32)], loader=LD_DIRECT, stride=2, ct=32)
+        self.l4 = A(device, fmn.conv4, [(64, 64)], loader=LD_DIRECT, stride=2, ct=32)
+        self.l5 = A(device, fmn.conv5, [(128, 128)], loader=LD_DIRECT, stride=1, ct=32)
+        self.l6 = A(device, fmn.conv6, [(128, 128), (64, 64)], loader=LD_BILINEAR_CAT, stride=1, ct=32)
+        self.l7 = A(device, fmn.conv7, [(64, 64), (32, 32)], loader=LD_BILINEAR_CAT, stride=1, ct=32)
+        self.l8 = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_CAT, stride=1, ct=32)
+        self.l9 = A(device, fmn.conv9, [(16, 16)], loader=LD_DIRECT, stride=1, ct=16, f32_out=True)
+
+    def logits(self, image_3HW, disp_HW, plane_disp_S):
+        S = plane_disp_S.numel()
+        H, W = disp_HW.shape
+        if H % 8 or W % 8:
+            raise ValueError("feature-mask network needs H and W divisible by 8 (three stride-2 stages and x2 upsampling back)")
+        img, dsp, pd = image_3HW.float().contiguous(), disp_HW.float().contiguous(), plane_disp_S.float().contiguous()
+        c1 = self.l1(S, H, W, srcA=img, srcB=dsp, plane_vals=pd)
+        c2 = self.l2(S, H, W, srcA=c1)
+        c3 = self.l3(S, H // 2, W // 2, srcA=c2)
+        c4 = self.l4(S, H // 4, W // 4, srcA=c3)
+        c5 = self.l5(S, H // 8, W // 8, srcA=c4)
+        c6 = self.l6(S, H // 4, W // 4, srcA=c5, srcB=c3, HA=H // 8, WA=W // 8)
+        c7 = self.l7(S, H // 2, W // 2, srcA=c6, srcB=c2, HA=H // 4, WA=W // 4)
+        c8 = self.l8(S, H, W, srcA=c7, srcB=c1, HA=H // 2, WA=W // 2)
+        return self.l9(S, H, W, srcA=c8)
+
+    def __call__(self, image_3HW, disp_HW, plane_disp_S):
+        """-> feature mask [S,H,W] fp32 (softmax over the planes, model/CPN/unet.py:68-69)"""
+        return torch.softmax(self.logits(image_3HW, disp_HW, plane_disp_S), dim=0)
+
+
+class DecoderEngine:
+    """DepthDecoder.forward (model/CPN/decoder.py:124-174) for B = 1: bottleneck on torch, the 11 gated convolutions over
+    S planes in HIP.  Returns the raw last-layer output [S,4,H,W] fp32 and the cumulative mask [S,H,W] fp32 - the hand-off
+    mpf_src_blend_flow(..., d_cum_mask) finishes in registers."""
+
+    DEC = [12, 24, 48, 96, 192]
+
+    def __init__(self, decoder, num_ch_enc, device, amp_dtype=torch.float16):
+        self.decoder = decoder
+        self.amp_dtype = amp_dtype
+        enc = [int(c) for c in num_ch_enc]
+        G = ConvLayer.gated
+        key = lambda *t: "-".join(str(tuple(t)))                     # noqa: E731
+        self.up0, self.up1 = {}, {}
+        dec = self.DEC
+        for i in range(4, -1, -1):
+            blk0, blk1 = decoder.convs[key("upconv", i, 0)], decoder.convs[key("upconv", i, 1)]
+            if i == 4:
+                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(0, 0), (enc[4] + 8, enc[4] + 2)], loader=LD_NEAREST_PLANE, ct=32)
+            else:
+                cin = dec[i + 1]
+                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(pad16(cin), cin)], loader=LD_DIRECT, ct=32)
+            cx = dec[i]
+            if i > 0:
+                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad16(cx), cx), (enc[i - 1] + 8, enc[i - 1] + 2)],
+                                loader=LD_NEAREST_PLANE, ct=32)
+            else:
+                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad16(cx), cx)], loader=LD_NEAREST_PLANE, ct=16)
+        self.disp0 = G(device, decoder.convs[key("dispconv", 0)], None, [(16, dec[0])], loader=LD_DIRECT, ct=16, planar=True)
+
+    def __call__(self, feats, feature_mask_SHW):
+        d = self.decoder
+        S, H, W = feature_mask_SHW.shape
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            top = d.conv_up2(d.upsample(d.conv_up1(d.upsample(d.conv_down2(d.downsample(d.conv_down1(d.downsample(feats[-1]))))))))
+        cum_mask = torch.cumsum(feature_mask_SHW, dim=0)
+        context = 1 - torch.cat([torch.zeros_like(cum_mask[-1:]), cum_mask[:-1]], dim=0)
+
+        def masks(h, w):
+            return (F.adaptive_avg_pool2d(context[None], (h, w))[0].contiguous(),
+                    F.adaptive_avg_pool2d(feature_mask_SHW[None], (h, w))[0].contiguous())
+
+        h, w = top.shape[-2:]
+        cm, fm = masks(h, w)
+        x = self.up0[4](S, h, w, srcB=_nhwc16(top), cm=cm, fm=fm)
+        for i in range(4, -1, -1):
+            if i < 4:
+                x = self.up0[i](S, h, w, srcA=x)
+            ha, wa = h, w
+            h, w = 2 * h, 2 * w
+            if i > 0:
+                f = feats[i - 1]
+                if tuple(f.shape[-2:]) != (h, w):
+                    raise ValueError("encoder feature %d is %s, decoder expects %s" % (i - 1, tuple(f.shape[-2:]), (h, w)))
+                cm, fm = masks(h, w)
+                x = self.up1[i](S, h, w, srcA=x, srcB=_nhwc16(f), cm=cm, fm=fm, HA=ha, WA=wa)
+            else:
+                x = self.up1[i](S, h, w, srcA=x, HA=ha, WA=wa)
+        raw = self.disp0(S, h, w, srcA=x)
+        cur = cum_mask if (h, w) == (H, W) else F.adaptive_avg_pool2d(cum_mask[None], (h, w))[0]
+        return raw, cur.contiguous()
+
+
+def pad16(c):
+    return (int(c) + 15) // 16 * 16
+
+
+class HipPredictor:
+    """MPIPredictor.forward(raw=True) (model/AdaMPI.py:55-78) for one image with the per-plane networks on the HIP engine."""
+
+    def __init__(self, model, encoder_dtype=torch.float16):
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.MpiFlowHipError("HipPredictor needs the model on the GPU; there is no CPU path")
+        self.model = model.eval()
+        self.encoder_dtype = encoder_dtype
+        self.fmn = FeatMaskEngine(model.fmn, dev)
+        self.dec = DecoderEngine(model.decoder, model.encoder.num_ch_enc, dev, amp_dtype=encoder_dtype)
+
+    @torch.no_grad()
+    def __call__(self, src_imgs, src_depths):
+        """(image [1,3,H,W], disparity [1,1,H,W]) -> (raw [S,4,H,W] fp32, cum_mask [S,H,W] fp32, plane disparities [S])"""
+        if src_imgs.shape[0] != 1:
+            raise ValueError("HipPredictor runs one image at a time (the S planes are the batch)")
+        m = self.model
+        disp = m.plane_disparities(src_imgs)[0]
+        fmask = self.fmn(src_imgs[0], src_depths[0, 0], disp)
+        with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=self.encoder_dtype is not None):
+            feats = m.encoder(src_imgs, src_depths)
+        raw, cum = self.dec(feats, fmask)
+        return raw, cum, disp

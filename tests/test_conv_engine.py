@@ -1,0 +1,244 @@
+"""Convolution engine of the MPI producer: mpf_conv3x3_f16 against torch, layer by layer and end to end.
+
+The per-layer checks feed the engine and torch the SAME fp16-representable inputs and weights, so the only differences
+are the fp32 summation order and the final fp16 rounding of the stored activation: tolerances are a few fp16 ulps.  The
+end-to-end checks compare with the fp32 torch modules (the bit-exact mirror of the reference model, tests/test_model.py):
+that tolerance is the cost of fp16 storage, the reference's own GPU precision."""
+import subprocess
+import sys
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- CPU: packing and ABI ---------------------------------------------------------------------------------------------
+
+def _pack_reference(w_rows, vmap, ct):
+    R = w_rows.shape[0]
+    nblk, nchunk, KS, vpp, tps = R // 16, len(vmap) // ct, (9 * ct + 31) // 32, ct // 8, 32 // ct
+    out = np.zeros((nchunk, KS, nblk, 64, 8), np.float32)
+    for c in range(nchunk):
+        for k in range(KS):
+            for b in range(nblk):
+                for l in range(64):
+                    q, r = l >> 4, l & 15
+                    slot = k * tps + q // vpp
+                    for j in range(8):
+                        v = int(vmap[c * ct + (q % vpp) * 8 + j])
+                        if slot < 9 and v >= 0:
+                            out[c, k, b, l, j] = w_rows[b * 16 + r, v, slot // 3, slot % 3]
+    return out
+
+
+@pytest.mark.parametrize("ct,segments", [(8, [(8, 5)]), (16, [(16, 12)]), (32, [(32, 24), (16, 10)])])
+def test_pack_weights_layout(ct, segments):
+    from mpiflow_amd.model.engine import ConvLayer, pack_weights
+    g = torch.Generator().manual_seed(ct)
+    vmap = ConvLayer._vmap(segments, ct)
+    cin = sum(r for _, r in segments)
+    w = torch.randn(32, cin, 3, 3, generator=g)
+    got = pack_weights(w, vmap, ct).float().numpy()
+    ref = _pack_reference(w.to(torch.float16).float().numpy(), vmap.numpy(), ct)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_conv_args_struct_matches_header(tmp_path):
+    """ctypes mirror == the C struct: compare sizeof and every offsetof through gcc."""
+    import ctypes
+    from mpiflow_amd import _lib
+    fields = [f[0] for f in _lib.MpfConvArgs._fields_]
+    src = tmp_path / "o.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mpiflow_hip.h"\nint main(void){printf("%zu", sizeof(MpfConvArgs));\n'
+                   + "".join('printf(" %%zu", offsetof(MpfConvArgs, %s));\n' % f for f in fields) + "return 0;}\n")
+    exe = tmp_path / "o"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    vals = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert vals[0] == ctypes.sizeof(_lib.MpfConvArgs)
+    assert vals[1:] == [getattr(_lib.MpfConvArgs, f).offset for f in fields]
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _model(S, H, W, seed=3):
+    from mpiflow_amd.model import MPIPredictor
+    return MPIPredictor(W, H, S).randomize_(seed).eval().to(_gpu())
+
+
+def _q16(t):
+    return t.to(torch.float16).float()
+
+
+def _quantise_convs(module):
+    """Round every conv weight to fp16-representable values (the engine stores fp16 weights) - makes the comparison tight."""
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.copy_(_q16(m.weight))
+
+
+def _nchw(x_SHWC, c):
+    return x_SHWC.float().permute(0, 3, 1, 2)[:, :c]
+
+
+def _close(got, ref, ulps=3.0, floor=2e-3):
+    """|got - ref| <= ulps * fp16 spacing at |ref| + floor * (fp32 sum-order noise scaled by the tensor's magnitude)"""
+    tol = ulps * ref.abs().clamp(min=2.0 ** -14) * 2.0 ** -10 + floor * ref.abs().max().clamp(min=1e-3) * 1e-1
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), "max |diff| %.3e at ref %.3e (%d of %d off)" % (
+        float((got - ref).abs().max()), float(ref.abs().max()), int(bad.sum()), bad.numel())
+
+
+@pytest.mark.gpu
+def test_fmn_layers_match_torch():
+    from mpiflow_amd.model.engine import FeatMaskEngine
+    dev = _gpu()
+    S, H, W = 5, 72, 104                      # ragged against the 8x32 / 4x32 tiles; divisible by 8 for the UNet
+    m = _model(S, 128, 128)
+    _quantise_convs(m.fmn)
+    eng = FeatMaskEngine(m.fmn, dev)
+    g = torch.Generator().manual_seed(0)
+    img = _q16(torch.rand(3, H, W, generator=g)).to(dev)
+    dsp = _q16(torch.rand(H, W, generator=g)).to(dev)
+    pd = _q16(torch.linspace(1, 0.001, S + 2)[1:-1]).to(dev)
+    fmn = m.fmn
+    with torch.no_grad():
+        x = torch.cat([img[None].expand(S, 3, H, W), dsp[None, None].expand(S, 1, H, W), pd.view(S, 1, 1, 1).expand(S, 1, H, W)], 1)
+        # layer by layer, each torch layer fed with the ENGINE's previous (fp16) activation
+        c1 = eng.l1(S, H, W, srcA=img, srcB=dsp, plane_vals=pd)
+        _close(_nchw(c1, 16), fmn.conv1(x))
+        c2 = eng.l2(S, H, W, srcA=c1)
+        _close(_nchw(c2, 32), fmn.conv2(_nchw(c1, 16)))
+        c3 = eng.l3(S, H // 2, W // 2, srcA=c2)
+        _close(_nchw(c3, 64), fmn.conv3(_nchw(c2, 32)))
+        c4 = eng.l4(S, H // 4, W // 4, srcA=c3)
+        _close(_nchw(c4, 128), fmn.conv4(_nchw(c3, 64)))
+        c5 = eng.l5(S, H // 8, W // 8, srcA=c4)
+        _close(_nchw(c5, 128), fmn.conv5(_nchw(c4, 128)))
+        c6 = eng.l6(S, H // 4, W // 4, srcA=c5, srcB=c3, HA=H // 8, WA=W // 8)
+        _close(_nchw(c6, 64), fmn.conv6(torch.cat([_q16(fmn.upsample(_nchw(c5, 128))), _nchw(c3, 64)], 1)), ulps=6)
+        c7 = eng.l7(S, H // 2, W // 2, srcA=c6, srcB=c2, HA=H // 4, WA=W // 4)
+        _close(_nchw(c7, 32), fmn.conv7(torch.cat([_q16(fmn.upsample(_nchw(c6, 64))), _nchw(c2, 32)], 1)), ulps=6)
+        c8 = eng.l8(S, H, W, srcA=c7, srcB=c1, HA=H // 2, WA=W // 2)
+        _close(_nchw(c8, 16), fmn.conv8(torch.cat([_q16(fmn.upsample(_nchw(c7, 32))), _nchw(c1, 16)], 1)), ulps=6)
+        lg = eng.l9(S, H, W, srcA=c8)
+        ref = fmn.conv9(_nchw(c8, 16))[:, 0]
+        assert float((lg - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+        # end to end against the fp32 module
+        full = fmn(img[None], dsp[None, None], pd[None])[0]
+        got = eng(img, dsp, pd)
+        assert float((got - full).abs().max()) < 2e-2
+        assert float((got.sum(0) - 1).abs().max()) < 1e-5
+
+
+def _plane_inputs(dec, feat_1CHW, cm, fm):
+    return dec._per_plane(feat_1CHW, cm[None], fm[None])
+
+
+@pytest.mark.gpu
+def test_decoder_layers_match_torch():
+    from mpiflow_amd.model.engine import DecoderEngine, _nhwc16
+    dev = _gpu()
+    S, H, W = 4, 128, 256
+    m = _model(S, H, W)
+    _quantise_convs(m.decoder)
+    dec = m.decoder
+    eng = DecoderEngine(dec, m.encoder.num_ch_enc, dev, amp_dtype=None)
+    g = torch.Generator().manual_seed(1)
+    key = lambda *t: "-".join(str(tuple(t)))                      # noqa: E731
+
+    def rnd(*shape):
+        return _q16(torch.rand(*shape, generator=g)).to(dev)
+
+    with torch.no_grad():
+        # (4,0): per-plane expansion of the bottleneck output alone
+        h, w = H // 32, W // 32
+        top, cm, fm = rnd(1, 512, h, w) - 0.5, rnd(S, h, w), rnd(S, h, w)
+        x = eng.up0[4](S, h, w, srcB=_nhwc16(top), cm=cm, fm=fm)
+        xin = _q16(_plane_inputs(dec, top, cm, fm))
+        _close(_nchw(x, 192), dec.convs[key("upconv", 4, 0)](xin), ulps=4)
+        # (4,1): x2 nearest of x ++ per-plane skip of the 1/16 feature map, 3 workgroup column groups
+        h, w = 2 * h, 2 * w
+        f3, cm, fm = rnd(1, 256, h, w) - 0.5, rnd(S, h, w), rnd(S, h, w)
+        y = eng.up1[4](S, h, w, srcA=x, srcB=_nhwc16(f3), cm=cm, fm=fm, HA=h // 2, WA=w // 2)
+        yin = torch.cat([F.interpolate(_nchw(x, 192), scale_factor=2, mode="nearest"), _q16(_plane_inputs(dec, f3, cm, fm))], 1)
+        _close(_nchw(y, 192), dec.convs[key("upconv", 4, 1)](yin), ulps=4)
+        # (3,0): direct gated block, reflection padding
+        z = eng.up0[3](S, h, w, srcA=y)
+        _close(_nchw(z, 96), dec.convs[key("upconv", 3, 0)](_nchw(y, 192)), ulps=4)
+        # (1,0) -> 24 channels stored as 32; (1,1) consumes them
+        a48 = (rnd(S, 20, 36, 48) - 0.3).to(torch.float16)
+        b = eng.up0[1](S, 20, 36, srcA=a48)
+        _close(_nchw(b, 24), dec.convs[key("upconv", 1, 0)](_nchw(a48, 48)), ulps=4)
+        assert float(b[..., 24:].abs().max()) == 0.0
+        f0, cm, fm = rnd(1, 64, 40, 72) - 0.5, rnd(S, 40, 72), rnd(S, 40, 72)
+        c = eng.up1[1](S, 40, 72, srcA=b, srcB=_nhwc16(f0), cm=cm, fm=fm, HA=20, WA=36)
+        cin = torch.cat([F.interpolate(_nchw(b, 24), scale_factor=2, mode="nearest"), _q16(_plane_inputs(dec, f0, cm, fm))], 1)
+        _close(_nchw(c, 24), dec.convs[key("upconv", 1, 1)](cin), ulps=4)
+        # (0,0), (0,1) (nearest only, 16 channels per tap) and the output layer (planar fp32)
+        d = eng.up0[0](S, 40, 72, srcA=c)
+        _close(_nchw(d, 12), dec.convs[key("upconv", 0, 0)](_nchw(c, 24)), ulps=4)
+        e = eng.up1[0](S, 80, 144, srcA=d, HA=40, WA=72)
+        _close(_nchw(e, 12), dec.convs[key("upconv", 0, 1)](F.interpolate(_nchw(d, 12), scale_factor=2, mode="nearest")), ulps=4)
+        raw = eng.disp0(S, 80, 144, srcA=e)
+        ref = dec.convs[key("dispconv", 0)](_nchw(e, 12))
+        assert tuple(raw.shape) == (S, 4, 80, 144)
+        assert float((raw - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+def test_predictor_engine_matches_fp32_model():
+    """Whole producer on the engine vs the fp32 torch model (same random parameters).  A randomly initialised 25-layer
+    network amplifies rounding, so the yardstick is the precision the reference itself runs at on a GPU - torch fp16
+    (`.half()`, gen_3dphoto_dynamic_v2.py:46,59,82-84): the engine (fp16 storage, fp32 accumulate and epilogue) must be at
+    least as close to fp32 as torch's fp16 autocast is, in the mean and at the 99.9th percentile, on rgb and sigma."""
+    from mpiflow_amd.model.engine import HipPredictor
+    dev = _gpu()
+    S, H, W = 8, 128, 256
+    m = _model(S, H, W, seed=5)
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(1, 3, H, W, generator=g).to(dev)
+    dsp = torch.rand(1, 1, H, W, generator=g).to(dev)
+    with torch.no_grad():
+        ref_raw, ref_cum, ref_disp = m(img, dsp, raw=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            h_raw, h_cum, _ = m(img, dsp, raw=True)
+    raw, cum, disp = HipPredictor(m, encoder_dtype=None)(img, dsp)
+    assert tuple(raw.shape) == (S, 4, H, W) and raw.dtype == torch.float32 and tuple(cum.shape) == (S, H, W)
+    assert torch.equal(disp, ref_disp[0])
+    assert float((cum - ref_cum[0]).abs().max()) < 2e-3
+
+    def act(r, c):
+        return torch.sigmoid(r[:, :3].float()), torch.relu(r[:, 3].float() * c.float()) + 1e-4
+
+    def err(x, ref):
+        d = (x - ref).abs().flatten()
+        return float(d.mean()), float(d.kthvalue(int(d.numel() * 0.999)).values)
+
+    for got, half, ref in zip(act(raw, cum), act(h_raw[0], h_cum[0]), act(ref_raw[0], ref_cum[0])):
+        (e_mean, e_tail), (h_mean, h_tail) = err(got, ref), err(half, ref)
+        assert e_mean <= h_mean and e_tail <= h_tail, (e_mean, h_mean, e_tail, h_tail)
+        assert e_mean < 5e-3
+
+
+@pytest.mark.gpu
+def test_conv_rejects_unsupported_and_bad_arguments():
+    import ctypes
+    from mpiflow_amd import _lib
+    _gpu()
+    lib = _lib.load()
+    a = _lib.MpfConvArgs()
+    assert lib.mpf_conv3x3_f16(None, None) == 10001
+    a.S, a.Hin, a.Win, a.Hout, a.Wout, a.stride = 1, 8, 8, 8, 8, 3
+    assert lib.mpf_conv3x3_f16(ctypes.byref(a), None) == 10001
+    assert b"stride" in lib.mpf_last_error()

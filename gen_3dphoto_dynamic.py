@@ -49,6 +49,9 @@ def parse(argv=None):
     p.add_argument("--planes", type=int, default=64)
     p.add_argument("--mpi-from", choices=["disparity", "npz", "model"], default="disparity")
     p.add_argument("--model-dtype", choices=["fp32", "fp16", "bf16"], default="fp32", help="autocast dtype of the network's convolutions")
+    p.add_argument("--model-engine", choices=["torch", "hip"], default="torch",
+                   help="torch: every convolution on PyTorch/MIOpen (fp32 = the reference's CPU numerics); hip: the per-plane networks on "
+                        "the MFMA convolution engine (fp16 storage, fp32 accumulate - the reference's GPU precision), one hipGraph per image")
     p.add_argument("--inpaint", choices=["auto", "cv2", "hip", "none"], default="auto")
     p.add_argument("--writers", type=int, default=8, help="writer threads (PNG encode + file I/O overlap the GPU); 0 = synchronous")
     opt, _ = p.parse_known_args(argv)
@@ -105,6 +108,10 @@ def main(argv=None):
             model = MPIPredictor.from_checkpoint(opt.ckpt_path, opt.width, opt.height).to(dev)      # :52-60
             opt.planes = model.num_planes
     amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype)
+    hip_model = None
+    if model is not None and opt.model_engine == "hip":
+        from mpiflow_amd.model.engine import HipPredictor
+        hip_model = HipPredictor(model, encoder_dtype=amp or torch.float16, graph=True)
     renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
     stats = pipeline.empty_stats()
     writer = io_formats.AsyncWriter(threads=opt.writers) if opt.writers > 0 else None
@@ -124,6 +131,8 @@ def main(argv=None):
             if opt.mpi_from == "npz":
                 z = np.load(os.path.join(opt.base, "mpis", name + ".npz"))
                 mpi, planes = torch.from_numpy(z["mpi"]).to(dev), torch.from_numpy(z["disparity"]).to(dev)
+            elif opt.mpi_from == "model" and hip_model is not None:
+                mpi, cum_mask, planes = hip_model(image, disp)             # static buffers: consumed by blend() below
             elif opt.mpi_from == "model":
                 with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):      # :92-93
                     raw, cm, pd = model(image, disp, raw=True)

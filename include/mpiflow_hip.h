@@ -205,6 +205,14 @@ typedef struct MpfConvArgs {
 
 int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream);
 
+/* The plane masks of the decoder in one pass over the feature-mask logits [S,H,W] (model/CPN/unet.py:68-69 softmax over the
+ * planes; model/CPN/decoder.py:126-130 cumulative and context masks; :131-150 their adaptive_avg_pool2d at every decoder
+ * scale).  Outputs: d_feature_mask [S,H,W] (optional), d_cum_mask [S,H,W], and for the five scales k = 2,4,8,16,32
+ * d_cm[i], d_fm[i] [S,H/k,W/k] = the k x k block means of the context mask (1 - cumulative mask of the planes in front)
+ * and of the feature mask.  d_cm / d_fm are HOST arrays of 5 device pointers.  H, W multiples of 32. */
+int mpf_plane_masks(const float *d_logits, int S, int H, int W, float *d_feature_mask, float *d_cum_mask, float *const *d_cm,
+                    float *const *d_fm, void *stream);
+
 /* THE REFERENCE'S FFI SYMBOL (external/forward_warping/warping.c:6; bound at moving_obj.py:12-13, called at :127-129).
  * Same name, same argument meaning, HOST pointers: src u8 [h*w*3], idx/idy int64 [h*w] (pre-clamped by the caller, as
  * in the reference), z f32 [h*w], warped u8 [h*w*5] (caller-owned).  Synchronous.  Runs the HIP kernels above on the

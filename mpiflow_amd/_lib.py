@@ -65,6 +65,7 @@ SIGNATURES = {
     "mpf_forward_warping_host": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
     "mpf_tune": (c_i, [ctypes.c_char_p, c_i]),
     "mpf_conv3x3_f16": (c_i, [ctypes.POINTER(MpfConvArgs), c_p]),
+    "mpf_plane_masks": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p]),
 }
 
 

@@ -55,6 +55,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b)
     return *reinterpret_cast<unsigned *>(&h);
 }
 
+__device__ __forceinline__ __half2 as_h2(unsigned w) { return *reinterpret_cast<__half2 *>(&w); }
+__device__ __forceinline__ unsigned as_u32(__half2 h) { return *reinterpret_cast<unsigned *>(&h); }
+
 __device__ __forceinline__ void unpack8(const u32x4 &v, float *f)
 {
 #pragma unroll
@@ -81,76 +84,127 @@ __device__ __forceinline__ int reflect_or_clamp(int i, int n, bool reflect)
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-// ---- loaders: 8 consecutive virtual input channels (vector vv) of plane s at conv-input pixel (y, x), as 8 fp16 -----------
+// ---- loaders ---------------------------------------------------------------------------------------------------------------
+// A thread stages the SAME 8-channel vector v of NI pixels of the tile for every chunk, so everything that depends on the
+// pixel only - border handling, source pixel indices, interpolation weights, the plane's mask values - is computed once
+// (Stage) and the per-chunk work is one or four 16-byte loads plus the arithmetic on them.
 template <int LOADER>
-__device__ __forceinline__ u32x4 load_vec(const MpfConvArgs &a, int s, int y, int x, int vv)
+struct Stage {
+    unsigned ia;            // pixel index into source A (always a valid address, also for padding pixels)
+    unsigned ib;            // pixel index into source B
+    bool ok;                // false: zero-padding pixel (or beyond the tile) -> the staged vector is zero
+};
+template <>
+struct Stage<LD_BILINEAR_CAT> {
+    unsigned ia, ib, dx, dy;            // ia: vector index of the top-left corner; dx, dy: steps to the right / lower neighbour (0 at the border)
+    float w00, w01, w10, w11;
+    bool ok;
+};
+template <>
+struct Stage<LD_NEAREST_PLANE> {
+    unsigned ia, ib;
+    __half2 cm2;            // (cm, cm)
+    unsigned masks;         // (cm, fm) as two fp16
+    bool ok;
+};
+
+template <int LOADER>
+__device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs &a, int s, int y, int x, bool in_tile)
 {
     const bool reflect = a.pad_mode == 1;
-    if (!reflect && (y < 0 || y >= a.Hin || x < 0 || x >= a.Win)) return zero4();
+    st.ok = in_tile && (reflect || (y >= 0 && y < a.Hin && x >= 0 && x < a.Win));
     y = reflect_or_clamp(y, a.Hin, reflect);
     x = reflect_or_clamp(x, a.Win, reflect);
     if constexpr (LOADER == LD_FMN_INPUT) {
-        // (r, g, b, disparity map, plane disparity, 0, 0, 0)    model/CPN/unet.py:44-50
-        if (vv != 0) return zero4();
-        const float *img = (const float *)a.srcA;
-        const float *dsp = (const float *)a.srcB;
-        const size_t n = (size_t)a.Hin * a.Win, o = (size_t)y * a.Win + x;
-        const float pd = a.plane_vals[s];
-        return u32x4{pack2(img[o], img[n + o]), pack2(img[2 * n + o], dsp[o]), pack2(pd, 0.f), 0u};
+        st.ia = (unsigned)(y * a.Win + x);
     } else if constexpr (LOADER == LD_DIRECT) {
-        if (vv * 8 >= a.CA) return zero4();
-        const u32x4 *p = (const u32x4 *)a.srcA;
-        return p[(((size_t)s * a.Hin + y) * a.Win + x) * (a.CA >> 3) + vv];
+        st.ia = (unsigned)((s * a.Hin + y) * a.Win + x);
     } else if constexpr (LOADER == LD_BILINEAR_CAT) {
-        const int va = a.CA >> 3;
-        if (vv < va) {
-            // x2 bilinear, align_corners=True (nn.Upsample in model/CPN/unet.py:42): src = dst * (in-1)/(out-1)
-            const float fy = a.fparams[0] * (float)y, fx = a.fparams[1] * (float)x;
-            int y0 = (int)fy, x0 = (int)fx;
-            const float ly = fy - (float)y0, lx = fx - (float)x0;
-            const int y1 = y0 + (y0 < a.HA - 1), x1 = x0 + (x0 < a.WA - 1);
-            const u32x4 *p = (const u32x4 *)a.srcA + (size_t)s * a.HA * a.WA * va + vv;
-            float v00[8], v01[8], v10[8], v11[8], o[8];
-            unpack8(p[((size_t)y0 * a.WA + x0) * va], v00);
-            unpack8(p[((size_t)y0 * a.WA + x1) * va], v01);
-            unpack8(p[((size_t)y1 * a.WA + x0) * va], v10);
-            unpack8(p[((size_t)y1 * a.WA + x1) * va], v11);
-            const float hy = 1.f - ly, hx = 1.f - lx;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = hy * (hx * v00[i] + lx * v01[i]) + ly * (hx * v10[i] + lx * v11[i]);
-            return pack8(o);
-        }
-        vv -= va;
-        if (vv * 8 >= a.CB) return zero4();
-        const u32x4 *p = (const u32x4 *)a.srcB;
-        return p[(((size_t)s * a.Hin + y) * a.Win + x) * (a.CB >> 3) + vv];
+        // x2 bilinear, align_corners=True (nn.Upsample in model/CPN/unet.py:42): src = dst * (in-1)/(out-1)
+        const float fy = a.fparams[0] * (float)y, fx = a.fparams[1] * (float)x;
+        int y0 = (int)fy, x0 = (int)fx;
+        y0 = y0 > a.HA - 1 ? a.HA - 1 : y0;
+        x0 = x0 > a.WA - 1 ? a.WA - 1 : x0;
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const unsigned va = (unsigned)a.CA >> 3;
+        st.ia = (unsigned)((s * a.HA + y0) * a.WA + x0) * va;
+        st.dx = x0 < a.WA - 1 ? va : 0u;
+        st.dy = y0 < a.HA - 1 ? va * (unsigned)a.WA : 0u;
+        st.w00 = hy * hx, st.w01 = hy * lx, st.w10 = ly * hx, st.w11 = ly * lx;
+        st.ib = (unsigned)((s * a.Hin + y) * a.Win + x);
     } else {
-        // LD_NEAREST_PLANE: [x2 nearest upsample of srcA (CA may be 0)] ++ [shared features * context mask, context mask,
-        // feature mask] (model/CPN/decoder.py:131-150: the per-plane expansion of an encoder feature map)
-        const int va = a.CA >> 3;
-        if (vv < va) {
-            const u32x4 *p = (const u32x4 *)a.srcA;
-            const int ya = a.HA == a.Hin ? y : (y >> 1), xa = a.HA == a.Hin ? x : (x >> 1);
-            return p[(((size_t)s * a.HA + ya) * a.WA + xa) * va + vv];
+        const int ya = a.HA == a.Hin ? y : (y >> 1), xa = a.HA == a.Hin ? x : (x >> 1);
+        st.ia = (unsigned)((s * a.HA + ya) * a.WA + xa);
+        st.ib = (unsigned)(y * a.Win + x);
+        st.cm2 = __float2half2_rn(0.f);
+        st.masks = 0u;
+        if (a.CB) {
+            const size_t o = (size_t)s * a.Hin * a.Win + st.ib;
+            const float cm = a.cm[o];
+            st.cm2 = __float2half2_rn(cm);
+            st.masks = pack2(cm, a.fm[o]);
         }
-        vv -= va;
-        if (vv * 8 >= a.CB) return zero4();
-        const size_t o = (size_t)y * a.Win + x, n = (size_t)a.Hin * a.Win;
-        const float cm = a.cm[s * n + o];
-        const int cf = a.CB - 8;                  // feature channels (multiple of 8); the last vector holds the two masks
-        if (vv * 8 < cf) {
-            const u32x4 *p = (const u32x4 *)a.srcB;
-            float f[8];
-            unpack8(p[o * (cf >> 3) + vv], f);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] *= cm;
-            return pack8(f);
-        }
-        return u32x4{pack2(cm, a.fm[s * n + o]), 0u, 0u, 0u};
     }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ u32x4 select4(bool c, const u32x4 &v) { return u32x4{c ? v[0] : 0u, c ? v[1] : 0u, c ? v[2] : 0u, c ? v[3] : 0u}; }
+
+// 8 consecutive virtual input channels (vector vv = chunk * VPP + sv) of the staged pixel, as 8 fp16.  Written without
+// divergent branches (clamped addresses + selects) so that the loads of all NI passes of a chunk can be in flight together.
+template <int LOADER, int VPP>
+__device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfConvArgs &a, int s, int chunk, int sv)
+{
+    const unsigned vv = (unsigned)(chunk * VPP + sv);
+    if constexpr (LOADER == LD_FMN_INPUT) {
+        // (r, g, b, disparity map, plane disparity, 0, 0, 0)    model/CPN/unet.py:44-50
+        const float *img = (const float *)a.srcA;
+        const float *dsp = (const float *)a.srcB;
+        const unsigned n = (unsigned)(a.Hin * a.Win), o = st.ia;
+        return select4(st.ok, u32x4{pack2(img[o], img[n + o]), pack2(img[2 * n + o], dsp[o]), pack2(a.plane_vals[s], 0.f), 0u});
+    } else if constexpr (LOADER == LD_DIRECT) {
+        const unsigned va = (unsigned)a.CA >> 3;
+        const unsigned vc = vv < va ? vv : va - 1;
+        return select4(st.ok && vv < va, ((const u32x4 *)a.srcA)[(size_t)st.ia * va + vc]);
+    } else if constexpr (LOADER == LD_BILINEAR_CAT) {
+        const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3;       // va % VPP == 0 (checked by the launcher)
+        if ((unsigned)(chunk * VPP) < va) {                                       // uniform: the whole chunk is source A
+            const u32x4 *p = (const u32x4 *)a.srcA + (st.ia + vv);
+            const u32x4 r00 = p[0], r01 = p[st.dx], r10 = p[st.dy], r11 = p[st.dy + st.dx];
+            u32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const __half2 h00 = as_h2(r00[i]), h01 = as_h2(r01[i]), h10 = as_h2(r10[i]), h11 = as_h2(r11[i]);
+                const float lo = fmaf(__low2float(h11), st.w11, fmaf(__low2float(h10), st.w10, fmaf(__low2float(h01), st.w01, __low2float(h00) * st.w00)));
+                const float hi = fmaf(__high2float(h11), st.w11, fmaf(__high2float(h10), st.w10, fmaf(__high2float(h01), st.w01, __high2float(h00) * st.w00)));
+                o[i] = pack2(lo, hi);
+            }
+            return select4(st.ok, o);
+        }
+        const unsigned vq = vv - va, vc = vq < vb ? vq : vb - 1;
+        return select4(st.ok && vq < vb, ((const u32x4 *)a.srcB)[(size_t)st.ib * vb + vc]);
+    } else {
+        // [x2 nearest upsample of srcA (CA may be 0)] ++ [shared features * context mask, context mask, feature mask]
+        // (model/CPN/decoder.py:131-150: the per-plane expansion of an encoder feature map)
+        const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3, nf = vb ? vb - 1 : 0u;
+        const bool isA = vv < va;
+        const unsigned vq = vv - va;
+        const bool isF = !isA && vq < nf, isM = !isA && vb && vq == nf;
+        const u32x4 *pa = (const u32x4 *)a.srcA + ((size_t)st.ia * va + (isA ? vv : 0u));
+        const u32x4 *pb = (const u32x4 *)a.srcB + ((size_t)st.ib * nf + (isF ? vq : 0u));
+        const u32x4 *p = isA ? pa : pb;
+        u32x4 f = zero4();
+        if (isA || isF) f = *p;                              // neither: nothing to read (CA == 0 or CB == 0 leave a null base)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned g = as_u32(__hmul2(as_h2(f[i]), st.cm2));
+            f[i] = isF ? g : f[i];
+        }
+        f[0] = isM ? st.masks : f[0];
+        return select4(st.ok, f);
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
 template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW>
@@ -159,6 +213,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const MpfConvArgs a)
     constexpr int GROUPS = TH * TW / 16, PG = GROUPS / 4, GPR = TW / 16;
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, PIXB = pix_stride_bytes(CT, ST), VPP = CT / 8;
     constexpr int KS = (9 * CT + 31) / 32, TPS = 32 / CT;      // k-steps per chunk, taps per k-step
+    constexpr int PPT = 256 / VPP, NI = (LH * LW + PPT - 1) / PPT;   // tile pixels staged per pass, passes
     static_assert(GROUPS % 4 == 0, "tile must give every wave the same number of pixel groups");
     __shared__ __attribute__((aligned(16))) unsigned char tile[LH * LW * PIXB];
 
@@ -167,6 +222,16 @@ __global__ __launch_bounds__(256) void k_conv3x3(const MpfConvArgs a)
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
     const int ix0 = ox0 * ST - 1, iy0 = oy0 * ST - 1;
 
+    // staging slots of this thread: vector sv of tile pixels sp + k * PPT
+    const int sv = tid % VPP, sp = tid / VPP;
+    Stage<LOADER> stage[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int p = sp + k * PPT;
+        const int ly = p / LW, lx = p - ly * LW;
+        stage_init<LOADER>(stage[k], a, s, iy0 + ly, ix0 + lx, p < LH * LW);
+    }
+
     f32x4 acc[PG][NB];
 #pragma unroll
     for (int g = 0; g < PG; ++g)
@@ -174,26 +239,33 @@ __global__ __launch_bounds__(256) void k_conv3x3(const MpfConvArgs a)
         for (int b = 0; b < NB; ++b) acc[g][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int q = lane >> 4, pi = lane & 15;
-    const u32x4 *wp = (const u32x4 *)a.wpack + ((size_t)cg * NB) * 64 + lane;
-    const int wstride = a.nblk * 64;                         // fragments of one k-step
+    // per-lane LDS byte offset of the tap each k-step reads (tap-packed layers: the tap depends on the lane's k-quarter)
+    int tapoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        int slot = ks * TPS + q / VPP;
+        slot = slot > 8 ? 8 : slot;                          // zero weights there; any finite operand will do
+        const int ky = slot / 3, kx = slot - ky * 3;
+        tapoff[ks] = (ky * LW + pi * ST + kx) * PIXB + (q % VPP) * 16;
+    }
+    const u32x4 *wp = (const u32x4 *)a.wpack + ((unsigned)(cg * NB) * 64u + (unsigned)lane);
+    const unsigned wstride = (unsigned)a.nblk * 64u;         // fragments of one k-step
 
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
         if (chunk) __syncthreads();
-        for (int i = tid; i < LH * LW * VPP; i += 256) {
-            const int p = i / VPP, v = i - p * VPP;
-            const int ly = p / LW, lx = p - ly * LW;
-            u32x4 val = load_vec<LOADER>(a, s, iy0 + ly, ix0 + lx, chunk * VPP + v);
-            *reinterpret_cast<u32x4 *>(tile + p * PIXB + v * 16) = val;
+        u32x4 staged[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv);
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int p = sp + k * PPT;
+            if (NI * PPT == LH * LW || p < LH * LW) *reinterpret_cast<u32x4 *>(tile + p * PIXB + sv * 16) = staged[k];
         }
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            int slot = ks * TPS + q / VPP;
-            slot = slot > 8 ? 8 : slot;                      // zero weights there; any finite operand will do
-            const int ky = slot / 3, kx = slot - ky * 3;
-            const int choff = (q % VPP) * 16;
             h8 af[NB];
-            const u32x4 *wk = wp + (size_t)(chunk * KS + ks) * wstride;
+            const u32x4 *wk = wp + (unsigned)(chunk * KS + ks) * wstride;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 u32x4 w = wk[b * 64];
@@ -202,8 +274,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const MpfConvArgs a)
 #pragma unroll
             for (int g = 0; g < PG; ++g) {
                 const int gi = wave * PG + g, gy = gi / GPR, gx = (gi - gy * GPR) * 16;
-                const int addr = ((gy * ST + ky) * LW + (gx + pi) * ST + kx) * PIXB + choff;
-                u32x4 bv = *reinterpret_cast<const u32x4 *>(tile + addr);
+                u32x4 bv = *reinterpret_cast<const u32x4 *>(tile + (gy * ST * LW + gx * ST) * PIXB + tapoff[ks]);
                 h8 bf = *reinterpret_cast<h8 *>(&bv);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) acc[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[b], bf, acc[g][b], 0, 0, 0);
@@ -290,7 +361,111 @@ int dispatch_nb(const MpfConvArgs &a, int nb, hipStream_t st)
     return MPF_ERR_UNSUPPORTED;
 }
 
+// ---- plane masks: softmax over the planes, cumulative / context masks, and their average-pooled pyramid -----------------------
+// One 1024-thread workgroup owns a 32 x 32 pixel block of all S planes; a wave owns an 8 x 8 sub-block in Morton order, so
+// the 2x2, 4x4 and 8x8 block sums are lane reductions (xor 1|2, 4|8, 16|32); the 16x16 and 32x32 sums are combined from the
+// per-wave sums parked in LDS.  Pass 1 is an online softmax (running max and sum), pass 2 normalises, accumulates the
+// cumulative mask and emits everything - the logits are read twice and nothing else is read.
+__global__ __launch_bounds__(1024) void k_plane_masks(const float *__restrict__ logits, int S, int H, int W, float *__restrict__ fmask,
+                                                       float *__restrict__ cum, float *__restrict__ cm2, float *__restrict__ fm2,
+                                                       float *__restrict__ cm4, float *__restrict__ fm4, float *__restrict__ cm8,
+                                                       float *__restrict__ fm8, float *__restrict__ cm16, float *__restrict__ fm16,
+                                                       float *__restrict__ cm32, float *__restrict__ fm32)
+{
+    extern __shared__ float wsum[];                          // [S][16 waves][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Morton order inside the wave: lane bits (x0 y0 x1 y1 x2 y2)
+    const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int wx = wave & 3, wy = wave >> 2;
+    const int x = blockIdx.x * 32 + wx * 8 + lx, y = blockIdx.y * 32 + wy * 8 + ly;
+    const bool in = x < W && y < H;
+    const size_t n = (size_t)H * W, o = (size_t)(in ? y : 0) * W + (in ? x : 0);
+    float mx = -INFINITY, sum = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float v = logits[s * n + o];
+        const float m2 = fmaxf(mx, v);
+        sum = sum * __expf(mx - m2) + __expf(v - m2);
+        mx = m2;
+    }
+    const float inv = 1.f / sum;
+    const int H2 = H >> 1, W2 = W >> 1, H4 = H >> 2, W4 = W >> 2, H8 = H >> 3, W8 = W >> 3;
+    float run = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float p = __expf(logits[s * n + o] - mx) * inv;
+        const float ctx = 1.f - run;                         // context mask: 1 - cumulative mask of the planes in front
+        run += p;
+        if (in) {
+            cum[s * n + o] = run;
+            if (fmask) fmask[s * n + o] = p;
+        }
+        float c = in ? ctx : 0.f, f = in ? p : 0.f;
+        c += __shfl_xor(c, 1); f += __shfl_xor(f, 1);
+        c += __shfl_xor(c, 2); f += __shfl_xor(f, 2);
+        if ((lane & 3) == 0 && in) {
+            const size_t q = (size_t)s * H2 * W2 + (size_t)(y >> 1) * W2 + (x >> 1);
+            cm2[q] = c * 0.25f; fm2[q] = f * 0.25f;
+        }
+        c += __shfl_xor(c, 4); f += __shfl_xor(f, 4);
+        c += __shfl_xor(c, 8); f += __shfl_xor(f, 8);
+        if ((lane & 15) == 0 && in) {
+            const size_t q = (size_t)s * H4 * W4 + (size_t)(y >> 2) * W4 + (x >> 2);
+            cm4[q] = c * 0.0625f; fm4[q] = f * 0.0625f;
+        }
+        c += __shfl_xor(c, 16); f += __shfl_xor(f, 16);
+        c += __shfl_xor(c, 32); f += __shfl_xor(f, 32);
+        if (lane == 0) {
+            if (in) {
+                const size_t q = (size_t)s * H8 * W8 + (size_t)(y >> 3) * W8 + (x >> 3);
+                cm8[q] = c * (1.f / 64.f); fm8[q] = f * (1.f / 64.f);
+            }
+            wsum[(s * 16 + wave) * 2] = c;
+            wsum[(s * 16 + wave) * 2 + 1] = f;
+        }
+    }
+    __syncthreads();
+    // 16x16 (4 per block) and 32x32 (1 per block) sums for every plane
+    const int H16 = H >> 4, W16 = W >> 4, H32 = H >> 5, W32 = W >> 5;
+    for (int i = tid; i < S * 4; i += 1024) {
+        const int s = i >> 2, k = i & 3, kx = k & 1, ky = k >> 1;
+        const int bx = blockIdx.x * 2 + kx, by = blockIdx.y * 2 + ky;
+        float c = 0.f, f = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int w = (ky * 2 + (j >> 1)) * 4 + kx * 2 + (j & 1);
+            c += wsum[(s * 16 + w) * 2];
+            f += wsum[(s * 16 + w) * 2 + 1];
+        }
+        if (bx < W16 && by < H16) {
+            const size_t q = (size_t)s * H16 * W16 + (size_t)by * W16 + bx;
+            cm16[q] = c * (1.f / 256.f); fm16[q] = f * (1.f / 256.f);
+        }
+    }
+    for (int s = tid; s < S; s += 1024) {
+        float c = 0.f, f = 0.f;
+        for (int w = 0; w < 16; ++w) {
+            c += wsum[(s * 16 + w) * 2];
+            f += wsum[(s * 16 + w) * 2 + 1];
+        }
+        if ((int)blockIdx.x < W32 && (int)blockIdx.y < H32) {
+            const size_t q = (size_t)s * H32 * W32 + (size_t)blockIdx.y * W32 + blockIdx.x;
+            cm32[q] = c * (1.f / 1024.f); fm32[q] = f * (1.f / 1024.f);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int mpf_plane_masks(const float *d_logits, int S, int H, int W, float *d_feature_mask, float *d_cum_mask, float *const *d_cm,
+                               float *const *d_fm, void *stream)
+{
+    MPF_REQUIRE(d_logits && d_cum_mask && d_cm && d_fm, "mpf_plane_masks: null pointer");
+    MPF_REQUIRE(S > 0 && S <= 512 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, "mpf_plane_masks: H and W must be multiples of 32 (five x2 scales), 1 <= S <= 512");
+    for (int i = 0; i < 5; ++i) MPF_REQUIRE(d_cm[i] && d_fm[i], "mpf_plane_masks: null pyramid level %d", i);
+    dim3 grid(W / 32, H / 32);
+    hipLaunchKernelGGL(k_plane_masks, grid, dim3(1024), (size_t)S * 16 * 2 * sizeof(float), (hipStream_t)stream, d_logits, S, H, W, d_feature_mask,
+                       d_cum_mask, d_cm[0], d_fm[0], d_cm[1], d_fm[1], d_cm[2], d_fm[2], d_cm[3], d_fm[3], d_cm[4], d_fm[4]);
+    return mpf_launch_status("k_plane_masks");
+}
 
 extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
 {
@@ -305,6 +480,7 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     MPF_REQUIRE((a.CA & 7) == 0 && (a.CB & 7) == 0, "mpf_conv3x3_f16: channel counts must be padded to multiples of 8");
     MPF_REQUIRE(a.wpack && a.ep && a.out, "mpf_conv3x3_f16: null weights/epilogue/output");
     MPF_REQUIRE(a.pad_mode == 0 || (a.Hin >= 2 && a.Win >= 2), "mpf_conv3x3_f16: reflection padding needs at least 2 rows and columns");
+    MPF_REQUIRE(a.loader != LD_BILINEAR_CAT || (a.CA % a.ct == 0 && a.CA > 0 && a.CB > 0), "mpf_conv3x3_f16: the upsampled source must fill whole chunks");
     MPF_REQUIRE((size_t)a.S * a.ncg <= 65535, "mpf_conv3x3_f16: planes x channel groups exceeds the grid limit");
     const int nb = a.nblk / a.ncg;
     const int key = a.loader * 1000 + a.epi * 100 + a.ct * 1 + a.stride * 10000;

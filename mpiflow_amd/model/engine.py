@@ -235,21 +235,16 @@ class DecoderEngine:
                 self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad16(cx), cx)], loader=LD_NEAREST_PLANE, ct=16)
         self.disp0 = G(device, decoder.convs[key("dispconv", 0)], None, [(16, dec[0])], loader=LD_DIRECT, ct=16, planar=True)
 
-    def __call__(self, feats, feature_mask_SHW):
+    def __call__(self, feats, masks):
+        """feats: the encoder's five feature maps [1,C,h,w]; masks: plane_masks(logits) -> (raw [S,4,H,W] fp32, cum_mask)"""
         d = self.decoder
-        S, H, W = feature_mask_SHW.shape
+        S, H, W = masks["cum"].shape
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             top = d.conv_up2(d.upsample(d.conv_up1(d.upsample(d.conv_down2(d.downsample(d.conv_down1(d.downsample(feats[-1]))))))))
-        cum_mask = torch.cumsum(feature_mask_SHW, dim=0)
-        context = 1 - torch.cat([torch.zeros_like(cum_mask[-1:]), cum_mask[:-1]], dim=0)
-
-        def masks(h, w):
-            return (F.adaptive_avg_pool2d(context[None], (h, w))[0].contiguous(),
-                    F.adaptive_avg_pool2d(feature_mask_SHW[None], (h, w))[0].contiguous())
-
         h, w = top.shape[-2:]
-        cm, fm = masks(h, w)
-        x = self.up0[4](S, h, w, srcB=_nhwc16(top), cm=cm, fm=fm)
+        if (h * 32, w * 32) != (H, W):
+            raise ValueError("bottleneck output is %s, expected %s" % ((h, w), (H // 32, W // 32)))
+        x = self.up0[4](S, h, w, srcB=_nhwc16(top), cm=masks["cm"][4], fm=masks["fm"][4])
         for i in range(4, -1, -1):
             if i < 4:
                 x = self.up0[i](S, h, w, srcA=x)
@@ -259,13 +254,29 @@ class DecoderEngine:
                 f = feats[i - 1]
                 if tuple(f.shape[-2:]) != (h, w):
                     raise ValueError("encoder feature %d is %s, decoder expects %s" % (i - 1, tuple(f.shape[-2:]), (h, w)))
-                cm, fm = masks(h, w)
-                x = self.up1[i](S, h, w, srcA=x, srcB=_nhwc16(f), cm=cm, fm=fm, HA=ha, WA=wa)
+                x = self.up1[i](S, h, w, srcA=x, srcB=_nhwc16(f), cm=masks["cm"][i - 1], fm=masks["fm"][i - 1], HA=ha, WA=wa)
             else:
                 x = self.up1[i](S, h, w, srcA=x, HA=ha, WA=wa)
-        raw = self.disp0(S, h, w, srcA=x)
-        cur = cum_mask if (h, w) == (H, W) else F.adaptive_avg_pool2d(cum_mask[None], (h, w))[0]
-        return raw, cur.contiguous()
+        return self.disp0(S, h, w, srcA=x), masks["cum"]
+
+
+def plane_masks(logits_SHW, want_feature_mask=False):
+    """mpf_plane_masks: softmax over the planes + cumulative mask + the context / feature mask pyramid (H/2 .. H/32) in one
+    pass over the logits.  -> dict(cum [S,H,W], cm [5 x [S,H/k,W/k]], fm [...], fmask [S,H,W] or None)"""
+    S, H, W = logits_SHW.shape
+    dev = logits_SHW.device
+    lg = logits_SHW.float().contiguous()
+    cum = torch.empty_like(lg)
+    fmask = torch.empty_like(lg) if want_feature_mask else None
+    cm = [torch.empty(S, H >> k, W >> k, dtype=torch.float32, device=dev) for k in range(1, 6)]
+    fm = [torch.empty_like(t) for t in cm]
+    arr = lambda ts: (ctypes.c_void_p * 5)(*[t.data_ptr() for t in ts])            # noqa: E731
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.load().mpf_plane_masks(ctypes.c_void_p(lg.data_ptr()), S, H, W,
+                                               ctypes.c_void_p(fmask.data_ptr()) if fmask is not None else None,
+                                               ctypes.c_void_p(cum.data_ptr()), arr(cm), arr(fm), stream), "mpf_plane_masks")
+    return dict(cum=cum, cm=cm, fm=fm, fmask=fmask)
 
 
 def pad16(c):
@@ -273,9 +284,13 @@ def pad16(c):
 
 
 class HipPredictor:
-    """MPIPredictor.forward(raw=True) (model/AdaMPI.py:55-78) for one image with the per-plane networks on the HIP engine."""
+    """MPIPredictor.forward(raw=True) (model/AdaMPI.py:55-78) for one image with the per-plane networks on the HIP engine.
 
-    def __init__(self, model, encoder_dtype=torch.float16):
+    graph=True captures the whole forward (torch encoder + 21 HIP launches) into one hipGraph per input size and replays
+    it: the forward is ~30 launches of a few hundred microseconds each, so Python/launch overhead would otherwise be as long
+    as the GPU work.  With a graph the returned tensors are STATIC buffers, overwritten by the next call."""
+
+    def __init__(self, model, encoder_dtype=torch.float16, graph=False):
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.MpiFlowHipError("HipPredictor needs the model on the GPU; there is no CPU path")
@@ -283,16 +298,46 @@ class HipPredictor:
         self.encoder_dtype = encoder_dtype
         self.fmn = FeatMaskEngine(model.fmn, dev)
         self.dec = DecoderEngine(model.decoder, model.encoder.num_ch_enc, dev, amp_dtype=encoder_dtype)
+        self.graph = graph
+        self._graphs = {}
+        # constants the torch parts would otherwise copy from the host on every call (not allowed while capturing a graph)
+        model.encoder.img_mean = model.encoder.img_mean.to(dev)
+        model.encoder.img_std = model.encoder.img_std.to(dev)
+        self._plane_disp = model.plane_disparities(torch.zeros(1, device=dev))[0].contiguous()
+
+    @torch.no_grad()
+    def _forward(self, src_imgs, src_depths):
+        m = self.model
+        disp = self._plane_disp
+        masks = plane_masks(self.fmn.logits(src_imgs[0], src_depths[0, 0], disp))
+        with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=self.encoder_dtype is not None):
+            feats = m.encoder(src_imgs, src_depths)
+        raw, cum = self.dec(feats, masks)
+        return raw, cum, disp
 
     @torch.no_grad()
     def __call__(self, src_imgs, src_depths):
         """(image [1,3,H,W], disparity [1,1,H,W]) -> (raw [S,4,H,W] fp32, cum_mask [S,H,W] fp32, plane disparities [S])"""
         if src_imgs.shape[0] != 1:
             raise ValueError("HipPredictor runs one image at a time (the S planes are the batch)")
-        m = self.model
-        disp = m.plane_disparities(src_imgs)[0]
-        fmask = self.fmn(src_imgs[0], src_depths[0, 0], disp)
-        with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=self.encoder_dtype is not None):
-            feats = m.encoder(src_imgs, src_depths)
-        raw, cum = self.dec(feats, fmask)
-        return raw, cum, disp
+        if not self.graph:
+            return self._forward(src_imgs, src_depths)
+        key = (tuple(src_imgs.shape), src_imgs.device.index)
+        if key not in self._graphs:
+            with torch.cuda.device(src_imgs.device):
+                s_img, s_dsp = src_imgs.float().clone(), src_depths.float().clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                 # warm-up off the capture: MIOpen picks its kernels, caches fill
+                    for _ in range(2):
+                        self._forward(s_img, s_dsp)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._forward(s_img, s_dsp)
+            self._graphs[key] = (g, s_img, s_dsp, out)
+        g, s_img, s_dsp, out = self._graphs[key]
+        s_img.copy_(src_imgs)
+        s_dsp.copy_(src_depths)
+        g.replay()
+        return out

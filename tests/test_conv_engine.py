@@ -197,6 +197,26 @@ def test_decoder_layers_match_torch():
 
 
 @pytest.mark.gpu
+def test_plane_masks_match_torch():
+    """mpf_plane_masks == softmax / cumsum / context mask / adaptive_avg_pool2d of the reference decoder (fp32 sum order aside)."""
+    from mpiflow_amd.model.engine import plane_masks
+    dev = _gpu()
+    S, H, W = 7, 96, 160
+    g = torch.Generator().manual_seed(4)
+    lg = (torch.randn(S, H, W, generator=g) * 3).to(dev)
+    got = plane_masks(lg, want_feature_mask=True)
+    fm = torch.softmax(lg, dim=0)
+    cum = torch.cumsum(fm, dim=0)
+    ctx = 1 - torch.cat([torch.zeros_like(cum[-1:]), cum[:-1]], dim=0)
+    assert float((got["fmask"] - fm).abs().max()) < 2e-6
+    assert float((got["cum"] - cum).abs().max()) < 4e-6
+    for i, k in enumerate((2, 4, 8, 16, 32)):
+        assert tuple(got["cm"][i].shape) == (S, H // k, W // k)
+        assert float((got["cm"][i] - F.adaptive_avg_pool2d(ctx[None], (H // k, W // k))[0]).abs().max()) < 4e-6
+        assert float((got["fm"][i] - F.adaptive_avg_pool2d(fm[None], (H // k, W // k))[0]).abs().max()) < 4e-6
+
+
+@pytest.mark.gpu
 def test_predictor_engine_matches_fp32_model():
     """Whole producer on the engine vs the fp32 torch model (same random parameters).  A randomly initialised 25-layer
     network amplifies rounding, so the yardstick is the precision the reference itself runs at on a GPU - torch fp16
@@ -229,6 +249,23 @@ def test_predictor_engine_matches_fp32_model():
         (e_mean, e_tail), (h_mean, h_tail) = err(got, ref), err(half, ref)
         assert e_mean <= h_mean and e_tail <= h_tail, (e_mean, h_mean, e_tail, h_tail)
         assert e_mean < 5e-3
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager():
+    """One captured hipGraph per input size; replays with new inputs give exactly the eager results."""
+    from mpiflow_amd.model.engine import HipPredictor
+    dev = _gpu()
+    S, H, W = 4, 128, 128
+    m = _model(S, H, W, seed=7)
+    eager, graphed = HipPredictor(m, encoder_dtype=None), HipPredictor(m, encoder_dtype=None, graph=True)
+    g = torch.Generator().manual_seed(9)
+    for _ in range(3):
+        img, dsp = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 1, H, W, generator=g).to(dev)
+        r0, c0, _ = eager(img, dsp)
+        r1, c1, _ = graphed(img, dsp)
+        assert torch.equal(r0, r1) and torch.equal(c0, c1)
+    assert len(graphed._graphs) == 1
 
 
 @pytest.mark.gpu

@@ -239,6 +239,33 @@ def test_cli_with_network_producer(dev, tmp_path):
     assert Image.open(out / "dst_images" / "a_0.png").size == (128, 128)
 
 
+def test_cli_with_network_on_hip_engine(dev, tmp_path):
+    """--model-engine hip: the per-plane networks on the MFMA engine, replayed from one hipGraph per image; two images so the
+    captured graph is replayed with new inputs (replay == eager is checked in tests/test_conv_engine.py)."""
+    import subprocess, sys, os
+    from PIL import Image
+    from mpiflow_amd import io_formats
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = tmp_path / "data"
+    for d in ("images", "disps", "masks"):
+        (base / d).mkdir(parents=True)
+    rs = np.random.RandomState(2)
+    for n in ("a", "b"):
+        Image.fromarray((rs.rand(100, 140, 3) * 255).astype(np.uint8)).save(base / "images" / (n + ".png"))
+        Image.fromarray((rs.rand(100, 140) * 255).astype(np.uint8)).save(base / "disps" / (n + ".png"))
+        m = np.zeros((100, 140), np.uint8); m[30:60, 40:90] = 1
+        Image.fromarray(m).save(base / "masks" / (n + ".png"))
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--base", str(base), "--out", str(out), "--width", "128",
+                        "--height", "128", "--repeat", "1", "--planes", "8", "--inpaint", "hip", "--mpi-from", "model", "--ckpt_path", "random:3",
+                        "--model-engine", "hip"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    flows = [io_formats.read_flo(str(out / "flows" / (n + "_0.flo"))) for n in ("a", "b")]
+    for f in flows:
+        assert f.shape == (128, 128, 2) and np.isfinite(f).all()
+    assert not np.array_equal(flows[0], flows[1])                         # the replay really saw the second image
+
+
 def test_hard_flow_entry_point(dev):
     """hard_flow=True: flow of the arg-max-weight plane.  A 1-ulp exp difference can move an arg-max between two planes with
     (nearly) equal weights, so a small fraction of pixels may legitimately pick a different plane; the rest must match closely."""

@@ -59,3 +59,6 @@ if "--torch" in sys.argv:
         print("torch fp32 forward %.1f ms" % ev(lambda: m(img, dsp, raw=True)))
         with torch.autocast("cuda", dtype=torch.float16):
             print("torch fp16-autocast forward %.1f ms" % ev(lambda: m(img, dsp, raw=True)))
+hg = E.HipPredictor(m, graph=True)
+hg(img, dsp)
+print("engine forward replayed from one hipGraph %.2f ms" % ev(lambda: hg(img, dsp), n=10))

@@ -208,7 +208,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
 template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW>
-__global__ __launch_bounds__(256) void k_conv3x3(const MpfConvArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB <= 2 ? 3 : (NB <= 4 ? 2 : 1))))
+void k_conv3x3(const MpfConvArgs a)
 {
     constexpr int GROUPS = TH * TW / 16, PG = GROUPS / 4, GPR = TW / 16;
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, PIXB = pix_stride_bytes(CT, ST), VPP = CT / 8;
@@ -491,11 +492,14 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     case 20000 + LD_DIRECT * 1000 + EP_AFFINE_RELU * 100 + 32:        return dispatch_nb<2, 32, LD_DIRECT, EP_AFFINE_RELU>(a, nb, st);
     case 10000 + LD_DIRECT * 1000 + EP_AFFINE_RELU * 100 + 32:        return dispatch_nb<1, 32, LD_DIRECT, EP_AFFINE_RELU>(a, nb, st);
     case 10000 + LD_BILINEAR_CAT * 1000 + EP_AFFINE_RELU * 100 + 32:  return dispatch_nb<1, 32, LD_BILINEAR_CAT, EP_AFFINE_RELU>(a, nb, st);
+    case 10000 + LD_BILINEAR_CAT * 1000 + EP_AFFINE_RELU * 100 + 16:  return dispatch_nb<1, 16, LD_BILINEAR_CAT, EP_AFFINE_RELU>(a, nb, st);
     case 10000 + LD_DIRECT * 1000 + EP_AFFINE_RELU_F32 * 100 + 16:    return dispatch_nb<1, 16, LD_DIRECT, EP_AFFINE_RELU_F32>(a, nb, st);
     // gated decoder (reflection padding)
     case 10000 + LD_NEAREST_PLANE * 1000 + EP_GATED_ELU * 100 + 32:   return dispatch_nb<1, 32, LD_NEAREST_PLANE, EP_GATED_ELU>(a, nb, st);
     case 10000 + LD_NEAREST_PLANE * 1000 + EP_GATED_ELU * 100 + 16:   return dispatch_nb<1, 16, LD_NEAREST_PLANE, EP_GATED_ELU>(a, nb, st);
     case 10000 + LD_DIRECT * 1000 + EP_GATED_ELU * 100 + 32:          return dispatch_nb<1, 32, LD_DIRECT, EP_GATED_ELU>(a, nb, st);
+    case 10000 + LD_DIRECT * 1000 + EP_GATED_ELU * 100 + 16:          return dispatch_nb<1, 16, LD_DIRECT, EP_GATED_ELU>(a, nb, st);
+    case 10000 + LD_DIRECT * 1000 + EP_AFFINE_RELU * 100 + 16:        return dispatch_nb<1, 16, LD_DIRECT, EP_AFFINE_RELU>(a, nb, st);
     case 10000 + LD_DIRECT * 1000 + EP_GATED_PLANAR_F32 * 100 + 16:   return dispatch_nb<1, 16, LD_DIRECT, EP_GATED_PLANAR_F32>(a, nb, st);
     }
     mpf_set_error("mpf_conv3x3_f16: combination loader=%d epilogue=%d ct=%d stride=%d is not built", a.loader, a.epi, a.ct, a.stride);

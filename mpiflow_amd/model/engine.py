@@ -24,6 +24,15 @@ LD_FMN_INPUT, LD_DIRECT, LD_BILINEAR_CAT, LD_NEAREST_PLANE = 0, 1, 2, 3
 EP_AFFINE_RELU, EP_AFFINE_RELU_F32, EP_GATED_ELU, EP_GATED_PLANAR_F32 = 0, 1, 2, 3
 
 
+def _ct(layer, default):
+    """Channels staged per tap and chunk for a layer; MPIFLOW_CT="l7=32,up1_1=16" overrides (tuning aid)."""
+    import os
+    for item in os.environ.get("MPIFLOW_CT", "").split(","):
+        if item.partition("=")[0].strip() == layer:
+            return int(item.partition("=")[2])
+    return default
+
+
 def pad8(c):
     return (int(c) + 7) // 8 * 8
 
@@ -133,7 +142,7 @@ class ConvLayer:
                     ep[2, rf:rf + n] = shift.cpu()[c0:c0 + n]
         CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
         return cls(device, loader=loader, epi=EP_GATED_PLANAR_F32 if planar else EP_GATED_ELU, stride=1, pad_mode=1, ct=ct,
-                   vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep, nblk=nblk, ncg=ncg, Cst=cout if planar else nf_total * 16,
+                   vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep, nblk=nblk, ncg=ncg, Cst=cout if planar else pad8(cout),
                    CA=CA, CB=CB)
 
     # -- launch -------------------------------------------------------------------------------------------------------
@@ -178,10 +187,10 @@ class FeatMaskEngine:
         self.l2 = A(device, fmn.conv2, [(16, 16)], loader=LD_DIRECT, stride=2, ct=16)
         self.l3 = A(device, fmn.conv3, [(32, 32)], loader=LD_DIRECT, stride=2, ct=32)
         self.l4 = A(device, fmn.conv4, [(64, 64)], loader=LD_DIRECT, stride=2, ct=32)
-        self.l5 = A(device, fmn.conv5, [(128, 128)], loader=LD_DIRECT, stride=1, ct=32)
-        self.l6 = A(device, fmn.conv6, [(128, 128), (64, 64)], loader=LD_BILINEAR_CAT, stride=1, ct=32)
-        self.l7 = A(device, fmn.conv7, [(64, 64), (32, 32)], loader=LD_BILINEAR_CAT, stride=1, ct=32)
-        self.l8 = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_CAT, stride=1, ct=32)
+        self.l5 = A(device, fmn.conv5, [(128, 128)], loader=LD_DIRECT, stride=1, ct=_ct("l5", 32))
+        self.l6 = A(device, fmn.conv6, [(128, 128), (64, 64)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l6", 16))
+        self.l7 = A(device, fmn.conv7, [(64, 64), (32, 32)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l7", 16))
+        self.l8 = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l8", 16))
         self.l9 = A(device, fmn.conv9, [(16, 16)], loader=LD_DIRECT, stride=1, ct=16, f32_out=True)
 
     def logits(self, image_3HW, disp_HW, plane_disp_S):
@@ -223,16 +232,16 @@ class DecoderEngine:
         for i in range(4, -1, -1):
             blk0, blk1 = decoder.convs[key("upconv", i, 0)], decoder.convs[key("upconv", i, 1)]
             if i == 4:
-                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(0, 0), (enc[4] + 8, enc[4] + 2)], loader=LD_NEAREST_PLANE, ct=32)
+                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(0, 0), (enc[4] + 8, enc[4] + 2)], loader=LD_NEAREST_PLANE, ct=_ct("up0_4", 32))
             else:
                 cin = dec[i + 1]
-                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(pad16(cin), cin)], loader=LD_DIRECT, ct=32)
+                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(pad8(cin), cin)], loader=LD_DIRECT, ct=_ct("up0_%d" % i, 32))
             cx = dec[i]
             if i > 0:
-                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad16(cx), cx), (enc[i - 1] + 8, enc[i - 1] + 2)],
-                                loader=LD_NEAREST_PLANE, ct=32)
+                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx), (enc[i - 1] + 8, enc[i - 1] + 2)],
+                                loader=LD_NEAREST_PLANE, ct=_ct("up1_%d" % i, 16 if i == 1 else 32))
             else:
-                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad16(cx), cx)], loader=LD_NEAREST_PLANE, ct=16)
+                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx)], loader=LD_NEAREST_PLANE, ct=16)
         self.disp0 = G(device, decoder.convs[key("dispconv", 0)], None, [(16, dec[0])], loader=LD_DIRECT, ct=16, planar=True)
 
     def __call__(self, feats, masks):

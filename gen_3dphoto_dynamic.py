@@ -32,7 +32,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mpiflow_amd import host_math, io_formats, pipeline, synth  # noqa: E402
+from mpiflow_amd import _lib, host_math, io_formats, ops, pipeline, synth  # noqa: E402
 from mpiflow_amd.utils import utils as U  # noqa: E402
 
 
@@ -99,7 +99,8 @@ def main(argv=None):
 
     img_base, disp_base, mask_base = (os.path.join(opt.base, d) for d in ("images", "disps", "masks"))
     names = sorted(os.listdir(img_base))
-    model = None
+    model = hip_model = None
+    amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype)
     if opt.mpi_from == "model":
         from mpiflow_amd.model import MPIPredictor
         if opt.ckpt_path.startswith("random:"):
@@ -107,66 +108,106 @@ def main(argv=None):
         else:
             model = MPIPredictor.from_checkpoint(opt.ckpt_path, opt.width, opt.height).to(dev)      # :52-60
             opt.planes = model.num_planes
-    amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype)
-    hip_model = None
-    if model is not None and opt.model_engine == "hip":
-        from mpiflow_amd.model.engine import HipPredictor
-        hip_model = HipPredictor(model, encoder_dtype=amp or torch.float16, graph=True)
+        if opt.model_engine == "hip":
+            from mpiflow_amd.model.engine import HipPredictor
+            hip_model = HipPredictor(model, encoder_dtype=amp or torch.float16, graph=True)
     renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
-    stats = pipeline.empty_stats()
-    writer = io_formats.AsyncWriter(threads=opt.writers) if opt.writers > 0 else None
+    dstats = pipeline.DeviceStats(dev)
+    ring = io_formats.OutputRing(opt.height, opt.width, dev, slots=max(4, 2 * max(opt.writers, 1)), threads=max(opt.writers, 1))
+    fill_ws = torch.empty(int(_lib.load().mpf_fill_holes_workspace(opt.height, opt.width)), dtype=torch.uint8, device=dev)
     t_start = time.perf_counter()
-    from PIL import Image
+    prof = {}
+
+    class lap:                                   # MPIFLOW_PROFILE=1: cumulative host seconds per stage (with a device sync per lap)
+        on = bool(os.environ.get("MPIFLOW_PROFILE"))
+
+        def __init__(self, key):
+            self.key = key
+
+        def __enter__(self):
+            self.t = time.perf_counter()
+
+        def __exit__(self, *exc):
+            if lap.on:
+                if os.environ.get("MPIFLOW_PROFILE") != "host":          # "host": submission time only, no device sync
+                    torch.cuda.synchronize()
+                prof[self.key] = prof.get(self.key, 0.0) + time.perf_counter() - self.t
+
     import torch.nn.functional as F
-    for i, img in enumerate(names):
+    tail_stream, tail_ready = torch.cuda.Stream(device=dev), torch.cuda.Event()
+    inputs = io_formats.InputPrefetcher(names, img_base, disp_base, mask_base, owned=lambda i: (i % world) == rank, pin=True)
+    n_pairs = 0
+    it = iter(inputs)
+    while True:
+        with lap("wait for decoded inputs"):
+            item = next(it, None)
+        if item is None:
+            break
+        i, img, mask_max, ids_host, image_host, disp_host = item
         name = img.split(".")[0]
-        mine = (i % world) == rank
-        obj_mask_np = np.array(Image.open(os.path.join(mask_base, img)).convert("L"))
+        mine = image_host is not None
         if mine:
-            image = U.image_to_tensor(os.path.join(img_base, img)).to(dev)
-            disp = U.disparity_to_tensor(os.path.join(disp_base, img)).to(dev)
-            image = F.interpolate(image, size=(opt.height, opt.width), mode="bilinear", align_corners=True)   # :86-89
-            disp = F.interpolate(disp, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
+            with lap("upload + resize image, disparity, mask"):
+                image = image_host.to(dev, non_blocking=True)[None]
+                disp = disp_host.to(dev, non_blocking=True)[None]
+                ids = ids_host.to(dev, non_blocking=True)
+                image = F.interpolate(image, size=(opt.height, opt.width), mode="bilinear", align_corners=True)   # :86-89
+                disp = F.interpolate(disp, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
             cum_mask = None
-            if opt.mpi_from == "npz":
-                z = np.load(os.path.join(opt.base, "mpis", name + ".npz"))
-                mpi, planes = torch.from_numpy(z["mpi"]).to(dev), torch.from_numpy(z["disparity"]).to(dev)
-            elif opt.mpi_from == "model" and hip_model is not None:
-                mpi, cum_mask, planes = hip_model(image, disp)             # static buffers: consumed by blend() below
-            elif opt.mpi_from == "model":
-                with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):      # :92-93
-                    raw, cm, pd = model(image, disp, raw=True)
-                mpi, cum_mask, planes = raw[0].float().contiguous(), cm[0].float().contiguous(), pd[0].float()
-            else:
-                mpi, planes = mpi_from_disparity(image[0], disp[0, 0], opt.planes)
-            renderer.blend(mpi, image[0], K, planes, cum_mask=cum_mask)      # once per image; the `repeat` pairs below reuse it
+            with lap("MPI producer + blend"):
+                if opt.mpi_from == "npz":
+                    z = np.load(os.path.join(opt.base, "mpis", name + ".npz"))
+                    mpi, planes = torch.from_numpy(z["mpi"]).to(dev), torch.from_numpy(z["disparity"]).to(dev)
+                elif hip_model is not None:
+                    mpi, cum_mask, planes = hip_model(image, disp)             # static buffers: consumed by blend() below
+                elif model is not None:
+                    with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):      # :92-93
+                        raw, cm, pd = model(image, disp, raw=True)
+                    mpi, cum_mask, planes = raw[0].float().contiguous(), cm[0].float().contiguous(), pd[0].float()
+                else:
+                    mpi, planes = mpi_from_disparity(image[0], disp[0, 0], opt.planes)
+                renderer.blend(mpi, image[0], K, planes, cum_mask=cum_mask)      # once per image; the `repeat` pairs below reuse it
+                ring.submit_source(ops.png_scanlines(renderer.src_u8), [os.path.join(out, "src_images", f"{name}_{r}.png") for r in range(opt.repeat)])  # :122
         for r in range(opt.repeat):
             # every rank draws for every pair, so the stream position is identical to a single-process run
-            obj_index = np.random.randint(obj_mask_np.max()) + 1                                             # :101
-            cam_ext_dynamic = host_math.generate_random_pose(opt.ext_cz)                                      # utils.py:207
-            cam_ext = host_math.generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0])                      # utils.py:208
+            with lap("pose draws"):
+                obj_index = np.random.randint(mask_max) + 1                                                       # :101
+                cam_ext_dynamic = host_math.generate_random_pose(opt.ext_cz)                                      # utils.py:207
+                cam_ext = host_math.generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0])                      # utils.py:208
             if not mine:
                 continue
-            obj_mask = torch.from_numpy((obj_mask_np == obj_index).astype(np.float32)).to(dev)[None, None]    # :102-105
-            obj_mask = F.interpolate(obj_mask, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
-            t0 = time.perf_counter()
-            res = pipeline.render_pair(image[0], obj_mask[0, 0], mpi, planes, K, cam_ext, cam_ext_dynamic, renderer=renderer,
-                                       cum_mask=cum_mask, reuse_blend=True)
-            inpainted = U._inpaint(res["frame_mix"], res["fill_mask"], opt.inpaint)
-            torch.cuda.synchronize()
-            st = pipeline.pair_stats(res["flow_mix"], res["fill_mask"])
-            st["kernel_seconds"] = time.perf_counter() - t0
-            stats = pipeline.merge_stats(stats, st)
-            jobs = ((io_formats.write_flo, os.path.join(out, "flows", f"{name}_{r}.flo"), res["flow_mix"].cpu().numpy()),        # :120
-                    (io_formats.write_png_bgr, os.path.join(out, "dst_images", f"{name}_{r}.png"), np.array(inpainted)),         # :121
-                    (io_formats.write_png_bgr, os.path.join(out, "src_images", f"{name}_{r}.png"), res["src_np"].cpu().numpy()))  # :122
-            for fn, path, arr in jobs:
-                if writer is not None:
-                    writer.submit(fn, path, arr)
-                else:
-                    fn(path, arr)
-    if writer is not None:
-        writer.close()
+            with lap("instance mask"):
+                obj_mask = (ids == obj_index).to(torch.float32)[None, None]                                       # :102-105
+                obj_mask = F.interpolate(obj_mask, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
+            with lap("render pair"):
+                res = pipeline.render_pair(image[0], obj_mask[0, 0], mpi, planes, K, cam_ext, cam_ext_dynamic, renderer=renderer,
+                                           cum_mask=cum_mask, reuse_blend=True)
+            # the tail of a pair (hole fill: one workgroup; scanlines; statistics; copies to the host) runs on a second stream, so
+            # it overlaps the next pair's render instead of serialising a one-CU kernel into the main stream
+            tail_ready.record()
+            for tns in (res["frame_mix"], res["fill_mask"], res["flow_mix"]):
+                tns.record_stream(tail_stream)
+            with torch.cuda.stream(tail_stream):
+                tail_stream.wait_event(tail_ready)
+                with lap("hole fill + PNG scanlines"):
+                    if opt.inpaint == "hip" or (opt.inpaint == "auto" and not U.have_cv2()):
+                        frame = ops.fill_holes(res["frame_mix"], res["fill_mask"], workspace=fill_ws)
+                        scan = ops.png_scanlines(frame)
+                    else:                                                                                         # :284-286 on the host
+                        frame = U._inpaint(res["frame_mix"], res["fill_mask"], opt.inpaint)
+                        scan = torch.from_numpy(io_formats.filter_up_rgb(np.asarray(frame)[:, :, ::-1]))
+                with lap("statistics + hand-off to the writers"):
+                    dstats.add(res["flow_mix"], res["fill_mask"])
+                    ring.submit_pair(res["flow_mix"], scan, os.path.join(out, "flows", f"{name}_{r}.flo"),            # :120
+                                     os.path.join(out, "dst_images", f"{name}_{r}.png"))                              # :121
+            n_pairs += 1
+    with lap("drain writers"):
+        torch.cuda.synchronize()
+        ring.close()
+    if lap.on and rank == 0:
+        for k, v in prof.items():
+            print("  %-40s %8.3f s" % (k, v))
+    stats = dstats.result(n_pairs)
     stats["wall_seconds"] = time.perf_counter() - t_start
     total = pipeline.reduce_stats(stats)
     if rank == 0:

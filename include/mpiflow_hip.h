@@ -102,11 +102,18 @@ int mpf_merge(const float *d_frame, const float *d_frame_dyn, const float *d_mas
               const float *d_flow, const float *d_flow_dyn, const float *d_obj_mask, float thresh, int H, int W,
               float *d_flow_mix, uint8_t *d_frame_mix, uint8_t *d_fill_mask, void *stream);
 
-/* One onion-peel pass of the built-in hole fill used when OpenCV is absent (NOT cv2.inpaint's Navier-Stokes; row A13 is
- * parity-unpinned): hole pixels touching a known pixel become the rounded mean of their known
- * 8-neighbours.  img u8 [H,W,3], hole u8 [H,W] (1 = hole); *d_remaining is incremented by the holes still open. */
-int mpf_fill_holes_step(const uint8_t *d_img_in, const uint8_t *d_hole_in, int H, int W, uint8_t *d_img_out,
-                        uint8_t *d_hole_out, unsigned *d_remaining, void *stream);
+/* Built-in hole fill used when OpenCV is absent (NOT cv2.inpaint's Navier-Stokes / Telea, utils/utils.py:284-286,
+ * moving_obj.py:162; row A13 is parity-unpinned): onion peel - pass k gives every hole pixel that touches
+ * a pixel known after pass k-1 the rounded mean of those 8-neighbours.  In place on d_img u8 [H,W,3]; d_hole u8 [H,W]
+ * (1 = hole) is cleared where filled (holes without any known pixel in their connected region stay 1).  One launch
+ * sequence on the stream, no host round trip.  d_workspace: mpf_fill_holes_workspace(H, W) bytes. */
+size_t mpf_fill_holes_workspace(int H, int W);
+int mpf_fill_holes(uint8_t *d_img, uint8_t *d_hole, int H, int W, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Frame -> PNG scanlines on the device (what cv2.imwrite does first, utils/utils.py:240-242 / gen_3dphoto_dynamic_v2.py:121-122):
+ * d_bgr u8 [H,W,3] -> d_scanlines u8 [H, 1 + 3W]: filter byte 2 ("Up") followed by the RGB row minus the previous row
+ * (mod 256).  The host only deflates these bytes and wraps them in chunks (mpiflow_amd/io_formats.py). */
+int mpf_png_filter_up(const uint8_t *d_bgr, int H, int W, uint8_t *d_scanlines, void *stream);
 
 /* [3,H,W] float RGB -> [H,W,3] u8 BGR, clip(rint(x*255))  (utils/utils.py:174-177) */
 int mpf_to_u8_bgr(const float *d_img, int H, int W, uint8_t *d_out, void *stream);

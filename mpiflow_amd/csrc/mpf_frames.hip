@@ -1,0 +1,134 @@
+// mpf_frames.hip - the output side of a pair: hole fill without host round trips and the
+// PNG scanline filter, so that what leaves the GPU is ready for a GIL-free deflate on a writer thread.
+//
+// Hole filling (row A13): the reference calls cv2.inpaint(frame_mix, fill_mask, 3, INPAINT_NS), utils/utils.py:284-286 -
+// third-party OpenCV arithmetic, parity unpinned.  What is here is NOT OpenCV's Navier-Stokes inpainting: it is a
+// deterministic onion-peel fill, used when OpenCV is not installed.  Its inputs (frame_mix, fill_mask) are pinned exactly;
+// its output is documented as a deviation in DESIGN.md.
+#include "mpf_common.h"
+
+namespace {
+
+constexpr int OPEN = 0x7FFFFFFF;            // layer of a hole pixel nobody has reached yet
+constexpr int QUEUED = 0x7FFFFFFE;          // ... that sits in the queue of the next pass
+
+// layer[p] = 0 for known pixels, OPEN for holes; hole pixels that touch a known pixel form the queue of pass 1
+__global__ __launch_bounds__(256) void k_fill_init(const uint8_t *__restrict__ hole, int H, int W, int *__restrict__ layer,
+                                                  int *__restrict__ queue, int *__restrict__ count)
+{
+    const int64_t N = (int64_t)H * W, n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool front = false;
+    if (n < N) {
+        const bool h = hole[n] != 0;
+        if (h) {
+            const int y = (int)(n / W), x = (int)(n - (int64_t)y * W);
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if ((dx || dy) && yy >= 0 && yy < H && xx >= 0 && xx < W && !hole[(int64_t)yy * W + xx]) front = true;
+                }
+        }
+        layer[n] = h ? (front ? QUEUED : OPEN) : 0;
+    }
+    const unsigned long long b = __ballot(front);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && b) base = atomicAdd(count, __popcll(b));
+    base = __shfl(base, 0);
+    if (front) queue[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)n;
+}
+
+// Onion peel in ONE workgroup, frontier by frontier: pass k fills the queued pixels with the rounded mean of their
+// neighbours of layer < k (the state after pass k-1: exactly what k successive full-image passes would compute), stamps
+// them with layer k, and queues their still-open neighbours for pass k+1.  Work is proportional to the number of hole
+// pixels, the passes are separated by workgroup barriers, nothing is reported to the host: the fill is one launch.
+__global__ __launch_bounds__(1024) void k_fill_peel(uint8_t *img, uint8_t *hole, int H, int W, int *layer, int *queue_a, int *queue_b,
+                                                    const int *count)
+{
+    __shared__ int n_next;
+    volatile uint8_t *vimg = img;
+    volatile int *vlayer = layer;
+    int nq = *count;
+    int *cur = queue_a, *nxt = queue_b;
+    for (int pass = 1; nq > 0; ++pass) {
+        if (threadIdx.x == 0) n_next = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+            const int p = cur[i];
+            const int y = p / W, x = p - y * W;
+            unsigned s0 = 0, s1 = 0, s2 = 0, cnt = 0;
+            int open_nb[8], n_open = 0;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if ((dx || dy) && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        const int k = yy * W + xx, lk = vlayer[k];
+                        if (lk < pass) { s0 += vimg[3 * k]; s1 += vimg[3 * k + 1]; s2 += vimg[3 * k + 2]; ++cnt; }
+                        else if (lk == OPEN) open_nb[n_open++] = k;
+                    }
+                }
+            // cnt >= 1: p was queued by a neighbour filled in the previous pass (or touches a known pixel)
+            vimg[3 * p] = (uint8_t)((s0 + cnt / 2) / cnt);
+            vimg[3 * p + 1] = (uint8_t)((s1 + cnt / 2) / cnt);
+            vimg[3 * p + 2] = (uint8_t)((s2 + cnt / 2) / cnt);
+            vlayer[p] = pass;
+            hole[p] = 0;
+            for (int j = 0; j < n_open; ++j)
+                if (atomicCAS(&layer[open_nb[j]], OPEN, QUEUED) == OPEN) nxt[atomicAdd(&n_next, 1)] = open_nb[j];
+        }
+        __threadfence();
+        __syncthreads();
+        nq = n_next;
+        __syncthreads();
+        int *t = cur; cur = nxt; nxt = t;
+    }
+}
+
+// PNG scanlines with filter type 2 ("Up"): out[y] = (2, row[y] - row[y-1] mod 256), row[-1] = 0; BGR -> RGB on the way.
+__global__ __launch_bounds__(256) void k_png_filter_up(const uint8_t *__restrict__ bgr, int H, int W, uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t pitch = 3 * (size_t)W + 1;
+    const uint8_t *cur = bgr + ((size_t)y * W + x) * 3;
+    uint8_t *o = out + y * pitch + 1 + 3 * (size_t)x;
+    uint8_t p0 = 0, p1 = 0, p2 = 0;
+    if (y > 0) {
+        const uint8_t *up = cur - 3 * (size_t)W;
+        p0 = up[0]; p1 = up[1]; p2 = up[2];
+    }
+    o[0] = (uint8_t)(cur[2] - p2);
+    o[1] = (uint8_t)(cur[1] - p1);
+    o[2] = (uint8_t)(cur[0] - p0);
+    if (x == 0) out[y * pitch] = 2;
+}
+
+}  // namespace
+
+extern "C" size_t mpf_fill_holes_workspace(int H, int W)
+{
+    const size_t N = (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0);
+    return 3 * N * sizeof(int) + 256;               // layer map, two frontier queues, counter
+}
+
+extern "C" int mpf_fill_holes(uint8_t *d_img, uint8_t *d_hole, int H, int W, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    MPF_REQUIRE(d_img && d_hole && d_workspace && H >= 1 && W >= 1, "mpf_fill_holes: bad argument");
+    MPF_REQUIRE((size_t)H * W < 0x7FFFFFFFull / 3, "mpf_fill_holes: image too large");
+    MPF_REQUIRE(workspace_bytes >= mpf_fill_holes_workspace(H, W), "mpf_fill_holes: workspace too small (%zu < %zu)", workspace_bytes,
+                mpf_fill_holes_workspace(H, W));
+    const int64_t N = (int64_t)H * W;
+    hipStream_t st = (hipStream_t)stream;
+    int *layer = (int *)d_workspace, *qa = layer + N, *qb = qa + N, *count = qb + N;
+    MPF_HIP(hipMemsetAsync(count, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_fill_init, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_hole, H, W, layer, qa, count);
+    hipLaunchKernelGGL(k_fill_peel, dim3(1), dim3(1024), 0, st, d_img, d_hole, H, W, layer, qa, qb, count);
+    return mpf_launch_status("k_fill_peel");
+}
+
+extern "C" int mpf_png_filter_up(const uint8_t *d_bgr, int H, int W, uint8_t *d_scanlines, void *stream)
+{
+    MPF_REQUIRE(d_bgr && d_scanlines && H >= 1 && W >= 1 && H <= 65535, "mpf_png_filter_up: bad argument");
+    hipLaunchKernelGGL(k_png_filter_up, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_bgr, H, W, d_scanlines);
+    return mpf_launch_status("k_png_filter_up");
+}

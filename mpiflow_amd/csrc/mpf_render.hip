@@ -849,59 +849,3 @@ extern "C" int mpf_to_u8_bgr(const float *d_img, int H, int W, uint8_t *d_out, v
     hipLaunchKernelGGL(k_to_u8_bgr, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_img, N, d_out);
     return mpf_launch_status("k_to_u8_bgr");
 }
-
-// ---------------------------------------------------------------------------------------------------------------
-// Hole filling for the merged frame (row A13: the reference calls cv2.inpaint(frame_mix, fill_mask, 3, INPAINT_NS),
-// utils/utils.py:284-286 - third-party OpenCV arithmetic, parity unpinned).  This is NOT OpenCV's Navier-Stokes
-// inpainting: it is a deterministic onion-peel fill (each pass gives every hole pixel that touches a known pixel the
-// rounded mean of its known 8-neighbours), used when OpenCV is not installed.  Its inputs (frame_mix, fill_mask)
-// are pinned exactly; its output is documented as a deviation in DESIGN.md.
-// ---------------------------------------------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(256)
-k_fill_step(const uint8_t *__restrict__ img_in, const uint8_t *__restrict__ hole_in, int H, int W, uint8_t *__restrict__ img_out,
-            uint8_t *__restrict__ hole_out, unsigned *__restrict__ remaining)
-{
-    const int64_t N = (int64_t)H * W;
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool still = false;
-    if (n < N) {
-        const int x = (int)(n % W), y = (int)(n / W);
-        if (!hole_in[n]) {
-            img_out[3 * n] = img_in[3 * n]; img_out[3 * n + 1] = img_in[3 * n + 1]; img_out[3 * n + 2] = img_in[3 * n + 2];
-            hole_out[n] = 0;
-        } else {
-            unsigned sum0 = 0, sum1 = 0, sum2 = 0, cnt = 0;
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int yy = y + dy, xx = x + dx;
-                    if ((dx || dy) && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                        const int64_t k = (int64_t)yy * W + xx;
-                        if (!hole_in[k]) { sum0 += img_in[3 * k]; sum1 += img_in[3 * k + 1]; sum2 += img_in[3 * k + 2]; ++cnt; }
-                    }
-                }
-            if (cnt) {
-                img_out[3 * n] = (uint8_t)((sum0 + cnt / 2) / cnt);
-                img_out[3 * n + 1] = (uint8_t)((sum1 + cnt / 2) / cnt);
-                img_out[3 * n + 2] = (uint8_t)((sum2 + cnt / 2) / cnt);
-                hole_out[n] = 0;
-            } else {
-                img_out[3 * n] = img_in[3 * n]; img_out[3 * n + 1] = img_in[3 * n + 1]; img_out[3 * n + 2] = img_in[3 * n + 2];
-                hole_out[n] = 1;
-                still = true;
-            }
-        }
-    }
-    const unsigned long long b = __ballot(still);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(remaining, (unsigned)__popcll(b));
-}
-
-extern "C" int mpf_fill_holes_step(const uint8_t *d_img_in, const uint8_t *d_hole_in, int H, int W, uint8_t *d_img_out,
-                                   uint8_t *d_hole_out, unsigned *d_remaining, void *stream)
-{
-    MPF_REQUIRE(d_img_in && d_hole_in && d_img_out && d_hole_out && d_remaining && H >= 1 && W >= 1, "mpf_fill_holes_step: bad argument");
-    const int64_t N = (int64_t)H * W;
-    hipLaunchKernelGGL(k_fill_step, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_img_in, d_hole_in, H, W,
-                       d_img_out, d_hole_out, d_remaining);
-    return mpf_launch_status("k_fill_step");
-}

@@ -55,7 +55,7 @@ def _ptr(t):
 
 def upload_params(host_buf, device):
     """Small per-call matrices -> device (one async H2D copy of a few KB on the current stream)."""
-    return host_buf.to(device=device, non_blocking=False)
+    return host_buf.pin_memory().to(device=device, non_blocking=True)
 
 
 # ---- fused hot path ---------------------------------------------------------------------------------------------
@@ -176,22 +176,32 @@ def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.9
 
 
 @_on_device
-def fill_holes(img_HW3_u8, hole_HW_u8, max_passes=None):
-    """Built-in deterministic hole fill (onion peel; NOT OpenCV's algorithm - see DESIGN.md, row A13)."""
+def fill_holes(img_HW3_u8, hole_HW_u8, out=None, hole_out=None, workspace=None):
+    """Built-in deterministic hole fill (onion peel; NOT OpenCV's algorithm - see DESIGN.md, row A13).  Stream-ordered, no
+    host synchronisation.  Returns the filled copy (`out`); `hole_out` (optional) receives the holes still open."""
     lib = _lib.load()
-    a = _dev(img_HW3_u8, "img", torch.uint8).clone()
-    ha = _dev(hole_HW_u8, "hole", torch.uint8).clone()
-    H, W, _ = a.shape
-    b, hb = torch.empty_like(a), torch.empty_like(ha)
-    rem = torch.zeros(1, dtype=torch.int32, device=a.device)
-    max_passes = max_passes or (H + W)
-    for it in range(max_passes):
-        rem.zero_()
-        _lib.check(lib.mpf_fill_holes_step(_ptr(a), _ptr(ha), H, W, _ptr(b), _ptr(hb), _ptr(rem), _stream()), "mpf_fill_holes_step")
-        a, b, ha, hb = b, a, hb, ha
-        if it % 4 == 3 and int(rem.item()) == 0:
-            break
-    return a
+    src = _dev(img_HW3_u8, "img", torch.uint8)
+    H, W, _ = src.shape
+    out = torch.empty_like(src) if out is None else out
+    out.copy_(src)
+    hole = torch.empty((H, W), dtype=torch.uint8, device=src.device) if hole_out is None else hole_out
+    hole.copy_(_dev(hole_HW_u8, "hole", torch.uint8))
+    need = int(lib.mpf_fill_holes_workspace(H, W))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=src.device)
+    _lib.check(lib.mpf_fill_holes(_ptr(out), _ptr(hole), H, W, _ptr(workspace), need, _stream()), "mpf_fill_holes")
+    return out
+
+
+@_on_device
+def png_scanlines(img_HW3_bgr_u8, out=None):
+    """[H,W,3] u8 BGR on the device -> PNG scanlines u8 [H, 1+3W] (filter "Up", RGB order) for io_formats.png_from_scanlines"""
+    lib = _lib.load()
+    img = _dev(img_HW3_bgr_u8, "img", torch.uint8)
+    H, W, _ = img.shape
+    out = torch.empty((H, 3 * W + 1), dtype=torch.uint8, device=img.device) if out is None else out
+    _lib.check(lib.mpf_png_filter_up(_ptr(img), H, W, _ptr(out), _stream()), "mpf_png_filter_up")
+    return out
 
 
 @_on_device

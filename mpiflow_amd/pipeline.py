@@ -40,11 +40,20 @@ class PairRenderer:
         self.n_views = n_views
 
     # -- host side: small matrices ---------------------------------------------------------------------------------
+    def _constants(self, K, disparity):
+        """K^-1 and the plane depths are per-image constants: recomputed only when K / the disparities change (keyed by the
+        tensors' identity and version, so an in-place edit invalidates them)."""
+        key = (id(K), K._version, id(disparity), disparity._version) if isinstance(K, torch.Tensor) and isinstance(disparity, torch.Tensor) else None
+        if key is None or getattr(self, "_const_key", None) != key:
+            self._const = (host_math.k_inverse(K), host_math.plane_depths(disparity))
+            self._const_key = key
+            self._const_refs = (K, disparity)          # keep the keyed objects alive so their ids cannot be recycled
+        return self._const
+
     def prepare(self, K, disparity, poses):
         """poses: list of 4x4 G_tgt_src (1 or 2).  Computes K^-1, plane depths, per-plane homographies on the host
         (torch-CPU, reference expressions) and uploads them.  Returns a dict handed to run()."""
-        k_inv = host_math.k_inverse(K)
-        d = host_math.plane_depths(disparity)
+        k_inv, d = self._constants(K, disparity)
         hts, wp = [], []
         for G in poses:
             H_ts, H_st = host_math.homographies(G, k_inv, K, d)
@@ -59,8 +68,8 @@ class PairRenderer:
         reference re-blends inside every render_3dphoto_dynamic call, i.e. `repeat` times per image
         (gen_3dphoto_dynamic_v2.py:99-118); with this, every further pair of the same image runs Stage A+C flow-only
         (reads 4*S*N instead of 16*S*N, writes nothing but the flows)."""
-        ops.src_blend_flow(mpi, image, K_inv=host_math.k_inverse(K), depth_S=host_math.plane_depths(disparity), homs_tgt_src=None,
-                           out_rgba=self.rgba, src_u8=self.src_u8, cum_mask=cum_mask)
+        k_inv, d = self._constants(K, disparity)
+        ops.src_blend_flow(mpi, image, K_inv=k_inv, depth_S=d, homs_tgt_src=None, out_rgba=self.rgba, src_u8=self.src_u8, cum_mask=cum_mask)
 
     def run(self, mpi, image, prep, obj_mask, complement=(False, True), cum_mask=None, reuse_blend=False):
         """mpi [S,4,H,W], image [3,H,W], obj_mask [H,W] on device.  Two or three launches:
@@ -161,6 +170,26 @@ def pair_stats(flow_mix, fill_mask):
     mag = torch.linalg.vector_norm(flow_mix.reshape(-1, 2), dim=1)
     return dict(pairs=1, sum_flow_mag=float(mag.sum()), hole_px=float(fill_mask.sum()), kernel_seconds=0.0,
                 max_flow_mag=float(mag.max()), wall_seconds=0.0, neg_min_flow=float(-flow_mix.min()))
+
+
+class DeviceStats:
+    """The per-pair statistics accumulated ON the device (no host synchronisation per pair); result() reads them back once."""
+
+    def __init__(self, device):
+        self.sums = torch.zeros(2, dtype=torch.float64, device=device)           # sum |flow|, hole pixels
+        self.maxs = torch.full((2,), -float("inf"), dtype=torch.float32, device=device)   # max |flow|, max(-flow)
+
+    def add(self, flow_mix, fill_mask):
+        mag = torch.linalg.vector_norm(flow_mix.reshape(-1, 2), dim=1)
+        self.sums += torch.stack([mag.sum(dtype=torch.float64), fill_mask.sum(dtype=torch.float64)])
+        self.maxs = torch.maximum(self.maxs, torch.stack([mag.max(), (-flow_mix).max()]))
+
+    def result(self, pairs):
+        s, m = self.sums.cpu().tolist(), self.maxs.cpu().tolist()
+        out = empty_stats()
+        if pairs:
+            out.update(pairs=pairs, sum_flow_mag=s[0], hole_px=s[1], max_flow_mag=m[0], neg_min_flow=m[1])
+        return out
 
 
 def merge_stats(a, b):

@@ -49,6 +49,14 @@ def generate_random_pose(ext_cz, base_motions=[0.1, 0.1, 0.1]):
     return host_math.generate_random_pose(ext_cz, base_motions=base_motions)
 
 
+def have_cv2():
+    try:
+        import cv2  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
 def _inpaint(frame_mix_dev, fill_mask_dev, method):
     """Row A13.  'cv2' = the reference's own call (third-party; used when OpenCV is installed), 'hip' = built-in
     onion-peel fill (documented deviation), 'none' = leave holes white."""

@@ -1,0 +1,138 @@
+"""Output side of a pair: PNG writer, hole fill, streaming ring, input prefetch."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _rgb(h, w, seed=0):
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 0.5 + 0.3 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
+    return (np.clip(base[..., None] + 0.1 * rs.randn(h, w, 3), 0, 1) * 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 3), (48, 64), (37, 1280)])
+def test_png_writer_round_trips_through_pillow(tmp_path, shape):
+    from PIL import Image
+    from mpiflow_amd import io_formats
+    bgr = _rgb(*shape)
+    path = str(tmp_path / "f.png")
+    io_formats.write_png_bgr(path, bgr)
+    back = np.array(Image.open(path))
+    assert back.shape == bgr.shape and np.array_equal(back, bgr[:, :, ::-1])          # file stores RGB (cv2.imwrite semantics)
+    data = io_formats.png_from_scanlines(io_formats.filter_up_rgb(bgr))
+    assert np.array_equal(np.array(Image.open(io.BytesIO(data))), bgr)
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+
+
+def test_input_prefetcher_matches_the_loaders(tmp_path):
+    from PIL import Image
+    from mpiflow_amd import io_formats
+    from mpiflow_amd.utils import utils as U
+    dirs = {}
+    for d in ("images", "disps", "masks"):
+        dirs[d] = tmp_path / d
+        dirs[d].mkdir()
+    names = ["b.png", "a.png", "c.png"]
+    for k, n in enumerate(names):
+        Image.fromarray(_rgb(20, 30, k)).save(dirs["images"] / n)
+        Image.fromarray(_rgb(20, 30, 10 + k)[..., 0]).save(dirs["disps"] / n)
+        Image.fromarray((_rgb(20, 30, 20 + k)[..., 0] // 100).astype(np.uint8)).save(dirs["masks"] / n)
+    order = sorted(names)
+    got = list(io_formats.InputPrefetcher(order, str(dirs["images"]), str(dirs["disps"]), str(dirs["masks"]), owned=lambda i: i != 1))
+    assert [g[1] for g in got] == order and [g[0] for g in got] == [0, 1, 2]
+    for i, n, mask, image, disp in got:
+        assert np.array_equal(mask, np.array(Image.open(dirs["masks"] / n).convert("L")))
+        if i == 1:
+            assert image is None and disp is None
+            continue
+        assert np.array_equal(image, U.image_to_tensor(str(dirs["images"] / n))[0].numpy())
+        assert np.array_equal(disp, U.disparity_to_tensor(str(dirs["disps"] / n))[0].numpy())
+
+
+def test_input_prefetcher_surfaces_errors(tmp_path):
+    from mpiflow_amd import io_formats
+    with pytest.raises(FileNotFoundError):
+        list(io_formats.InputPrefetcher(["missing.png"], str(tmp_path), str(tmp_path), str(tmp_path), owned=lambda i: True))
+
+
+def _peel_reference(img, hole):
+    """Plain restatement of the onion peel: repeat full-image passes on a copy of the previous state."""
+    img, hole = img.astype(np.int64).copy(), hole.astype(bool).copy()
+    H, W = hole.shape
+    while True:
+        new_img, new_hole, progress = img.copy(), hole.copy(), False
+        for y, x in zip(*np.nonzero(hole)):
+            acc, cnt = np.zeros(3, np.int64), 0
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    yy, xx = y + dy, x + dx
+                    if (dy or dx) and 0 <= yy < H and 0 <= xx < W and not hole[yy, xx]:
+                        acc += img[yy, xx]
+                        cnt += 1
+            if cnt:
+                new_img[y, x] = (acc + cnt // 2) // cnt
+                new_hole[y, x] = False
+                progress = True
+        img, hole = new_img, new_hole
+        if not progress:
+            return img.astype(np.uint8), hole.astype(np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["blobs", "all_hole", "no_hole", "border"])
+def test_hole_fill_matches_the_peel_definition(case):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mpiflow_amd import ops
+    dev = torch.device("cuda:0")
+    H, W = 41, 67
+    img = _rgb(H, W, 3)
+    rs = np.random.RandomState(5)
+    hole = np.zeros((H, W), np.uint8)
+    if case == "blobs":
+        hole[5:20, 8:30] = 1
+        hole[25:40, 40:66] = 1
+        hole[rs.rand(H, W) < 0.05] = 1
+    elif case == "all_hole":
+        hole[:] = 1
+    elif case == "border":
+        hole[:, :9] = 1
+        hole[-6:, :] = 1
+    ref_img, ref_hole = _peel_reference(img, hole)
+    hole_out = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    got = ops.fill_holes(torch.from_numpy(img).to(dev), torch.from_numpy(hole).to(dev), hole_out=hole_out)
+    assert np.array_equal(hole_out.cpu().numpy(), ref_hole)
+    known = ref_hole == 0
+    assert np.array_equal(got.cpu().numpy()[known], ref_img[known])
+
+
+@pytest.mark.gpu
+def test_png_scanlines_on_device_and_output_ring(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image
+    from mpiflow_amd import io_formats, ops
+    dev = torch.device("cuda:0")
+    H, W = 48, 80
+    ring = io_formats.OutputRing(H, W, dev, slots=3, threads=2)
+    frames, flows = [], []
+    for k in range(7):                                   # more pairs than slots: exercises the back-pressure path
+        bgr = _rgb(H, W, k)
+        flow = np.random.RandomState(k).randn(H, W, 2).astype(np.float32)
+        scan = ops.png_scanlines(torch.from_numpy(bgr).to(dev))
+        assert np.array_equal(scan.cpu().numpy(), io_formats.filter_up_rgb(bgr[:, :, ::-1]))
+        ring.submit_pair(torch.from_numpy(flow).to(dev), scan, str(tmp_path / ("f%d.flo" % k)), str(tmp_path / ("d%d.png" % k)))
+        frames.append(bgr)
+        flows.append(flow)
+    ring.submit_source(ops.png_scanlines(torch.from_numpy(frames[0]).to(dev)), [str(tmp_path / ("s%d.png" % r)) for r in range(3)])
+    ring.close()
+    for k in range(7):
+        assert np.array_equal(np.array(Image.open(tmp_path / ("d%d.png" % k)))[:, :, ::-1], frames[k])
+        assert np.array_equal(io_formats.read_flo(str(tmp_path / ("f%d.flo" % k))), flows[k])
+    for r in range(3):
+        assert np.array_equal(np.array(Image.open(tmp_path / ("s%d.png" % r)))[:, :, ::-1], frames[0])
+    assert sorted(os.listdir(tmp_path)) == sorted(["f%d.flo" % k for k in range(7)] + ["d%d.png" % k for k in range(7)] + ["s%d.png" % r for r in range(3)])

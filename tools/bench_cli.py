@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""End-to-end generator throughput: gen_3dphoto_dynamic.py on a synthetic KITTI-shaped dataset (375x1242 PNGs -> 384x1280,
+64 planes, repeat 5), network on the HIP engine vs torch, with and without writer threads."""
+import os, subprocess, sys, tempfile, time
+import numpy as np
+from PIL import Image
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+n_img = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 12
+tmp = tempfile.mkdtemp(prefix="mpf_cli_")
+base = os.path.join(tmp, "data")
+for d in ("images", "disps", "masks"):
+    os.makedirs(os.path.join(base, d))
+rs = np.random.RandomState(0)
+yy, xx = np.mgrid[0:375, 0:1242]
+for i in range(n_img):
+    img = (np.clip(0.5 + 0.25 * np.sin(xx / (17.0 + i)) + 0.25 * np.cos(yy / 23.0) + 0.05 * rs.randn(375, 1242), 0, 1) * 255).astype(np.uint8)
+    Image.fromarray(np.stack([img, np.roll(img, 7, 1), np.roll(img, 13, 0)], -1)).save(os.path.join(base, "images", "%04d.png" % i))
+    Image.fromarray((255 * (0.1 + 0.8 * yy / 375)).astype(np.uint8)).save(os.path.join(base, "disps", "%04d.png" % i))
+    m = np.zeros((375, 1242), np.uint8); m[150:300, 300:600] = 1; m[200:330, 800:1000] = 2
+    Image.fromarray(m).save(os.path.join(base, "masks", "%04d.png" % i))
+configs = [("hip engine, 16 writers (warm-up run)", ["--model-engine", "hip", "--writers", "16"]),
+           ("hip engine, 16 writers", ["--model-engine", "hip", "--writers", "16"]),
+           ("hip engine, 4 writers", ["--model-engine", "hip", "--writers", "4"])]
+if "--torch" in sys.argv:
+    configs.append(("torch fp16, 16 writers", ["--model-engine", "torch", "--model-dtype", "fp16", "--writers", "16"]))
+for label, extra in configs:
+    out = os.path.join(tmp, "out_" + label.replace(" ", "_").replace(",", ""))
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "gen_3dphoto_dynamic.py"), "--base", base, "--out", out, "--repeat", "5", "--mpi-from", "model",
+                        "--ckpt_path", "random:0", "--inpaint", "hip"] + extra, capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    last = [l for l in r.stdout.splitlines() if l.startswith("pairs")]
+    print("%-34s process %.1f s | %s" % (label, dt, last[-1] if last else r.stderr[-400:]))
+    for l in r.stdout.splitlines():
+        if l.startswith("  "):
+            print("      " + l)

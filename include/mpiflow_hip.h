@@ -208,6 +208,8 @@ typedef struct MpfConvArgs {
     int Cst;                          /* channels of the output tensor (NHWC pitch, or planes for the planar epilogue) */
     int loader, epi, stride, pad_mode; /* pad_mode 0 zero, 1 reflection */
     float fparams[4];
+    int wlds;                         /* 1: the A fragments of a chunk are staged in LDS once per workgroup (many-chunk / many-block
+                                         layers), 0: every wave loads its fragments from global memory (tuning choice, same results) */
 } MpfConvArgs;
 
 int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream);

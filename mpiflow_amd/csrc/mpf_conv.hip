@@ -207,16 +207,19 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
-template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB <= 2 ? 3 : (NB <= 4 ? 2 : 1))))
+template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB <= 2 ? 3 : (NB <= 6 ? 2 : 1))))
 void k_conv3x3(const MpfConvArgs a)
 {
     constexpr int GROUPS = TH * TW / 16, PG = GROUPS / 4, GPR = TW / 16;
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, PIXB = pix_stride_bytes(CT, ST), VPP = CT / 8;
     constexpr int KS = (9 * CT + 31) / 32, TPS = 32 / CT;      // k-steps per chunk, taps per k-step
     constexpr int PPT = 256 / VPP, NI = (LH * LW + PPT - 1) / PPT;   // tile pixels staged per pass, passes
+    constexpr int WVEC = KS * NB * 64, NW = (WVEC + 255) / 256;      // 16-byte weight vectors per chunk, per thread
+    constexpr int TILE_BYTES = (LH * LW * PIXB + 255) / 256 * 256;
     static_assert(GROUPS % 4 == 0, "tile must give every wave the same number of pixel groups");
-    __shared__ __attribute__((aligned(16))) unsigned char tile[LH * LW * PIXB];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *tile = lds, *wlds = lds + TILE_BYTES;      // input tile | this chunk's A fragments (shared by the 4 waves)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.z / a.ncg, cg = blockIdx.z - s * a.ncg;
@@ -249,14 +252,32 @@ void k_conv3x3(const MpfConvArgs a)
         const int ky = slot / 3, kx = slot - ky * 3;
         tapoff[ks] = (ky * LW + pi * ST + kx) * PIXB + (q % VPP) * 16;
     }
-    const u32x4 *wp = (const u32x4 *)a.wpack + ((unsigned)(cg * NB) * 64u + (unsigned)lane);
-    const unsigned wstride = (unsigned)a.nblk * 64u;         // fragments of one k-step
+    // weights (host-packed in fragment order, 1 KB per fragment).  WLDS: the chunk's KS x NB fragments go through LDS once
+    // per workgroup - per-wave fragment loads cost as much L1 time as the MFMAs they feed, which is what bounds the
+    // many-chunk / many-block layers; the few-chunk, LDS-hungry layers are better off loading fragments per wave (!WLDS).
+    const u32x4 *wbase = (const u32x4 *)a.wpack + (unsigned)(cg * NB) * 64u;
+    const unsigned wstride = (unsigned)a.nblk * 64u;         // vectors of one k-step in global memory
 
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
         if (chunk) __syncthreads();
-        u32x4 staged[NI];
+        u32x4 staged[NI], wst[WLDS ? NW : 1];
+        if constexpr (WLDS) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const unsigned v = (unsigned)(tid + j * 256);
+                const unsigned ks = v / (NB * 64), r = v - ks * (NB * 64);
+                if (NW * 256 == WVEC || v < WVEC) wst[j] = wbase[(unsigned)(chunk * KS + ks) * wstride + r];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv);
+        if constexpr (WLDS) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int v = tid + j * 256;
+                if (NW * 256 == WVEC || v < WVEC) *reinterpret_cast<u32x4 *>(wlds + v * 16) = wst[j];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int p = sp + k * PPT;
@@ -266,10 +287,11 @@ void k_conv3x3(const MpfConvArgs a)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             h8 af[NB];
-            const u32x4 *wk = wp + (unsigned)(chunk * KS + ks) * wstride;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                u32x4 w = wk[b * 64];
+                u32x4 w;
+                if constexpr (WLDS) w = *reinterpret_cast<const u32x4 *>(wlds + ((ks * NB + b) * 64 + lane) * 16);
+                else w = wbase[(unsigned)(chunk * KS + ks) * wstride + (unsigned)(b * 64 + lane)];
                 af[b] = *reinterpret_cast<h8 *>(&w);
             }
 #pragma unroll
@@ -283,67 +305,29 @@ void k_conv3x3(const MpfConvArgs a)
         }
     }
 
-    // ---- epilogue: lane holds rows 4q..4q+3 (output channels) of column pi (pixel) of every 16x16 block --------------------
-    const int rows = a.nblk * 16;
-    const float *ep0 = a.ep, *ep1 = a.ep + rows, *ep2 = a.ep + 2 * rows;
-#pragma unroll
-    for (int g = 0; g < PG; ++g) {
-        const int gi = wave * PG + g, gy = gi / GPR, gx = (gi - gy * GPR) * 16;
-        const int oy = oy0 + gy, ox = ox0 + gx + pi;
-        if (oy >= a.Hout || ox >= a.Wout) continue;
-        const size_t opix = ((size_t)s * a.Hout + oy) * a.Wout + ox;
-        if constexpr (EPI == EP_AFFINE_RELU || EPI == EP_AFFINE_RELU_F32) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int r0 = (cg * NB + b) * 16 + 4 * q;
-                float y[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = fmaxf(acc[g][b][i] * ep0[r0 + i] + ep1[r0 + i], 0.f);
-                if constexpr (EPI == EP_AFFINE_RELU) {
-                    if (r0 < a.Cst) *reinterpret_cast<u32x2 *>((__half *)a.out + opix * a.Cst + r0) = u32x2{pack2(y[0], y[1]), pack2(y[2], y[3])};
-                } else {
-                    if (r0 == 0) ((float *)a.out)[opix] = y[0];       // single-channel fp32 map [S,H,W]
-                }
-            }
-        } else {
-            constexpr int NF = NB / 2;
-#pragma unroll
-            for (int b = 0; b < NF; ++b) {
-                const int rf = (cg * NB + b) * 16 + 4 * q, rm = (cg * NB + NF + b) * 16 + 4 * q;
-                const int c0 = (cg * NF + b) * 16 + 4 * q;
-                float y[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float gsum = (acc[g][b][i] + ep0[rf + i]) * sigmoidf_(acc[g][NF + b][i] + ep0[rm + i]);
-                    if constexpr (EPI == EP_GATED_ELU) {
-                        const float t = gsum * ep1[rf + i] + ep2[rf + i];
-                        y[i] = t > 0.f ? t : (__expf(t) - 1.f);
-                    } else {
-                        y[i] = gsum;
-                    }
-                }
-                if constexpr (EPI == EP_GATED_ELU) {
-                    if (c0 < a.Cst) *reinterpret_cast<u32x2 *>((__half *)a.out + opix * a.Cst + c0) = u32x2{pack2(y[0], y[1]), pack2(y[2], y[3])};
-                } else {
-                    if (c0 < a.Cst) {                               // planar fp32 [S, Cst, H, W], Cst <= 4 channels used
-                        const size_t n = (size_t)a.Hout * a.Wout;
-                        float *o = (float *)a.out + (size_t)s * a.Cst * n + (size_t)oy * a.Wout + ox;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (c0 + i < a.Cst) o[(size_t)(c0 + i) * n] = y[i];
-                    }
-                }
-            }
-        }
+#include "mpf_conv_epilogue.inc"
+}
+
+template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS>
+int launch_w(const MpfConvArgs &a, hipStream_t st)
+{
+    constexpr int LW = TW * ST + 2, LH = TH * ST + 2, KS = (9 * CT + 31) / 32;
+    constexpr int LDS_BYTES = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + (WLDS ? KS * NB * 1024 : 0);
+    static_assert(LDS_BYTES <= 160 * 1024, "tile + weights exceed the LDS of a CU");
+    static bool attr_set = false;
+    if (!attr_set && LDS_BYTES > 64 * 1024) {
+        MPF_HIP(hipFuncSetAttribute((const void *)k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
     }
+    dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH, a.S * a.ncg);
+    hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS>), grid, dim3(256), LDS_BYTES, st, a);
+    return mpf_launch_status("k_conv3x3");
 }
 
 template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW>
 int launch(const MpfConvArgs &a, hipStream_t st)
 {
-    dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH, a.S * a.ncg);
-    hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW>), grid, dim3(256), 0, st, a);
-    return mpf_launch_status("k_conv3x3");
+    return a.wlds ? launch_w<ST, CT, LOADER, EPI, NB, TH, TW, true>(a, st) : launch_w<ST, CT, LOADER, EPI, NB, TH, TW, false>(a, st);
 }
 
 template <int ST, int CT, int LOADER, int EPI>

@@ -33,6 +33,20 @@ def _ct(layer, default):
     return default
 
 
+# layers whose weights go through LDS once per workgroup (measured per layer at 64x384x1280, profiles/r1/engine_layers.txt):
+# the many-chunk / many-block layers and the full-resolution single-block ones; the others load fragments per wave
+_WLDS_LAYERS = {"l1", "l2", "l5", "l6", "l8", "l9", "up0_4", "up1_4", "up1_3", "up1_2", "up1_1", "up0_3", "up0_2", "up0_1", "up0_0"}
+
+
+def _wlds(layer, default):
+    """MPIFLOW_WLDS="all" | "none" | "l8,up1_1" overrides the per-layer choice (tuning aid)."""
+    import os
+    v = os.environ.get("MPIFLOW_WLDS")
+    if v is None:
+        return default
+    return v == "all" or layer in v.split(",")
+
+
 def pad8(c):
     return (int(c) + 7) // 8 * 8
 
@@ -76,7 +90,8 @@ def _bn_affine(bn):
 class ConvLayer:
     """One packed layer + its launch."""
 
-    def __init__(self, device, *, loader, epi, stride, pad_mode, ct, vmap, rows_w, ep, nblk, ncg, Cst, CA, CB):
+    def __init__(self, device, *, loader, epi, stride, pad_mode, ct, vmap, rows_w, ep, nblk, ncg, Cst, CA, CB, name=""):
+        self.name, self.wlds_default = name, name in _WLDS_LAYERS
         self.loader, self.epi, self.stride, self.pad_mode, self.ct = loader, epi, stride, pad_mode, ct
         self.nchunk = vmap.numel() // ct
         self.nblk, self.ncg, self.Cst, self.CA, self.CB = nblk, ncg, Cst, CA, CB
@@ -96,7 +111,7 @@ class ConvLayer:
         return torch.tensor(idx, dtype=torch.long)
 
     @classmethod
-    def affine_relu(cls, device, cbr, segments, *, loader, stride, ct, f32_out=False):
+    def affine_relu(cls, device, cbr, segments, *, loader, stride, ct, f32_out=False, name=""):
         """Conv2d(bias) + BatchNorm(eval) + ReLU (ConvBNReLU, model/CPN/unet.py:6-15), zero padding."""
         conv, bn = cbr.layer[0], cbr.layer[1]
         cout = conv.out_channels
@@ -112,10 +127,10 @@ class ConvLayer:
         CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
         return cls(device, loader=loader, epi=EP_AFFINE_RELU_F32 if f32_out else EP_AFFINE_RELU, stride=stride, pad_mode=0, ct=ct,
                    vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep, nblk=nblk, ncg=nblk // nb, Cst=1 if f32_out else pad8(cout),
-                   CA=CA, CB=CB)
+                   CA=CA, CB=CB, name=name)
 
     @classmethod
-    def gated(cls, device, gconv, bn, segments, *, loader, ct, planar=False):
+    def gated(cls, device, gconv, bn, segments, *, loader, ct, planar=False, name=""):
         """GatedConv (+ BatchNorm + ELU when bn is given), reflection padding (model/CPN/decoder.py:10-71)."""
         cf, cmk = gconv.conv2d, gconv.mask_conv2d
         cout = cf.out_channels
@@ -143,7 +158,7 @@ class ConvLayer:
         CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
         return cls(device, loader=loader, epi=EP_GATED_PLANAR_F32 if planar else EP_GATED_ELU, stride=1, pad_mode=1, ct=ct,
                    vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep, nblk=nblk, ncg=ncg, Cst=cout if planar else pad8(cout),
-                   CA=CA, CB=CB)
+                   CA=CA, CB=CB, name=name)
 
     # -- launch -------------------------------------------------------------------------------------------------------
     def __call__(self, S, Hin, Win, srcA=None, srcB=None, cm=None, fm=None, plane_vals=None, HA=None, WA=None, out=None):
@@ -165,6 +180,7 @@ class ConvLayer:
         a.HA, a.WA = (HA if HA is not None else Hin), (WA if WA is not None else Win)
         a.ct, a.nchunk, a.nblk, a.ncg, a.Cst = self.ct, self.nchunk, self.nblk, self.ncg, self.Cst
         a.loader, a.epi, a.stride, a.pad_mode = self.loader, self.epi, self.stride, self.pad_mode
+        a.wlds = int(_wlds(self.name, self.wlds_default))
         if self.loader == LD_BILINEAR_CAT:
             a.fparams[0] = (a.HA - 1) / (Hin - 1) if Hin > 1 else 0.0
             a.fparams[1] = (a.WA - 1) / (Win - 1) if Win > 1 else 0.0
@@ -183,15 +199,15 @@ class FeatMaskEngine:
 
     def __init__(self, fmn, device):
         A = ConvLayer.affine_relu
-        self.l1 = A(device, fmn.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8)
-        self.l2 = A(device, fmn.conv2, [(16, 16)], loader=LD_DIRECT, stride=2, ct=16)
-        self.l3 = A(device, fmn.conv3, [(32, 32)], loader=LD_DIRECT, stride=2, ct=32)
-        self.l4 = A(device, fmn.conv4, [(64, 64)], loader=LD_DIRECT, stride=2, ct=32)
-        self.l5 = A(device, fmn.conv5, [(128, 128)], loader=LD_DIRECT, stride=1, ct=_ct("l5", 32))
-        self.l6 = A(device, fmn.conv6, [(128, 128), (64, 64)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l6", 16))
-        self.l7 = A(device, fmn.conv7, [(64, 64), (32, 32)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l7", 16))
-        self.l8 = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l8", 16))
-        self.l9 = A(device, fmn.conv9, [(16, 16)], loader=LD_DIRECT, stride=1, ct=16, f32_out=True)
+        self.l1 = A(device, fmn.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8, name="l1")
+        self.l2 = A(device, fmn.conv2, [(16, 16)], loader=LD_DIRECT, stride=2, ct=16, name="l2")
+        self.l3 = A(device, fmn.conv3, [(32, 32)], loader=LD_DIRECT, stride=2, ct=32, name="l3")
+        self.l4 = A(device, fmn.conv4, [(64, 64)], loader=LD_DIRECT, stride=2, ct=32, name="l4")
+        self.l5 = A(device, fmn.conv5, [(128, 128)], loader=LD_DIRECT, stride=1, ct=_ct("l5", 32), name="l5")
+        self.l6 = A(device, fmn.conv6, [(128, 128), (64, 64)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l6", 16), name="l6")
+        self.l7 = A(device, fmn.conv7, [(64, 64), (32, 32)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l7", 16), name="l7")
+        self.l8 = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l8", 16), name="l8")
+        self.l9 = A(device, fmn.conv9, [(16, 16)], loader=LD_DIRECT, stride=1, ct=16, f32_out=True, name="l9")
 
     def logits(self, image_3HW, disp_HW, plane_disp_S):
         S = plane_disp_S.numel()
@@ -232,17 +248,17 @@ class DecoderEngine:
         for i in range(4, -1, -1):
             blk0, blk1 = decoder.convs[key("upconv", i, 0)], decoder.convs[key("upconv", i, 1)]
             if i == 4:
-                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(0, 0), (enc[4] + 8, enc[4] + 2)], loader=LD_NEAREST_PLANE, ct=_ct("up0_4", 32))
+                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(0, 0), (enc[4] + 8, enc[4] + 2)], loader=LD_NEAREST_PLANE, ct=_ct("up0_4", 32), name="up0_4")
             else:
                 cin = dec[i + 1]
-                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(pad8(cin), cin)], loader=LD_DIRECT, ct=_ct("up0_%d" % i, 32))
+                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(pad8(cin), cin)], loader=LD_DIRECT, ct=_ct("up0_%d" % i, 16 if i in (1, 2, 3) else 32), name="up0_%d" % i)
             cx = dec[i]
             if i > 0:
                 self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx), (enc[i - 1] + 8, enc[i - 1] + 2)],
-                                loader=LD_NEAREST_PLANE, ct=_ct("up1_%d" % i, 16 if i == 1 else 32))
+                                loader=LD_NEAREST_PLANE, ct=_ct("up1_%d" % i, 16 if i in (1, 2, 3) else 32), name="up1_%d" % i)
             else:
-                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx)], loader=LD_NEAREST_PLANE, ct=16)
-        self.disp0 = G(device, decoder.convs[key("dispconv", 0)], None, [(16, dec[0])], loader=LD_DIRECT, ct=16, planar=True)
+                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx)], loader=LD_NEAREST_PLANE, ct=16, name="up1_0")
+        self.disp0 = G(device, decoder.convs[key("dispconv", 0)], None, [(16, dec[0])], loader=LD_DIRECT, ct=16, planar=True, name="disp0")
 
     def __call__(self, feats, masks):
         """feats: the encoder's five feature maps [1,C,h,w]; masks: plane_masks(logits) -> (raw [S,4,H,W] fp32, cum_mask)"""

@@ -260,26 +260,32 @@ class DecoderEngine:
                 self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx)], loader=LD_NEAREST_PLANE, ct=16, name="up1_0")
         self.disp0 = G(device, decoder.convs[key("dispconv", 0)], None, [(16, dec[0])], loader=LD_DIRECT, ct=16, planar=True, name="disp0")
 
-    def __call__(self, feats, masks):
-        """feats: the encoder's five feature maps [1,C,h,w]; masks: plane_masks(logits) -> (raw [S,4,H,W] fp32, cum_mask)"""
+    def shared_inputs(self, feats):
+        """The batch-1 part: bottleneck on the 1/32 feature map (torch) and the NHWC fp16 images of everything the per-plane
+        layers read.  -> (top [h,w,512], [skip feature maps NHWC fp16 for the 1/2 .. 1/16 scales])"""
         d = self.decoder
-        S, H, W = masks["cum"].shape
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             top = d.conv_up2(d.upsample(d.conv_up1(d.upsample(d.conv_down2(d.downsample(d.conv_down1(d.downsample(feats[-1]))))))))
-        h, w = top.shape[-2:]
+        return _nhwc16(top), [_nhwc16(f) for f in feats[:4]]
+
+    def __call__(self, feats, masks, shared=None):
+        """feats: the encoder's five feature maps [1,C,h,w]; masks: plane_masks(logits) -> (raw [S,4,H,W] fp32, cum_mask)"""
+        S, H, W = masks["cum"].shape
+        top, skips = shared if shared is not None else self.shared_inputs(feats)
+        h, w = top.shape[:2]
         if (h * 32, w * 32) != (H, W):
             raise ValueError("bottleneck output is %s, expected %s" % ((h, w), (H // 32, W // 32)))
-        x = self.up0[4](S, h, w, srcB=_nhwc16(top), cm=masks["cm"][4], fm=masks["fm"][4])
+        x = self.up0[4](S, h, w, srcB=top, cm=masks["cm"][4], fm=masks["fm"][4])
         for i in range(4, -1, -1):
             if i < 4:
                 x = self.up0[i](S, h, w, srcA=x)
             ha, wa = h, w
             h, w = 2 * h, 2 * w
             if i > 0:
-                f = feats[i - 1]
-                if tuple(f.shape[-2:]) != (h, w):
-                    raise ValueError("encoder feature %d is %s, decoder expects %s" % (i - 1, tuple(f.shape[-2:]), (h, w)))
-                x = self.up1[i](S, h, w, srcA=x, srcB=_nhwc16(f), cm=masks["cm"][i - 1], fm=masks["fm"][i - 1], HA=ha, WA=wa)
+                f = skips[i - 1]
+                if tuple(f.shape[:2]) != (h, w):
+                    raise ValueError("encoder feature %d is %s, decoder expects %s" % (i - 1, tuple(f.shape[:2]), (h, w)))
+                x = self.up1[i](S, h, w, srcA=x, srcB=f, cm=masks["cm"][i - 1], fm=masks["fm"][i - 1], HA=ha, WA=wa)
             else:
                 x = self.up1[i](S, h, w, srcA=x, HA=ha, WA=wa)
         return self.disp0(S, h, w, srcA=x), masks["cum"]
@@ -325,6 +331,7 @@ class HipPredictor:
         self.dec = DecoderEngine(model.decoder, model.encoder.num_ch_enc, dev, amp_dtype=encoder_dtype)
         self.graph = graph
         self._graphs = {}
+        self._side, self._fork, self._join = torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event()
         # constants the torch parts would otherwise copy from the host on every call (not allowed while capturing a graph)
         model.encoder.img_mean = model.encoder.img_mean.to(dev)
         model.encoder.img_std = model.encoder.img_std.to(dev)
@@ -334,10 +341,21 @@ class HipPredictor:
     def _forward(self, src_imgs, src_depths):
         m = self.model
         disp = self._plane_disp
+        # the batch-1 torch part (encoder, bottleneck: ~60 small launches) runs on a side stream underneath the feature-mask
+        # network, which fills the GPU on its own; the decoder joins the two
+        main = torch.cuda.current_stream()
+        self._fork.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(self._fork)
+            with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=self.encoder_dtype is not None):
+                feats = m.encoder(src_imgs, src_depths)
+            shared = self.dec.shared_inputs(feats)
+            self._join.record(self._side)
         masks = plane_masks(self.fmn.logits(src_imgs[0], src_depths[0, 0], disp))
-        with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=self.encoder_dtype is not None):
-            feats = m.encoder(src_imgs, src_depths)
-        raw, cum = self.dec(feats, masks)
+        main.wait_event(self._join)
+        for t in [shared[0]] + shared[1]:
+            t.record_stream(main)
+        raw, cum = self.dec(feats, masks, shared=shared)
         return raw, cum, disp
 
     @torch.no_grad()

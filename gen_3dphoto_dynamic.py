@@ -75,12 +75,19 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (multi-process path on a 1-GPU box): MPIFLOW_DIST_BACKEND=gloo, MPIFLOW_FORCE_DEVICE=0
+    backend = os.environ.get("MPIFLOW_DIST_BACKEND", "nccl")
+    if "MPIFLOW_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["MPIFLOW_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)        # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
 
     random.seed(opt.seed)                         # gen_3dphoto_dynamic_v2.py:38-39
     np.random.seed(opt.seed)

@@ -215,6 +215,39 @@ def test_cli_end_to_end(dev, tmp_path):
     assert Image.open(outs[0] / "dst_images" / "im0_0.png").size == (64, 48)
 
 
+def test_cli_two_ranks_write_the_files_of_one_rank(dev, tmp_path):
+    """Image sharding: two ranks (gloo, both on GPU 0 - the box has one) produce byte-identical files to a
+    single-rank run, because every rank replays the whole RNG schedule and each image is owned by exactly one rank."""
+    import subprocess, sys, os
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = tmp_path / "data"
+    for d in ("images", "disps", "masks"):
+        (base / d).mkdir(parents=True)
+    rs = np.random.RandomState(3)
+    for i in range(3):
+        Image.fromarray((rs.rand(40, 56, 3) * 255).astype(np.uint8)).save(base / "images" / ("im%d.png" % i))
+        yy, xx = np.mgrid[0:40, 0:56]
+        Image.fromarray((255 * (0.2 + 0.6 * xx / 56)).astype(np.uint8)).save(base / "disps" / ("im%d.png" % i))
+        m = np.zeros((40, 56), np.uint8); m[10:25, 15:35] = 1; m[28:36, 5:20] = 2 + (i % 2)
+        Image.fromarray(m).save(base / "masks" / ("im%d.png" % i))
+    args = ["--base", str(base), "--width", "64", "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "hip"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--out", str(one)] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(root, "gen_3dphoto_dynamic.py"), "--out", str(two)] + args,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "pairs 6 " in r.stdout and "(2 ranks)" in r.stdout
+    for sub in ("flows", "dst_images", "src_images"):
+        files = sorted(os.listdir(one / sub))
+        assert len(files) == 6 and files == sorted(os.listdir(two / sub))
+        for f in files:
+            assert open(one / sub / f, "rb").read() == open(two / sub / f, "rb").read(), "%s/%s differs between 1 and 2 ranks" % (sub, f)
+
+
 def test_cli_with_network_producer(dev, tmp_path):
     """--mpi-from model with deterministic random weights: the network's raw output goes through the fused epilogue."""
     import subprocess, sys, os

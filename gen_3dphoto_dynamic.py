@@ -46,6 +46,8 @@ def parse(argv=None):
     p.add_argument("--repeat", type=int, default=5)
     p.add_argument("--base", type=str, required=True)
     p.add_argument("--out", type=str, required=True)
+    p.add_argument("--poses", choices=["v2", "coco", "copy"], default="v2",
+                   help="pose sampler constants: utils/utils.py (gen_3dphoto_dynamic_v2.py), utils/utils_coco.py or 'utils/utils copy.py'")
     p.add_argument("--planes", type=int, default=64)
     p.add_argument("--mpi-from", choices=["disparity", "npz", "model"], default="disparity")
     p.add_argument("--model-dtype", choices=["fp32", "fp16", "bf16"], default="fp32", help="autocast dtype of the network's convolutions")
@@ -179,8 +181,8 @@ def main(argv=None):
             # every rank draws for every pair, so the stream position is identical to a single-process run
             with lap("pose draws"):
                 obj_index = np.random.randint(mask_max) + 1                                                       # :101
-                cam_ext_dynamic = host_math.generate_random_pose(opt.ext_cz)                                      # utils.py:207
-                cam_ext = host_math.generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0])                      # utils.py:208
+                cam_ext_dynamic = host_math.generate_random_pose(opt.ext_cz, profile=opt.poses)                   # utils.py:207
+                cam_ext = host_math.generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0], profile=opt.poses)   # utils.py:208
             if not mine:
                 continue
             with lap("instance mask"):

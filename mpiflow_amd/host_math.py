@@ -134,29 +134,44 @@ def transformation_from_parameters(axisangle, translation, invert=False):
     return torch.matmul(R, T) if invert else torch.matmul(T, R)
 
 
-def generate_random_pose(ext_cz, base_motions=(0.1, 0.1, 0.1), rng=None):
-    """Random camera extrinsic (utils/utils.py:121-156).  Draw order - 3x randrange(2), 3x random(), 3x randrange(2),
-    3x random() on Python's `random` - is part of the contract (seeded runs reproduce the reference's poses).
+# The reference carries three copies of its pose sampler that differ only in constants:
+#   "v2"    utils/utils.py:121-156         (gen_3dphoto_dynamic_v2.py; the default)
+#   "coco"  utils/utils_coco.py:121-154
+#   "copy"  "utils/utils copy.py":121-160
+# forward_base: the base_motions[0] value that marks the CAMERA draw (z forced forward); any other draw is an object motion
+#               and gets its translation signs halved - "coco" has neither rule.  half_angle_signs_unless: base_motions[0]
+#               value that keeps full-size rotation signs (None: never halved).
+POSE_PROFILES = {
+    "v2":   dict(default_base=(0.1, 0.1, 0.1), forward_base=0.1, cz_from_ext=True, xy_scale=None, half_angle_signs_unless=None, angle_scale=0.4),
+    "coco": dict(default_base=(0.1, 0.1, 0.1), forward_base=None, cz_from_ext=False, xy_scale=None, half_angle_signs_unless=0.05, angle_scale=0.5),
+    "copy": dict(default_base=(0.05, 0.05, 0.05), forward_base=0.05, cz_from_ext=False, xy_scale=0.3, half_angle_signs_unless=0.05, angle_scale=0.2),
+}
+
+
+def generate_random_pose(ext_cz=0.1, base_motions=None, rng=None, profile="v2"):
+    """Random camera extrinsic.  Draw order - 3x randrange(2), 3x random(), 3x randrange(2), 3x random() on Python's
+    `random` - is part of the contract (seeded runs reproduce the reference's poses), and so is the order of the float
+    operations (the pose feeds 3x3 algebra whose last ulp matters).
     `rng`: a random.Random; default = the module-level generator the reference uses.  Returns a [4,4] fp32 CPU tensor."""
     import random as _random
     rng = rng or _random
-    scx = (-1) ** rng.randrange(2)
-    scy = (-1) ** rng.randrange(2)
-    scz = (-1) ** rng.randrange(2)
-    if base_motions[0] == 0.1:
-        scz = -1                       # "most cameras move forward in kitti"
-    else:
-        scx, scy, scz = scx * 0.5, scy * 0.5, scz * 0.5
-    cx = (rng.random() * 0.1 + base_motions[0]) * scx
-    cy = (rng.random() * 0.1 + base_motions[1]) * scy
-    cz = (rng.random() * ext_cz + base_motions[2]) * scz
-    sax = (-1) ** rng.randrange(2)
-    say = (-1) ** rng.randrange(2)
-    saz = (-1) ** rng.randrange(2)
-    ax = (rng.random() * math.pi / 36.0) * sax
-    ay = (rng.random() * math.pi / 36.0) * say
-    az = (rng.random() * math.pi / 36.0) * saz
-    camera_ang = [ax * 0.4, ay * 0.4, az * 0.4]
-    axisangle = torch.from_numpy(np.array([[camera_ang]], dtype=np.float32)).float()
-    translation = torch.from_numpy(np.array([[[cx, cy, cz]]])).float()
+    prof = POSE_PROFILES[profile]
+    base = prof["default_base"] if base_motions is None else base_motions
+    sign_t = [(-1) ** rng.randrange(2) for _ in range(3)]
+    if prof["forward_base"] is not None:
+        if base[0] == prof["forward_base"]:
+            sign_t[2] = -1                                   # "most cameras move forward in kitti"
+        else:
+            sign_t = [v * 0.5 for v in sign_t]                # object motion
+    width = [0.1, 0.1, ext_cz if prof["cz_from_ext"] else 0.1]
+    t = [(rng.random() * width[i] + base[i]) * sign_t[i] for i in range(3)]
+    if prof["xy_scale"] is not None:
+        t = [t[0] * prof["xy_scale"], t[1] * prof["xy_scale"], t[2]]
+    sign_a = [(-1) ** rng.randrange(2) for _ in range(3)]
+    if prof["half_angle_signs_unless"] is not None and not base[0] == prof["half_angle_signs_unless"]:
+        sign_a = [v * 0.5 for v in sign_a]
+    ang = [(rng.random() * math.pi / 36.0) * sign_a[i] for i in range(3)]
+    ang = [v * prof["angle_scale"] for v in ang]
+    axisangle = torch.from_numpy(np.array([[ang]], dtype=np.float32)).float()
+    translation = torch.from_numpy(np.array([[t]])).float()
     return transformation_from_parameters(axisangle, translation)[0]

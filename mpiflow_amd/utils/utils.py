@@ -75,7 +75,7 @@ def _inpaint(frame_mix_dev, fill_mask_dev, method):
 
 
 def render_3dphoto_dynamic(opt, src_imgs, obj_mask, disp, mpi_all_src, disparity_all_src, k_src, k_tgt, data_path=None,
-                           name=None, hard_flow=False, mask_thresh=0.99, inpaint="auto", return_intermediates=False):
+                           name=None, hard_flow=False, mask_thresh=0.99, inpaint="auto", return_intermediates=False, pose_profile="v2"):
     """One training pair from one MPI (reference utils/utils.py:159-288).
 
     Draws the dynamic pose then the camera pose from `random` (same order as the reference), blends the source image
@@ -87,8 +87,9 @@ def render_3dphoto_dynamic(opt, src_imgs, obj_mask, disp, mpi_all_src, disparity
     dev = mpi_all_src.device
     S = mpi_all_src.shape[1]
     h, w = mpi_all_src.shape[-2:]
-    cam_ext_dynamic = generate_random_pose(opt.ext_cz)
-    cam_ext = generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0])
+    ext_cz = opt.ext_cz if pose_profile == "v2" else 0.1
+    cam_ext_dynamic = host_math.generate_random_pose(ext_cz, profile=pose_profile)
+    cam_ext = host_math.generate_random_pose(ext_cz, base_motions=[0, 0, 0], profile=pose_profile)
     out = pipeline.render_pair(src_imgs[0].to(dev, torch.float32), obj_mask.reshape(h, w).to(dev, torch.float32),
                                mpi_all_src[0].to(torch.float32), disparity_all_src[0], k_src, cam_ext, cam_ext_dynamic,
                                thresh=mask_thresh, hard_flow=hard_flow)

@@ -307,6 +307,17 @@ def gen_pose_schedule(seed=114514, n=16, ext_cz=0.15):
         dyn.append(R.utils.generate_random_pose(ext_cz).numpy())
         cam.append(R.utils.generate_random_pose(ext_cz, base_motions=[0, 0, 0]).numpy())
     save("pose_schedule", seed=seed, ext_cz=ext_cz, G_dyn=np.stack(dyn), G_cam=np.stack(cam))
+    # the two other copies of the sampler the reference ships (utils/utils_coco.py:121-154, "utils/utils copy.py":121-160)
+    extra = {}
+    V = ref_harness.variant_utils()
+    for key, mod in (("coco", V.coco), ("copy", V.copy)):
+        random.seed(seed)
+        d2, c2 = [], []
+        for _ in range(n):
+            d2.append(mod.generate_random_pose().numpy())
+            c2.append(mod.generate_random_pose(base_motions=[0, 0, 0]).numpy())
+        extra["G_dyn_" + key], extra["G_cam_" + key] = np.stack(d2), np.stack(c2)
+    save("pose_schedule_variants", seed=seed, **extra)
 
 
 def gen_geometry(seed=11):

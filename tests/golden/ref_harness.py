@@ -195,3 +195,15 @@ def modules():
     return types.SimpleNamespace(geometry=geometry, homography_sampler=homography_sampler,
                                  mpi_rendering=mpi_rendering, rendering_utils=rendering_utils,
                                  utils=ref_utils, moving_obj=moving_obj)
+
+
+def variant_utils():
+    """The two other copies of the per-image module the reference ships: utils/utils_coco.py and
+    "utils/utils copy.py" (a file name with a space: loaded by path)."""
+    install()
+    import importlib.util
+    import utils.utils_coco as coco
+    spec = importlib.util.spec_from_file_location("utils.utils_copy", os.path.join(REFERENCE_ROOT, "utils", "utils copy.py"))
+    copy = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(copy)
+    return types.SimpleNamespace(coco=coco, copy=copy)

@@ -27,6 +27,21 @@ def test_host_matrices_match_reference(name):
     assert bits_equal(H_st.numpy(), g["H_src_tgt_cam"]) == 0
 
 
+def test_pose_profiles_of_the_other_reference_variants():
+    """utils/utils_coco.py and "utils/utils copy.py" carry their own sampler constants: same RNG stream,
+    bit-identical 4x4 poses for the goldens recorded from those modules."""
+    import random as _random
+    from mpiflow_amd import host_math
+    g = load_golden("pose_schedule_variants")
+    for profile in ("coco", "copy"):
+        rng = _random.Random(int(g["seed"]))
+        for k in range(g["G_dyn_" + profile].shape[0]):
+            dyn = host_math.generate_random_pose(rng=rng, profile=profile)
+            cam = host_math.generate_random_pose(base_motions=[0, 0, 0], rng=rng, profile=profile)
+            assert np.array_equal(dyn.numpy(), g["G_dyn_" + profile][k]), (profile, k)
+            assert np.array_equal(cam.numpy(), g["G_cam_" + profile][k]), (profile, k)
+
+
 def test_pose_schedule_matches_reference_rng_stream():
     from mpiflow_amd import pipeline
     g = load_golden("pose_schedule")

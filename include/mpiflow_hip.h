@@ -142,6 +142,12 @@ int mpf_volume_render(const float *d_rgb, const float *d_sigma, const float *d_x
  * out[c,n] = cascade-sum_s weights[s,n] * values[s,c,n]   (values NULL: plain sum of the weights, C must be 1) */
 int mpf_weighted_sum(const float *d_weights, const float *d_values, int S, int C, int64_t N, float *d_out, void *stream);
 
+/* alpha_composition (utils/mpi/mpi_rendering.py:42-59) and the blend weights of render(use_alpha=True) (:36):
+ * d_alpha [S,N]; d_values [S,C,N] with d_out [C,N] = cascade-sum_s values * weights (both NULL to skip);
+ * d_weights [S,N] = alpha_s * prod_{k<s}(1 - alpha_k) (optional); d_cumprod_eps [S,N] = prod_{k<=s}(1 - alpha_k + 1e-6) (optional) */
+int mpf_alpha_composite(const float *d_alpha, const float *d_values, int S, int C, int64_t N, float *d_out, float *d_weights,
+                        float *d_cumprod_eps, void *stream);
+
 /* ================= depth -> flow projection and forward warp (geometry.py, moving_obj.py, warping.c) ============= */
 
 /* moving_obj.py:29-30: depth = 1 / (disp + 0.005), values above 100 clamped to 100 */

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mpf_homography_flow": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "mpf_volume_render": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "mpf_weighted_sum": (c_i, [c_p, c_p, c_i, c_i, c_i64, c_p, c_p]),
+    "mpf_alpha_composite": (c_i, [c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mpf_disp_to_depth": (c_i, [c_p, c_i64, c_p, c_p]),
     "mpf_backproject_project": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "mpf_backproject": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),

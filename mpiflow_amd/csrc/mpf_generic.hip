@@ -275,6 +275,50 @@ extern "C" int mpf_weighted_sum(const float *d_weights, const float *d_values, i
     return mpf_launch_status("k_weighted_sum");
 }
 
+// ---- alpha_composition and the use_alpha blend weights (utils/mpi/mpi_rendering.py:42-59, :36) ------------------------------
+template <int NL>
+__global__ void __launch_bounds__(256)
+k_alpha_composite(const float *__restrict__ alpha, const float *__restrict__ values, int S, int C, int64_t N, float *__restrict__ out,
+                  float *__restrict__ weights, float *__restrict__ cumprod_eps)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (n >= N) return;
+    double keep = 1.0, keep_eps = 1.0;                       // torch.cumprod accumulates float tensors in double on the CPU
+    MpfCsum<NL> acc;
+    acc.init();
+    for (int s = 0; s < S; ++s) {
+        const float a = alpha[(int64_t)s * N + n];
+        const float w = a * (float)keep;                     // alpha * [1, cumprod(1 - alpha)[:-1]]
+        keep *= (double)(1.0f - a);
+        if (c == 0) {
+            if (weights) weights[(int64_t)s * N + n] = w;
+            if (cumprod_eps) {
+                keep_eps *= (double)((1.0f - a) + 1e-6f);
+                cumprod_eps[(int64_t)s * N + n] = (float)keep_eps;
+            }
+        }
+        if (values) {
+            acc.push(values[((int64_t)s * C + c) * N + n] * w);
+            if (((s + 1) & 15) == 0) acc.fold(s + 1);
+        }
+    }
+    if (values && out) out[(int64_t)c * N + n] = acc.final();
+}
+
+extern "C" int mpf_alpha_composite(const float *d_alpha, const float *d_values, int S, int C, int64_t N, float *d_out, float *d_weights,
+                                   float *d_cumprod_eps, void *stream)
+{
+    MPF_REQUIRE(d_alpha && S >= 1 && S < 4096 && N >= 1, "mpf_alpha_composite: bad argument");
+    MPF_REQUIRE((d_values == nullptr) == (d_out == nullptr) && (!d_values || (C >= 1 && C < 65536)), "mpf_alpha_composite: values and out go together");
+    dim3 grid((unsigned)((N + 255) / 256), d_values ? C : 1), block(256);
+    if (S < 256)
+        hipLaunchKernelGGL(k_alpha_composite<2>, grid, block, 0, (hipStream_t)stream, d_alpha, d_values, S, C, N, d_out, d_weights, d_cumprod_eps);
+    else
+        hipLaunchKernelGGL(k_alpha_composite<3>, grid, block, 0, (hipStream_t)stream, d_alpha, d_values, S, C, N, d_out, d_weights, d_cumprod_eps);
+    return mpf_launch_status("k_alpha_composite");
+}
+
 // ---- BackprojectDepth + Project3D  (geometry.py:41-49, :63-76) --------------------------------------------------
 
 struct MpfProj { float ik[9]; float P[12]; };

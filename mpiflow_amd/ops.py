@@ -306,6 +306,27 @@ def weighted_sum(weights_SN, values_SCN=None):
 # ---- depth -> flow, forward warp -----------------------------------------------------------------------------------
 
 @_on_device
+def alpha_composite(alpha_SN, values_SCN=None, want_weights=True, want_cumprod_eps=False):
+    """alpha_composition (mpi_rendering.py:42-59) -> dict(out [C,N] | None, weights [S,N] | None, cumprod_eps [S,N] | None)"""
+    lib = _lib.load()
+    al = _dev(alpha_SN, "alpha")
+    S, N = al.shape[0], al[0].numel()
+    al = al.reshape(S, N)
+    dev = al.device
+    vals = out = None
+    C = 1
+    if values_SCN is not None:
+        vals = _dev(values_SCN, "values")
+        C = vals.shape[1]
+        vals = vals.reshape(S, C, N)
+        out = torch.empty((C, N), dtype=_f32, device=dev)
+    w = torch.empty((S, N), dtype=_f32, device=dev) if want_weights else None
+    ce = torch.empty((S, N), dtype=_f32, device=dev) if want_cumprod_eps else None
+    _lib.check(lib.mpf_alpha_composite(_ptr(al), _ptr(vals), S, C, ctypes.c_int64(N), _ptr(out), _ptr(w), _ptr(ce), _stream()), "mpf_alpha_composite")
+    return dict(out=out, weights=w, cumprod_eps=ce)
+
+
+@_on_device
 def disp_to_depth(disp):
     lib = _lib.load()
     d = _dev(disp, "disp")

@@ -6,8 +6,9 @@ each function is a drop-in on its own and reproduces the reference's semantics e
 channels rather than recomputing them).  The fused fast path that never materialises an [S,...] intermediate lives in
 mpiflow_amd.pipeline / utils.utils.render_3dphoto_dynamic.
 
-Off the generation path and therefore not provided: alpha_composition / use_alpha=True
-(:42-59), get_xyz_from_depth (:157-177), disparity_consistency_src_to_tgt (:180-210).
+Also provided although MPI-Flow's generation never takes them: alpha_composition / use_alpha=True (:42-59) and
+get_xyz_from_depth (:157-177).  Not provided: disparity_consistency_src_to_tgt (:180-210), a training loss of the MINE code
+base this module was taken from.
 """
 import torch
 
@@ -25,7 +26,9 @@ def render(rgb_BS3HW, sigma_BS1HW, xyz_BS3HW, src_sigma_BS1HW=None, src_flow_BS2
            use_alpha=False, is_bg_depth_inf=False, hard_flow=False, obj_mask=None):
     """reference utils/mpi/mpi_rendering.py:7-39 -> (imgs_syn, depth_syn, blend_weights, weights, flowA2B, obj_mask)"""
     if use_alpha:
-        raise NotImplementedError("use_alpha=True (alpha_composition) is off the MPI-Flow generation path")
+        # The reference's use_alpha branch (:33-38) computes alpha_composition results and then fails at its return statement
+        # (`flowA2B` is only bound in the other branch): same exception here.  alpha_composition() itself is provided below.
+        raise UnboundLocalError("local variable 'flowA2B' referenced before assignment (reference utils/mpi/mpi_rendering.py:39, use_alpha=True)")
     imgs_syn, depth_syn, blend_weights, weights, flowB2A, obj_mask = plane_volume_rendering(
         rgb_BS3HW, sigma_BS1HW, xyz_BS3HW, src_sigma_BS1HW, src_flow_BS2HW, src_xyz_BS3HW, is_bg_depth_inf,
         hard_flow=hard_flow, obj_mask=obj_mask)
@@ -34,6 +37,27 @@ def render(rgb_BS3HW, sigma_BS1HW, xyz_BS3HW, src_sigma_BS1HW=None, src_flow_BS2
         flowA2B = plane_volume_rendering_flow(src_sigma_BS1HW, src_flow_BS2HW, src_xyz_BS3HW, is_bg_depth_inf,
                                               hard_flow=hard_flow)
     return imgs_syn, depth_syn, blend_weights, weights, flowA2B, obj_mask
+
+
+def alpha_composition(alpha_BK1HW, value_BKCHW):
+    """reference :42-59 ("Single-View View Synthesis with Multiplane Images") -> (value_composed BxCxHxW, weights BxKx1xHxW)"""
+    B, K, _, H, W = alpha_BK1HW.size()
+    C = value_BKCHW.size(2)
+    vals, wts = [], []
+    for b in range(B):
+        r = ops.alpha_composite(alpha_BK1HW[b, :, 0], value_BKCHW[b])
+        vals.append(r["out"].reshape(C, H, W))
+        wts.append(r["weights"].reshape(K, 1, H, W))
+    return torch.stack(vals), torch.stack(wts)
+
+
+def get_xyz_from_depth(meshgrid_homo, depth, K_inv):
+    """xyz = (K^-1 . (x,y,1)) * depth   (reference :157-177): meshgrid 3xHxW (only its size is read), depth Bx1xHxW,
+    K_inv Bx3x3 -> Bx3xHxW"""
+    H, W = meshgrid_homo.size(1), meshgrid_homo.size(2)
+    B, _, H_d, W_d = depth.size()
+    assert H == H_d and W == W_d
+    return torch.stack([ops.backproject(depth[b, 0], K_inv[b])[:3].reshape(3, H, W) for b in range(B)])
 
 
 def plane_volume_rendering(rgb_BS3HW, sigma_BS1HW, xyz_BS3HW, src_sigma_BS1HW, src_flow_BS2HW, src_xyz_BS3HW,

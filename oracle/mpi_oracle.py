@@ -228,6 +228,19 @@ def volume_render(rgb_S3HW, sigma_S1HW, xyz_S3HW, extra_SEHW=None):
     return out
 
 
+def alpha_composition(alpha_S1HW, value_SCHW=None):
+    """-> dict(out [C,H,W] | None, weights [S,H,W], cumprod_eps [S,H,W])   (mpi_rendering.py:42-59, :36)"""
+    alpha = _c(alpha_S1HW)
+    S, _, H, W = alpha.shape
+    N = H * W
+    val = _c(value_SCHW) if value_SCHW is not None else None
+    C = 0 if val is None else val.shape[1]
+    out = dict(out=np.empty((C, H, W), np.float32) if C else None, weights=np.empty((S, H, W), np.float32),
+               cumprod_eps=np.empty((S, H, W), np.float32))
+    lib().orc_alpha_composition(_p(alpha), _p(val), S, C, ctypes.c_int64(N), _p(out["out"]), _p(out["weights"]), _p(out["cumprod_eps"]))
+    return out
+
+
 # --------------------------------------------------------------------------------------------------------------
 # fused stages
 # --------------------------------------------------------------------------------------------------------------

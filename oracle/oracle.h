@@ -49,6 +49,10 @@ void orc_volume_render(const float *rgb, const float *sigma, const float *xyz, i
                        float *rgb_out, float *depth_out, float *tacc_out, float *weights_out,
                        const float *extra_in, int E, float *extra_out);
 
+/* alpha_composition + the use_alpha blend weights (utils/mpi/mpi_rendering.py:42-59, :36); C <= 8 */
+void orc_alpha_composition(const float *alpha, const float *values, int S, int C, int64_t N, float *out, float *weights_out,
+                           float *cumprod_eps_out);
+
 /* ---- oracle_mpi.c : streaming restatements of the fused stages (what the HIP kernels implement) -------- */
 
 /* Stage A + C.  mpi [S,4,H,W] planar (rgb, sigma), img [3,H,W].  For every source pixel: transmittance chain on

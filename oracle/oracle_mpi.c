@@ -233,6 +233,31 @@ void orc_volume_render(const float *rgb, const float *sigma, const float *xyz, i
     }
 }
 
+/* alpha_composition (utils/mpi/mpi_rendering.py:42-59) and the blend weights of the use_alpha branch of render() (:36).
+ * alpha [S,N], values [S,C,N] (may be NULL).  preserve_s = prod_{k<s} (1 - alpha_k)  (torch.cumprod: double accumulator,
+ * L5), weights_s = alpha_s * preserve_s, out_c = cascade-sum_s values_sc * weights_s (L6);
+ * cumprod_eps_s = prod_{k<=s} ((1 - alpha_k) + 1e-6)  (inclusive - "blend_weights"). */
+void orc_alpha_composition(const float *alpha, const float *values, int S, int C, int64_t N, float *out, float *weights_out,
+                           float *cumprod_eps_out)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n) {
+        double keep = 1.0, keep_eps = 1.0;
+        csum_t cc[8];
+        for (int c = 0; c < C && c < 8; ++c) csum_init(&cc[c]);
+        for (int s = 0; s < S; ++s) {
+            const float a = alpha[(int64_t)s * N + n];
+            const float w = a * (float)keep;
+            keep *= (double)(1.0f - a);
+            keep_eps *= (double)((1.0f - a) + 1e-6f);
+            if (weights_out) weights_out[(int64_t)s * N + n] = w;
+            if (cumprod_eps_out) cumprod_eps_out[(int64_t)s * N + n] = (float)keep_eps;
+            if (values) for (int c = 0; c < C && c < 8; ++c) csum_push(&cc[c], values[((int64_t)s * C + c) * N + n] * w);
+        }
+        if (values && out) for (int c = 0; c < C && c < 8; ++c) out[c * N + n] = csum_final(&cc[c]);
+    }
+}
+
 /* ---- streaming restatements of the fused stages ------------------------------------------------------- */
 
 /* Stage A + C: utils/utils.py:190-204 (source-frame transmittance -> blend) fused with

@@ -320,6 +320,33 @@ def gen_pose_schedule(seed=114514, n=16, ext_cz=0.15):
     save("pose_schedule_variants", seed=seed, **extra)
 
 
+def gen_alpha(seed=23):
+    """render(use_alpha=True) = alpha_composition (mpi_rendering.py:33-59) and get_xyz_from_depth (:157-177)."""
+    rs = np.random.RandomState(seed)
+    B, S, H, W = 1, 20, 10, 14
+    sigma = rs.rand(B, S, 1, H, W).astype(np.float32)
+    sigma[:, ::5] = 0.0
+    sigma[:, 3] = 1.0
+    rgb = rs.rand(B, S, 3, H, W).astype(np.float32)
+    xyz = (rs.rand(B, S, 3, H, W).astype(np.float32) * 4 + 0.5)
+    T = torch.from_numpy
+    try:                                   # the reference's own use_alpha branch never binds flowA2B (:33-39): record that it raises
+        R.mpi_rendering.render(T(rgb), T(sigma), T(xyz), use_alpha=True)
+        render_raises = ""
+    except UnboundLocalError as e:
+        render_raises = type(e).__name__
+    imgs, weights = R.mpi_rendering.alpha_composition(T(sigma), T(rgb))
+    depth, _ = R.mpi_rendering.alpha_composition(T(sigma), T(xyz[:, :, 2:]))
+    blend = torch.cumprod(1 - T(sigma) + 1e-6, dim=1)                      # :36
+    dep = (rs.rand(B, 1, H, W).astype(np.float32) * 5 + 0.5)
+    K = synth.intrinsics(H, W)
+    k_inv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    mesh = R.homography_sampler.HomographySample(H, W, device=torch.device("cpu")).meshgrid
+    xyz_d = R.mpi_rendering.get_xyz_from_depth(mesh, T(dep), T(k_inv)[None])
+    save("alpha_composition", sigma=sigma, rgb=rgb, xyz=xyz, imgs=imgs.numpy(), depth=depth.numpy(), blend_weights=blend.numpy(),
+         weights=weights.numpy(), depth_map=dep, K_inv=k_inv, xyz_from_depth=xyz_d.numpy(), render_use_alpha_raises=render_raises)
+
+
 def gen_geometry(seed=11):
     """geometry.py known answers: transformation_from_parameters (both branches), BackprojectDepth, Project3D."""
     rs = np.random.RandomState(seed)
@@ -382,6 +409,7 @@ JOBS = {
                       gen_collision_stress()),
     "exp": gen_exp,
     "pose": gen_pose_schedule,
+    "alpha": gen_alpha,
     "geometry": gen_geometry,
     "model": gen_model,
     "hard": gen_hard_flow,

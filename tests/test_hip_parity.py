@@ -482,3 +482,35 @@ def test_blend_once_then_flow_only_pairs(dev):
         b = pipeline.render_pair(img, om, mpi, inp["disparity"], inp["K"], Gc, Gd, renderer=r2, reuse_blend=True)
         for k in ("flow_mix", "frame_mix", "fill_mask", "src_np", "flows"):
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_alpha_composition_and_xyz_from_depth(dev, oracle):
+    """The off-path helpers of utils.mpi.mpi_rendering: alpha_composition bit-exact vs oracle and golden, get_xyz_from_depth
+    vs golden; render(use_alpha=True) raises like the reference does."""
+    from mpiflow_amd import ops
+    from mpiflow_amd.utils.mpi import mpi_rendering as M
+    from mpiflow_amd.utils.mpi.homography_sampler import HomographySample
+    g = load_golden("alpha_composition")
+    sigma, rgb, xyz = (torch.from_numpy(g[k]).to(dev) for k in ("sigma", "rgb", "xyz"))
+    imgs, weights = M.alpha_composition(sigma, rgb)
+    assert bits_equal(imgs.cpu().numpy(), g["imgs"]) == 0 and bits_equal(weights.cpu().numpy(), g["weights"]) == 0
+    depth, _ = M.alpha_composition(sigma, xyz[:, :, 2:])
+    assert bits_equal(depth.cpu().numpy(), g["depth"]) == 0
+    r = ops.alpha_composite(sigma[0, :, 0], want_weights=False, want_cumprod_eps=True)
+    assert bits_equal(r["cumprod_eps"].cpu().numpy().reshape(g["blend_weights"][0, :, 0].shape), g["blend_weights"][0, :, 0]) == 0
+    with pytest.raises(UnboundLocalError):
+        M.render(rgb, sigma, xyz, use_alpha=True)
+    H, W = g["depth_map"].shape[-2:]
+    mesh = HomographySample(H, W, dev).meshgrid
+    got = M.get_xyz_from_depth(mesh, torch.from_numpy(g["depth_map"]).to(dev), torch.from_numpy(g["K_inv"]).to(dev)[None])
+    assert bits_equal(got.cpu().numpy(), g["xyz_from_depth"]) == 0
+    # a long stack exercises the three-level cascade sum and the fp64 running product
+    rs = np.random.RandomState(1)
+    S, N = 300, 777
+    al = (rs.rand(S, 1, 1, N) * 0.05).astype(np.float32)
+    val = rs.rand(S, 2, 1, N).astype(np.float32)
+    ref = oracle.alpha_composition(al, val)
+    got = ops.alpha_composite(torch.from_numpy(al[:, 0, 0]).to(dev), torch.from_numpy(val[:, :, 0]).to(dev), want_cumprod_eps=True)
+    assert bits_equal(got["out"].cpu().numpy(), ref["out"][:, 0]) == 0 and bits_equal(got["weights"].cpu().numpy(), ref["weights"][:, 0]) == 0
+    assert bits_equal(got["cumprod_eps"].cpu().numpy(), ref["cumprod_eps"][:, 0]) == 0

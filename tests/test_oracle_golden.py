@@ -255,3 +255,15 @@ def test_moving_object_small(oracle):
     assert bits_equal((1 - out["masks"]["H"]).astype(np.uint8), g["inpaint_mask"].astype(np.uint8)) == 0
     m = out["masks"]
     assert ((m["H'"] == 1) <= (m["H"] == 1)).all() and ((m["M'"] >= m["M"]).all())
+
+
+def test_alpha_composition_against_reference(oracle):
+    """alpha_composition (mpi_rendering.py:42-59) + the use_alpha blend weights (:36): bit-exact restatement."""
+    g = load_golden("alpha_composition")
+    sigma, rgb, xyz = g["sigma"][0], g["rgb"][0], g["xyz"][0]
+    r = oracle.alpha_composition(sigma, rgb)
+    assert bits_equal(r["out"], g["imgs"][0]) == 0 and bits_equal(r["weights"], g["weights"][0, :, 0]) == 0
+    assert bits_equal(r["cumprod_eps"], g["blend_weights"][0, :, 0]) == 0
+    d = oracle.alpha_composition(sigma, xyz[:, 2:3])
+    assert bits_equal(d["out"], g["depth"][0]) == 0
+    assert str(g["render_use_alpha_raises"]) == "UnboundLocalError"

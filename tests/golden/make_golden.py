@@ -347,6 +347,22 @@ def gen_alpha(seed=23):
          weights=weights.numpy(), depth_map=dep, K_inv=k_inv, xyz_from_depth=xyz_d.numpy(), render_use_alpha_raises=render_raises)
 
 
+def gen_flo(seed=31):
+    """write_flow.writeFlow (write_flow.py:74-103): the bytes of a small .flo file as the reference writes it."""
+    import importlib
+    import tempfile
+    wf = importlib.import_module("write_flow")
+    rs = np.random.RandomState(seed)
+    flow = (rs.randn(7, 11, 2) * 30).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        a, b = os.path.join(d, "a.flo"), os.path.join(d, "b.flo")
+        wf.writeFlow(a, flow)
+        wf.writeFlow(b, flow[:, :, 0].astype(np.float64), flow[:, :, 1].astype(np.float64))
+        raw_a, raw_b = open(a, "rb").read(), open(b, "rb").read()
+        back = wf.readFlow(a)
+    save("flo_file", flow=flow, file_bytes=np.frombuffer(raw_a, np.uint8), file_bytes_uv=np.frombuffer(raw_b, np.uint8), read_back=back)
+
+
 def gen_geometry(seed=11):
     """geometry.py known answers: transformation_from_parameters (both branches), BackprojectDepth, Project3D."""
     rs = np.random.RandomState(seed)
@@ -410,6 +426,7 @@ JOBS = {
     "exp": gen_exp,
     "pose": gen_pose_schedule,
     "alpha": gen_alpha,
+    "flo": gen_flo,
     "geometry": gen_geometry,
     "model": gen_model,
     "hard": gen_hard_flow,

@@ -157,3 +157,19 @@ def test_async_writer_writes_everything_and_propagates_errors(tmp_path):
     w2.flo(str(tmp_path / "no_such_dir" / "x.flo"), flows[0])
     with pytest.raises(Exception):
         w2.close()
+
+
+def test_write_flow_mirror_writes_the_reference_bytes(tmp_path, capsys):
+    """mpiflow_amd.write_flow.writeFlow / readFlow == write_flow.py:14-33, :74-103 (file bytes recorded from the reference)"""
+    from mpiflow_amd import write_flow
+    g = load_golden("flo_file")
+    a, b = str(tmp_path / "a.flo"), str(tmp_path / "b.flo")
+    write_flow.writeFlow(a, g["flow"])
+    write_flow.writeFlow(b, g["flow"][:, :, 0].astype(np.float64), g["flow"][:, :, 1].astype(np.float64))
+    assert open(a, "rb").read() == g["file_bytes"].tobytes()
+    assert open(b, "rb").read() == g["file_bytes_uv"].tobytes()
+    back = write_flow.readFlow(a)
+    assert back.dtype == np.float32 and np.array_equal(back, g["read_back"])
+    bad = tmp_path / "bad.flo"
+    bad.write_bytes(b"\0" * 64)
+    assert write_flow.readFlow(str(bad)) is None and "Magic number incorrect" in capsys.readouterr().out

@@ -145,7 +145,7 @@ def main(argv=None):
     import torch.nn.functional as F
     tail_stream, tail_ready = torch.cuda.Stream(device=dev), torch.cuda.Event()
     inputs = io_formats.InputPrefetcher(names, img_base, disp_base, mask_base, owned=lambda i: (i % world) == rank, pin=True)
-    n_pairs = 0
+    n_pairs, t_first, n_first = 0, None, 0
     it = iter(inputs)
     while True:
         with lap("wait for decoded inputs"):
@@ -210,6 +210,8 @@ def main(argv=None):
                     ring.submit_pair(res["flow_mix"], scan, os.path.join(out, "flows", f"{name}_{r}.flo"),            # :120
                                      os.path.join(out, "dst_images", f"{name}_{r}.png"))                              # :121
             n_pairs += 1
+        if mine and t_first is None:
+            t_first, n_first = time.perf_counter(), n_pairs       # start-up (graph capture, first MIOpen calls) ends with the first image
     with lap("drain writers"):
         torch.cuda.synchronize()
         ring.close()
@@ -217,7 +219,10 @@ def main(argv=None):
         for k, v in prof.items():
             print("  %-40s %8.3f s" % (k, v))
     stats = dstats.result(n_pairs)
-    stats["wall_seconds"] = time.perf_counter() - t_start
+    t_end = time.perf_counter()
+    stats["wall_seconds"] = t_end - t_start
+    if t_first is not None and n_pairs > n_first and rank == 0:
+        print("steady state after the first image: %.1f pairs/s on this rank" % ((n_pairs - n_first) / (t_end - t_first)))
     total = pipeline.reduce_stats(stats)
     if rank == 0:
         print("pairs %d  mean|flow| %.3f px  max|flow| %.2f px  hole px/pair %.0f  wall %.1f s  (%d rank%s)" % (

@@ -32,5 +32,5 @@ for label, extra in configs:
     last = [l for l in r.stdout.splitlines() if l.startswith("pairs")]
     print("%-34s process %.1f s | %s" % (label, dt, last[-1] if last else r.stderr[-400:]))
     for l in r.stdout.splitlines():
-        if l.startswith("  "):
+        if l.startswith("  ") or l.startswith("steady"):
             print("      " + l)

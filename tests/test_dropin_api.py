@@ -93,7 +93,7 @@ def test_render_and_render_tgt_rgb_depth(dev, name):
     assert bits_equal(N(r_tmask[0, 0]), g["rtd_tgt_mask"]) == 0
     assert max_abs(N(r_flow[0]), g["rtd_flow_unclipped"]) < 5e-5
     assert max_abs(N(r_depth[0, 0]), g["rtd_depth"]) < 2e-5 * max(1.0, float(np.abs(g["rtd_depth"]).max()))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(UnboundLocalError):        # what the reference's own use_alpha branch does (mpi_rendering.py:33-39)
         mpi_rendering.render(rgb, sig, xyz_src, use_alpha=True)
 
 

@@ -194,6 +194,18 @@ def fill_holes(img_HW3_u8, hole_HW_u8, out=None, hole_out=None, workspace=None):
 
 
 @_on_device
+def pair_stats(flow_mix_HW2, fill_mask_HW, out4):
+    """mpf_pair_stats: {sum |flow|, hole px, max |flow|, max(-flow)} of one pair into out4 (4 float64 on the device), stream-ordered"""
+    lib = _lib.load()
+    flow = _dev(flow_mix_HW2, "flow_mix")
+    fill = _dev(fill_mask_HW, "fill_mask", torch.uint8)
+    H, W = fill.shape
+    assert out4.dtype == torch.float64 and out4.numel() == 4 and out4.is_contiguous()
+    _lib.check(lib.mpf_pair_stats(_ptr(flow), _ptr(fill), H, W, _ptr(out4), _stream()), "mpf_pair_stats")
+    return out4
+
+
+@_on_device
 def png_scanlines(img_HW3_bgr_u8, out=None):
     """[H,W,3] u8 BGR on the device -> PNG scanlines u8 [H, 1+3W] (filter "Up", RGB order) for io_formats.png_from_scanlines"""
     lib = _lib.load()

@@ -173,21 +173,27 @@ def pair_stats(flow_mix, fill_mask):
 
 
 class DeviceStats:
-    """The per-pair statistics accumulated ON the device (no host synchronisation per pair); result() reads them back once."""
+    """The per-pair statistics stay ON the device (one mpf_pair_stats launch per pair into its own slot, no host
+    synchronisation); result() reduces the slots and reads them back once."""
+
+    CHUNK = 4096
 
     def __init__(self, device):
-        self.sums = torch.zeros(2, dtype=torch.float64, device=device)           # sum |flow|, hole pixels
-        self.maxs = torch.full((2,), -float("inf"), dtype=torch.float32, device=device)   # max |flow|, max(-flow)
+        self.device = torch.device(device)
+        self.chunks, self.n = [], 0
 
     def add(self, flow_mix, fill_mask):
-        mag = torch.linalg.vector_norm(flow_mix.reshape(-1, 2), dim=1)
-        self.sums += torch.stack([mag.sum(dtype=torch.float64), fill_mask.sum(dtype=torch.float64)])
-        self.maxs = torch.maximum(self.maxs, torch.stack([mag.max(), (-flow_mix).max()]))
+        from . import ops
+        if self.n % self.CHUNK == 0:
+            self.chunks.append(torch.zeros((self.CHUNK, 4), dtype=torch.float64, device=self.device))
+        ops.pair_stats(flow_mix, fill_mask, self.chunks[-1][self.n % self.CHUNK])
+        self.n += 1
 
     def result(self, pairs):
-        s, m = self.sums.cpu().tolist(), self.maxs.cpu().tolist()
         out = empty_stats()
-        if pairs:
+        if self.n:
+            rows = torch.cat(self.chunks)[:self.n]
+            s, m = rows[:, :2].sum(0).cpu().tolist(), rows[:, 2:].max(0).values.cpu().tolist()
             out.update(pairs=pairs, sum_flow_mag=s[0], hole_px=s[1], max_flow_mag=m[0], neg_min_flow=m[1])
         return out
 

@@ -136,3 +136,24 @@ def test_png_scanlines_on_device_and_output_ring(tmp_path):
     for r in range(3):
         assert np.array_equal(np.array(Image.open(tmp_path / ("s%d.png" % r)))[:, :, ::-1], frames[0])
     assert sorted(os.listdir(tmp_path)) == sorted(["f%d.flo" % k for k in range(7)] + ["d%d.png" % k for k in range(7)] + ["s%d.png" % r for r in range(3)])
+
+
+@pytest.mark.gpu
+def test_pair_stats_kernel(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mpiflow_amd import pipeline
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(8)
+    st = pipeline.DeviceStats(dev)
+    tot = dict(sum=0.0, hole=0.0, mx=0.0, neg=-np.inf)
+    for k in range(3):
+        flow = (rs.randn(37, 53, 2) * (5 + 10 * k)).astype(np.float32)
+        fill = (rs.rand(37, 53) < 0.1).astype(np.uint8)
+        st.add(torch.from_numpy(flow).to(dev), torch.from_numpy(fill).to(dev))
+        mag = np.sqrt((flow.astype(np.float64) ** 2).sum(-1))
+        tot["sum"] += mag.sum(); tot["hole"] += fill.sum(); tot["mx"] = max(tot["mx"], mag.max()); tot["neg"] = max(tot["neg"], (-flow).max())
+    r = st.result(3)
+    assert r["pairs"] == 3 and r["hole_px"] == tot["hole"]
+    assert abs(r["sum_flow_mag"] - tot["sum"]) < 1e-3 * tot["sum"] * 1e-3
+    assert abs(r["max_flow_mag"] - tot["mx"]) < 1e-4 and r["neg_min_flow"] == float(tot["neg"])

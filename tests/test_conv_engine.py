@@ -252,6 +252,28 @@ def test_predictor_engine_matches_fp32_model(S, H, W, seed):
 
 
 @pytest.mark.gpu
+def test_engine_at_the_generator_size():
+    """64 planes at 384x1280 (the CLI's default size): finite output, the cumulative mask ends at 1 (softmax over the planes),
+    and the engine stays closer to the fp32 model than torch's fp16 autocast does (mean |rgb| error)."""
+    from mpiflow_amd.model.engine import HipPredictor
+    dev = _gpu()
+    S, H, W = 64, 384, 1280
+    m = _model(S, H, W, seed=1)
+    g = torch.Generator().manual_seed(3)
+    img, dsp = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 1, H, W, generator=g).to(dev)
+    raw, cum, disp = HipPredictor(m)(img, dsp)
+    assert tuple(raw.shape) == (S, 4, H, W) and bool(torch.isfinite(raw).all())
+    assert float((cum[-1] - 1).abs().max()) < 1e-5 and float(cum.min()) >= 0 and bool((cum[1:] >= cum[:-1] - 1e-6).all())
+    with torch.no_grad():
+        ref = m(img, dsp, raw=True)[0][0]
+        with torch.autocast("cuda", dtype=torch.float16):
+            half = m(img, dsp, raw=True)[0][0].float()
+    e_engine = float((torch.sigmoid(raw[:, :3]) - torch.sigmoid(ref[:, :3])).abs().mean())
+    e_half = float((torch.sigmoid(half[:, :3]) - torch.sigmoid(ref[:, :3])).abs().mean())
+    assert e_engine <= e_half and e_engine < 2e-2, (e_engine, e_half)          # random 25-layer network: both ~1e-2 at 64 planes
+
+
+@pytest.mark.gpu
 def test_graph_replay_equals_eager():
     """One captured hipGraph per input size; replays with new inputs reproduce the eager run: the masks (HIP kernels only)
     exactly, the raw output as closely as two eager runs agree with each other - MIOpen's batch-1 encoder convolutions are

@@ -96,7 +96,7 @@ struct Stage {
 };
 template <>
 struct Stage<LD_BILINEAR_CAT> {
-    unsigned ia, ib, dx, dy;            // ia: vector index of the top-left corner; dx, dy: steps to the right / lower neighbour (0 at the border)
+    unsigned ia, ib;                    // ia: byte offset of the top-left corner (this thread's vector) in the RAW low-resolution LDS tile
     float w00, w01, w10, w11;
     bool ok;
 };
@@ -108,8 +108,14 @@ struct Stage<LD_NEAREST_PLANE> {
     bool ok;
 };
 
+// RAW tile of the x2 bilinear loader: the low-resolution source pixels a conv tile can touch, staged in LDS once per chunk
+// (RH x RW pixels; the scale (in-1)/(out-1) is < 1/2, so LH rows span at most LH/2 + 1 source rows plus the +1 neighbour)
+__host__ __device__ constexpr int raw_rows(int LH) { return LH / 2 + 2; }
+__host__ __device__ constexpr int raw_cols(int LW) { return LW / 2 + 2; }
+
 template <int LOADER>
-__device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs &a, int s, int y, int x, bool in_tile)
+__device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs &a, int s, int y, int x, bool in_tile, int ry0 = 0, int rx0 = 0,
+                                           int raw_pitch = 0, int vpp = 1, int sv = 0)
 {
     const bool reflect = a.pad_mode == 1;
     st.ok = in_tile && (reflect || (y >= 0 && y < a.Hin && x >= 0 && x < a.Win));
@@ -126,10 +132,8 @@ __device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs 
         y0 = y0 > a.HA - 1 ? a.HA - 1 : y0;
         x0 = x0 > a.WA - 1 ? a.WA - 1 : x0;
         const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-        const unsigned va = (unsigned)a.CA >> 3;
-        st.ia = (unsigned)((s * a.HA + y0) * a.WA + x0) * va;
-        st.dx = x0 < a.WA - 1 ? va : 0u;
-        st.dy = y0 < a.HA - 1 ? va * (unsigned)a.WA : 0u;
+        // the raw tile holds rows ry0.. and columns rx0.. clamped to the source, so the +1 neighbours exist there at the borders too
+        st.ia = (unsigned)((((y0 - ry0) * raw_pitch + (x0 - rx0)) * vpp + sv) * 16);
         st.w00 = hy * hx, st.w01 = hy * lx, st.w10 = ly * hx, st.w11 = ly * lx;
         st.ib = (unsigned)((s * a.Hin + y) * a.Win + x);
     } else {
@@ -152,7 +156,8 @@ __device__ __forceinline__ u32x4 select4(bool c, const u32x4 &v) { return u32x4{
 // 8 consecutive virtual input channels (vector vv = chunk * VPP + sv) of the staged pixel, as 8 fp16.  Written without
 // divergent branches (clamped addresses + selects) so that the loads of all NI passes of a chunk can be in flight together.
 template <int LOADER, int VPP>
-__device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfConvArgs &a, int s, int chunk, int sv)
+__device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfConvArgs &a, int s, int chunk, int sv, const unsigned char *raw = nullptr,
+                                            int raw_dx = 0, int raw_dy = 0)
 {
     const unsigned vv = (unsigned)(chunk * VPP + sv);
     if constexpr (LOADER == LD_FMN_INPUT) {
@@ -168,8 +173,9 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
     } else if constexpr (LOADER == LD_BILINEAR_CAT) {
         const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3;       // va % VPP == 0 (checked by the launcher)
         if ((unsigned)(chunk * VPP) < va) {                                       // uniform: the whole chunk is source A
-            const u32x4 *p = (const u32x4 *)a.srcA + (st.ia + vv);
-            const u32x4 r00 = p[0], r01 = p[st.dx], r10 = p[st.dy], r11 = p[st.dy + st.dx];
+            const unsigned char *p = raw + st.ia;
+            const u32x4 r00 = *reinterpret_cast<const u32x4 *>(p), r01 = *reinterpret_cast<const u32x4 *>(p + raw_dx);
+            const u32x4 r10 = *reinterpret_cast<const u32x4 *>(p + raw_dy), r11 = *reinterpret_cast<const u32x4 *>(p + raw_dy + raw_dx);
             u32x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -218,8 +224,12 @@ void k_conv3x3(const MpfConvArgs a)
     constexpr int WVEC = KS * NB * 64, NW = (WVEC + 255) / 256;      // 16-byte weight vectors per chunk, per thread
     constexpr int TILE_BYTES = (LH * LW * PIXB + 255) / 256 * 256;
     static_assert(GROUPS % 4 == 0, "tile must give every wave the same number of pixel groups");
+    constexpr bool RAW = LOADER == LD_BILINEAR_CAT;
+    constexpr int RH = raw_rows(LH), RW = raw_cols(LW), RAWVEC = RH * RW * VPP, NR = (RAWVEC + 255) / 256;
+    constexpr int WL_BYTES = WLDS ? KS * NB * 1024 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *tile = lds, *wlds = lds + TILE_BYTES;      // input tile | this chunk's A fragments (shared by the 4 waves)
+    unsigned char *raw = lds + TILE_BYTES + WL_BYTES;         // | raw low-resolution tile of the bilinear loader
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.z / a.ncg, cg = blockIdx.z - s * a.ncg;
@@ -228,12 +238,24 @@ void k_conv3x3(const MpfConvArgs a)
 
     // staging slots of this thread: vector sv of tile pixels sp + k * PPT
     const int sv = tid % VPP, sp = tid / VPP;
+    // bilinear loader: origin of the raw tile = source pixel of the tile's first (clamped) row / column
+    int ry0 = 0, rx0 = 0;
+    unsigned rawsrc[RAW ? NR : 1];
+    if constexpr (RAW) {
+        ry0 = (int)(a.fparams[0] * (float)max(iy0, 0));
+        rx0 = (int)(a.fparams[1] * (float)max(ix0, 0));
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {                        // this thread's raw vectors: (pixel j / VPP, vector j % VPP)
+            const int j = tid + k * 256, rp = j / VPP, rr = rp / RW, rq = rp - rr * RW;
+            rawsrc[k] = (unsigned)((s * a.HA + min(ry0 + rr, a.HA - 1)) * a.WA + min(rx0 + rq, a.WA - 1)) * ((unsigned)a.CA >> 3) + (unsigned)(j % VPP);
+        }
+    }
     Stage<LOADER> stage[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int p = sp + k * PPT;
         const int ly = p / LW, lx = p - ly * LW;
-        stage_init<LOADER>(stage[k], a, s, iy0 + ly, ix0 + lx, p < LH * LW);
+        stage_init<LOADER>(stage[k], a, s, iy0 + ly, ix0 + lx, p < LH * LW, ry0, rx0, RW, VPP, sv);
     }
 
     f32x4 acc[PG][NB];
@@ -269,8 +291,20 @@ void k_conv3x3(const MpfConvArgs a)
                 if (NW * 256 == WVEC || v < WVEC) wst[j] = wbase[(unsigned)(chunk * KS + ks) * wstride + r];
             }
         }
+        if constexpr (RAW) {
+            if ((unsigned)(chunk * VPP) < ((unsigned)a.CA >> 3)) {              // uniform: a chunk of the upsampled source
+                u32x4 rv[NR];
 #pragma unroll
-        for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv);
+                for (int k = 0; k < NR; ++k)
+                    if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC) rv[k] = ((const u32x4 *)a.srcA)[rawsrc[k] + (unsigned)(chunk * VPP)];
+#pragma unroll
+                for (int k = 0; k < NR; ++k)
+                    if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC) *reinterpret_cast<u32x4 *>(raw + (tid + k * 256) * 16) = rv[k];
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv, raw, VPP * 16, RW * VPP * 16);
         if constexpr (WLDS) {
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
@@ -312,7 +346,8 @@ template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS
 int launch_w(const MpfConvArgs &a, hipStream_t st)
 {
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, KS = (9 * CT + 31) / 32;
-    constexpr int LDS_BYTES = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + (WLDS ? KS * NB * 1024 : 0);
+    constexpr int RAW_BYTES = LOADER == LD_BILINEAR_CAT ? raw_rows(LH) * raw_cols(LW) * (CT / 8) * 16 : 0;
+    constexpr int LDS_BYTES = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + (WLDS ? KS * NB * 1024 : 0) + RAW_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "tile + weights exceed the LDS of a CU");
     static bool attr_set = false;
     if (!attr_set && LDS_BYTES > 64 * 1024) {

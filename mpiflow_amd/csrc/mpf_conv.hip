@@ -258,13 +258,20 @@ void k_conv3x3(const MpfConvArgs a)
         stage_init<LOADER>(stage[k], a, s, iy0 + ly, ix0 + lx, p < LH * LW, ry0, rx0, RW, VPP, sv);
     }
 
+    const int q = lane >> 4, pi = lane & 15;
+    // gated layers start their accumulators at the convolution biases (row 4q+i of block b), the others at zero
     f32x4 acc[PG][NB];
 #pragma unroll
-    for (int g = 0; g < PG; ++g)
+    for (int b = 0; b < NB; ++b) {
+        f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EP_GATED_ELU || EPI == EP_GATED_PLANAR_F32) {
+            const float *bias = a.ep + (cg * NB + b) * 16 + 4 * q;
+            init = f32x4{bias[0], bias[1], bias[2], bias[3]};
+        }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[g][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < PG; ++g) acc[g][b] = init;
+    }
 
-    const int q = lane >> 4, pi = lane & 15;
     // per-lane LDS byte offset of the tap each k-step reads (tap-packed layers: the tap depends on the lane's k-quarter)
     int tapoff[KS];
 #pragma unroll

@@ -110,10 +110,12 @@ int mpf_merge(const float *d_frame, const float *d_frame_dyn, const float *d_mas
 size_t mpf_fill_holes_workspace(int H, int W);
 int mpf_fill_holes(uint8_t *d_img, uint8_t *d_hole, int H, int W, void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* End-of-batch statistics of one pair, without a host round trip: d_out4 (4 doubles) =
- * { sum |flow|, hole pixels, max |flow|, max(-flow) } of d_flow_mix [H,W,2] f32 / d_fill_mask [H,W] u8.  One workgroup,
- * deterministic summation order. */
-int mpf_pair_stats(const float *d_flow_mix, const uint8_t *d_fill_mask, int H, int W, double *d_out4, void *stream);
+/* End-of-batch statistics of one pair, without a host round trip: d_out holds
+ * MPF_PAIR_STATS_SLICES rows of 4 doubles, one per fixed contiguous slice of the frame:
+ * { sum |flow|, hole pixels, max |flow|, max(-flow) } of d_flow_mix [H,W,2] f32 / d_fill_mask [H,W] u8 (empty slices: 0, 0,
+ * -inf, -inf).  Sum the first two columns and take the maximum of the last two.  Deterministic summation order. */
+#define MPF_PAIR_STATS_SLICES 64
+int mpf_pair_stats(const float *d_flow_mix, const uint8_t *d_fill_mask, int H, int W, double *d_out, void *stream);
 
 /* Frame -> PNG scanlines on the device (what cv2.imwrite does first, utils/utils.py:240-242 / gen_3dphoto_dynamic_v2.py:121-122):
  * d_bgr u8 [H,W,3] -> d_scanlines u8 [H, 1 + 3W]: filter byte 2 ("Up") followed by the RGB row minus the previous row

@@ -103,14 +103,15 @@ __global__ __launch_bounds__(256) void k_png_filter_up(const uint8_t *__restrict
     if (x == 0) out[y * pitch] = 2;
 }
 
-// per-pair statistics in one workgroup (deterministic: fixed per-thread strides, fp64 partial sums, LDS tree):
-// out[0] = sum |flow|, out[1] = hole pixels, out[2] = max |flow|, out[3] = max(-flow component)
-__global__ __launch_bounds__(1024) void k_pair_stats(const float *__restrict__ flow, const uint8_t *__restrict__ fill, int64_t N, double *__restrict__ out)
+// per-pair statistics, deterministic: MPF_PAIR_STATS_SLICES workgroups reduce fixed contiguous slices (fixed per-thread
+// strides, fp64 partial sums, LDS tree) into one row each: {sum |flow|, hole pixels, max |flow|, max(-flow component)}
+__global__ __launch_bounds__(256) void k_pair_stats(const float *__restrict__ flow, const uint8_t *__restrict__ fill, int64_t N, double *__restrict__ out)
 {
-    __shared__ double red[4][1024];
+    __shared__ double red[4][256];
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x, n0 = (int64_t)blockIdx.x * per, n1 = n0 + per < N ? n0 + per : N;
     double s_mag = 0.0, s_hole = 0.0;
     float m_mag = -INFINITY, m_neg = -INFINITY;
-    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += blockDim.x) {
         const float2 f = reinterpret_cast<const float2 *>(flow)[n];
         const float mag = sqrtf(fmaf(f.y, f.y, f.x * f.x));
         s_mag += (double)mag;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(1024) void k_pair_stats(const float *__restrict__ f
     }
     red[0][threadIdx.x] = s_mag; red[1][threadIdx.x] = s_hole; red[2][threadIdx.x] = (double)m_mag; red[3][threadIdx.x] = (double)m_neg;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
+    for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) {
             red[0][threadIdx.x] += red[0][threadIdx.x + w];
             red[1][threadIdx.x] += red[1][threadIdx.x + w];
@@ -129,16 +130,16 @@ __global__ __launch_bounds__(1024) void k_pair_stats(const float *__restrict__ f
         }
         __syncthreads();
     }
-    if (threadIdx.x < 4) out[threadIdx.x] = red[threadIdx.x][0];
+    if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
 }  // namespace
 
-extern "C" int mpf_pair_stats(const float *d_flow_mix, const uint8_t *d_fill_mask, int H, int W, double *d_out4, void *stream)
+extern "C" int mpf_pair_stats(const float *d_flow_mix, const uint8_t *d_fill_mask, int H, int W, double *d_out, void *stream)
 {
-    MPF_REQUIRE(d_flow_mix && d_fill_mask && d_out4 && H >= 1 && W >= 1, "mpf_pair_stats: bad argument");
+    MPF_REQUIRE(d_flow_mix && d_fill_mask && d_out && H >= 1 && W >= 1, "mpf_pair_stats: bad argument");
     MPF_REQUIRE((((uintptr_t)d_flow_mix) & 7) == 0, "mpf_pair_stats: flow must be 8-byte aligned");
-    hipLaunchKernelGGL(k_pair_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_flow_mix, d_fill_mask, (int64_t)H * W, d_out4);
+    hipLaunchKernelGGL(k_pair_stats, dim3(MPF_PAIR_STATS_SLICES), dim3(256), 0, (hipStream_t)stream, d_flow_mix, d_fill_mask, (int64_t)H * W, d_out);
     return mpf_launch_status("k_pair_stats");
 }
 

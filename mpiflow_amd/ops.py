@@ -193,14 +193,18 @@ def fill_holes(img_HW3_u8, hole_HW_u8, out=None, hole_out=None, workspace=None):
     return out
 
 
+PAIR_STATS_SLICES = 64          # MPF_PAIR_STATS_SLICES
+
+
 @_on_device
 def pair_stats(flow_mix_HW2, fill_mask_HW, out4):
-    """mpf_pair_stats: {sum |flow|, hole px, max |flow|, max(-flow)} of one pair into out4 (4 float64 on the device), stream-ordered"""
+    """mpf_pair_stats: per-slice {sum |flow|, hole px, max |flow|, max(-flow)} of one pair into out4 ([64,4] float64 on the device),
+    stream-ordered"""
     lib = _lib.load()
     flow = _dev(flow_mix_HW2, "flow_mix")
     fill = _dev(fill_mask_HW, "fill_mask", torch.uint8)
     H, W = fill.shape
-    assert out4.dtype == torch.float64 and out4.numel() == 4 and out4.is_contiguous()
+    assert out4.dtype == torch.float64 and out4.numel() == 4 * PAIR_STATS_SLICES and out4.is_contiguous()
     _lib.check(lib.mpf_pair_stats(_ptr(flow), _ptr(fill), H, W, _ptr(out4), _stream()), "mpf_pair_stats")
     return out4
 

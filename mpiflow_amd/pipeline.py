@@ -176,7 +176,7 @@ class DeviceStats:
     """The per-pair statistics stay ON the device (one mpf_pair_stats launch per pair into its own slot, no host
     synchronisation); result() reduces the slots and reads them back once."""
 
-    CHUNK = 4096
+    CHUNK = 1024
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -185,14 +185,14 @@ class DeviceStats:
     def add(self, flow_mix, fill_mask):
         from . import ops
         if self.n % self.CHUNK == 0:
-            self.chunks.append(torch.zeros((self.CHUNK, 4), dtype=torch.float64, device=self.device))
+            self.chunks.append(torch.zeros((self.CHUNK, ops.PAIR_STATS_SLICES, 4), dtype=torch.float64, device=self.device))
         ops.pair_stats(flow_mix, fill_mask, self.chunks[-1][self.n % self.CHUNK])
         self.n += 1
 
     def result(self, pairs):
         out = empty_stats()
         if self.n:
-            rows = torch.cat(self.chunks)[:self.n]
+            rows = torch.cat(self.chunks)[:self.n].reshape(-1, 4)
             s, m = rows[:, :2].sum(0).cpu().tolist(), rows[:, 2:].max(0).values.cpu().tolist()
             out.update(pairs=pairs, sum_flow_mag=s[0], hole_px=s[1], max_flow_mag=m[0], neg_min_flow=m[1])
         return out

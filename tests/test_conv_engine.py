@@ -261,7 +261,7 @@ def test_engine_at_the_generator_size():
     m = _model(S, H, W, seed=1)
     g = torch.Generator().manual_seed(3)
     img, dsp = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 1, H, W, generator=g).to(dev)
-    raw, cum, disp = HipPredictor(m)(img, dsp)
+    raw, cum, disp = HipPredictor(m, encoder_dtype=None)(img, dsp)       # fp32 encoder: the comparison isolates the engine's own rounding
     assert tuple(raw.shape) == (S, 4, H, W) and bool(torch.isfinite(raw).all())
     assert float((cum[-1] - 1).abs().max()) < 1e-5 and float(cum.min()) >= 0 and bool((cum[1:] >= cum[:-1] - 1e-6).all())
     with torch.no_grad():

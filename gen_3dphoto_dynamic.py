@@ -119,7 +119,7 @@ def main(argv=None):
             opt.planes = model.num_planes
         if opt.model_engine == "hip":
             from mpiflow_amd.model.engine import HipPredictor
-            hip_model = HipPredictor(model, encoder_dtype=amp or torch.float16, graph=True)
+            hip_model = HipPredictor(model, encoder_dtype=amp, graph=True)
     renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
     dstats = pipeline.DeviceStats(dev)
     ring = io_formats.OutputRing(opt.height, opt.width, dev, slots=max(4, 2 * max(opt.writers, 1)), threads=max(opt.writers, 1))

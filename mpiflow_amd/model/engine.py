@@ -317,11 +317,15 @@ def pad16(c):
 class HipPredictor:
     """MPIPredictor.forward(raw=True) (model/AdaMPI.py:55-78) for one image with the per-plane networks on the HIP engine.
 
+    encoder_dtype: autocast dtype of the batch-1 torch part (ResNet-18 encoder, bottleneck).  Default None = fp32: it runs on a
+    side stream underneath the feature-mask network either way, fp16 is not faster there (0.98 vs 1.15 ms) and costs 3x the
+    end-to-end error (mean |rgb| error vs the fp32 model 3.2e-3 with an fp32 encoder, 1.1e-2 with fp16; torch fp16: 1.2e-2).
+
     graph=True captures the whole forward (torch encoder + 21 HIP launches) into one hipGraph per input size and replays
     it: the forward is ~30 launches of a few hundred microseconds each, so Python/launch overhead would otherwise be as long
     as the GPU work.  With a graph the returned tensors are STATIC buffers, overwritten by the next call."""
 
-    def __init__(self, model, encoder_dtype=torch.float16, graph=False):
+    def __init__(self, model, encoder_dtype=None, graph=False):
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.MpiFlowHipError("HipPredictor needs the model on the GPU; there is no CPU path")

@@ -177,14 +177,20 @@ def main(argv=None):
                     mpi, planes = mpi_from_disparity(image[0], disp[0, 0], opt.planes)
                 renderer.blend(mpi, image[0], K, planes, cum_mask=cum_mask)      # once per image; the `repeat` pairs below reuse it
                 ring.submit_source(ops.png_scanlines(renderer.src_u8), [os.path.join(out, "src_images", f"{name}_{r}.png") for r in range(opt.repeat)])  # :122
+        # every rank draws for every pair, so the stream position is identical to a single-process run.  The reference interleaves
+        # an np.random draw (instance id, :101) with 24 `random` draws (two poses, utils.py:207-208) per pair; the two generators
+        # are independent, so the image's draws are taken in that order here and its 2 x repeat poses built in one batched call
+        with lap("pose draws"):
+            obj_indices, pose_params = [], []
+            for r in range(opt.repeat):
+                obj_indices.append(np.random.randint(mask_max) + 1)
+                pose_params.append(host_math.draw_pose_parameters(opt.ext_cz, profile=opt.poses))
+                pose_params.append(host_math.draw_pose_parameters(opt.ext_cz, base_motions=[0, 0, 0], profile=opt.poses))
+            poses = host_math.poses_from_parameters(pose_params) if mine else None
         for r in range(opt.repeat):
-            # every rank draws for every pair, so the stream position is identical to a single-process run
-            with lap("pose draws"):
-                obj_index = np.random.randint(mask_max) + 1                                                       # :101
-                cam_ext_dynamic = host_math.generate_random_pose(opt.ext_cz, profile=opt.poses)                   # utils.py:207
-                cam_ext = host_math.generate_random_pose(opt.ext_cz, base_motions=[0, 0, 0], profile=opt.poses)   # utils.py:208
             if not mine:
                 continue
+            obj_index, cam_ext_dynamic, cam_ext = obj_indices[r], poses[2 * r], poses[2 * r + 1]
             with lap("instance mask"):
                 obj_mask = (ids == obj_index).to(torch.float32)[None, None]                                       # :102-105
                 obj_mask = F.interpolate(obj_mask, size=(opt.height, opt.width), mode="bilinear", align_corners=True)

@@ -66,6 +66,25 @@ def homographies(G_tgt_src, K_src_inv, K_tgt, depth_S):
     return H_ts, H_st
 
 
+def homographies_multi(G_list, K_src_inv, K_tgt, depth_S):
+    """homographies() for P poses in ONE batched evaluation ([P*S,3,3] stacks: every matrix goes through the same per-matrix
+    matmul / LU code as in a [S,3,3] batch, so the results are bit-identical - asserted against the goldens).
+    -> (H_tgt_src [P,S,3,3], H_src_tgt [P,S,3,3])"""
+    d = _cpu32(depth_S).reshape(-1)
+    S, P = d.numel(), len(G_list)
+    G = torch.stack([_cpu32(g).reshape(4, 4) for g in G_list]).unsqueeze(1).repeat(1, S, 1, 1).reshape(P * S, 4, 4)
+    Kinv = _cpu32(K_src_inv).reshape(1, 3, 3).repeat(P * S, 1, 1)
+    Kt = _cpu32(K_tgt).reshape(1, 3, 3).repeat(P * S, 1, 1)
+    R = G[:, 0:3, 0:3]
+    t = G[:, 0:3, 3]
+    n = torch.tensor([0, 0, 1], dtype=torch.float32).unsqueeze(0).repeat(P * S, 1)
+    d33 = d.repeat(P).reshape(P * S, 1, 1).repeat(1, 3, 3)
+    R_tnd = R - torch.matmul(t.unsqueeze(2), n.unsqueeze(1)) / -d33
+    H_ts = torch.matmul(Kt, torch.matmul(R_tnd, Kinv))
+    H_st = inverse(H_ts.to(torch.float64)).to(torch.float32)
+    return H_ts.reshape(P, S, 3, 3), H_st.reshape(P, S, 3, 3)
+
+
 def pack_params(K_inv=None, G=None, homs=None, depths=None, records=None):
     """Build the `d_params` host image (float32 CPU tensor) of include/mpiflow_hip.h.
     homs: [R,3,3] (record r = s*P + p), depths: [R] (already repeated per record)."""
@@ -148,11 +167,10 @@ POSE_PROFILES = {
 }
 
 
-def generate_random_pose(ext_cz=0.1, base_motions=None, rng=None, profile="v2"):
-    """Random camera extrinsic.  Draw order - 3x randrange(2), 3x random(), 3x randrange(2), 3x random() on Python's
-    `random` - is part of the contract (seeded runs reproduce the reference's poses), and so is the order of the float
-    operations (the pose feeds 3x3 algebra whose last ulp matters).
-    `rng`: a random.Random; default = the module-level generator the reference uses.  Returns a [4,4] fp32 CPU tensor."""
+def draw_pose_parameters(ext_cz=0.1, base_motions=None, rng=None, profile="v2"):
+    """The 12 draws of one pose and the reference's scalar arithmetic on them -> (axis-angle [3], translation [3]) as Python
+    floats.  Draw order - 3x randrange(2), 3x random(), 3x randrange(2), 3x random() on Python's `random` - is part of the
+    contract (seeded runs reproduce the reference's poses), and so is the order of the float operations."""
     import random as _random
     rng = rng or _random
     prof = POSE_PROFILES[profile]
@@ -172,6 +190,21 @@ def generate_random_pose(ext_cz=0.1, base_motions=None, rng=None, profile="v2"):
         sign_a = [v * 0.5 for v in sign_a]
     ang = [(rng.random() * math.pi / 36.0) * sign_a[i] for i in range(3)]
     ang = [v * prof["angle_scale"] for v in ang]
+    return ang, t
+
+
+def poses_from_parameters(params):
+    """[(axis-angle, translation), ...] -> [n,4,4] fp32 CPU, one batched transformation_from_parameters (bit-identical to n
+    single evaluations: element-wise ops and per-matrix 4x4 products; asserted against the reference's pose goldens)."""
+    aa = torch.from_numpy(np.array([p[0] for p in params], dtype=np.float32).reshape(-1, 1, 3)).float()
+    tr = torch.from_numpy(np.array([p[1] for p in params]).reshape(-1, 1, 3)).float()
+    return transformation_from_parameters(aa, tr)
+
+
+def generate_random_pose(ext_cz=0.1, base_motions=None, rng=None, profile="v2"):
+    """Random camera extrinsic (utils/utils.py:121-156 and its two variants) -> [4,4] fp32 CPU tensor.
+    `rng`: a random.Random; default = the module-level generator the reference uses."""
+    ang, t = draw_pose_parameters(ext_cz, base_motions, rng, profile)
     axisangle = torch.from_numpy(np.array([[ang]], dtype=np.float32)).float()
     translation = torch.from_numpy(np.array([[t]])).float()
     return transformation_from_parameters(axisangle, translation)[0]

@@ -54,12 +54,9 @@ class PairRenderer:
         """poses: list of 4x4 G_tgt_src (1 or 2).  Computes K^-1, plane depths, per-plane homographies on the host
         (torch-CPU, reference expressions) and uploads them.  Returns a dict handed to run()."""
         k_inv, d = self._constants(K, disparity)
-        hts, wp = [], []
-        for G in poses:
-            H_ts, H_st = host_math.homographies(G, k_inv, K, d)
-            hts.append(H_ts)
-            wp.append(ops.upload_params(ops.warp_params(H_st, k_inv, G, d), self.device))
-        bf, P = ops.blend_flow_params(k_inv, d, torch.stack(hts))
+        H_ts, H_st = host_math.homographies_multi(poses, k_inv, K, d)             # all poses of the pair in one batched evaluation
+        wp = [ops.upload_params(ops.warp_params(H_st[i], k_inv, G, d), self.device) for i, G in enumerate(poses)]
+        bf, P = ops.blend_flow_params(k_inv, d, H_ts)
         return dict(P=P, blend=ops.upload_params(bf, self.device), warp=wp, k_inv=k_inv, depths=d)
 
     # -- device side: launches only ------------------------------------------------------------------------------------

@@ -173,3 +173,26 @@ def test_write_flow_mirror_writes_the_reference_bytes(tmp_path, capsys):
     bad = tmp_path / "bad.flo"
     bad.write_bytes(b"\0" * 64)
     assert write_flow.readFlow(str(bad)) is None and "Magic number incorrect" in capsys.readouterr().out
+
+
+def test_batched_host_algebra_is_bit_identical_to_single_evaluations():
+    """The generator builds an image's 2 x repeat poses and a pair's 2 x S homographies in one batched call each; the results
+    must be the bits of the one-at-a-time evaluations (which are pinned against the reference)."""
+    import random as _random
+    from mpiflow_amd import host_math, synth
+    g = load_golden("pose_schedule")
+    rng = _random.Random(int(g["seed"]))
+    params = []
+    for _ in range(g["G_dyn"].shape[0]):
+        params.append(host_math.draw_pose_parameters(float(g["ext_cz"]), rng=rng))
+        params.append(host_math.draw_pose_parameters(float(g["ext_cz"]), base_motions=[0, 0, 0], rng=rng))
+    M = host_math.poses_from_parameters(params).numpy()
+    assert np.array_equal(M[0::2], g["G_dyn"]) and np.array_equal(M[1::2], g["G_cam"])
+    K = torch.from_numpy(synth.intrinsics(48, 64))
+    k_inv = host_math.k_inverse(K)
+    d = host_math.plane_depths(torch.from_numpy(synth.plane_disparities(20)))
+    poses = [torch.from_numpy(g["G_cam"][3]), torch.from_numpy(g["G_dyn"][5]), torch.from_numpy(g["G_dyn"][0])]
+    H_ts, H_st = host_math.homographies_multi(poses, k_inv, K, d)
+    for i, G in enumerate(poses):
+        a, b = host_math.homographies(G, k_inv, K, d)
+        assert torch.equal(H_ts[i], a) and torch.equal(H_st[i], b)

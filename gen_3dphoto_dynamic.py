@@ -56,6 +56,10 @@ def parse(argv=None):
                         "the MFMA convolution engine (fp16 storage, fp32 accumulate - the reference's GPU precision), one hipGraph per image")
     p.add_argument("--inpaint", choices=["auto", "cv2", "hip", "none"], default="auto")
     p.add_argument("--writers", type=int, default=8, help="writer threads (PNG encode + file I/O overlap the GPU); 0 = synchronous")
+    p.add_argument("--lanes", type=int, default=1,
+                   help="images in flight on this GPU, each with its own streams, plane-stack buffer and network graph (same files for any "
+                        "value).  Measured on MI355X: 1 lane 359 pairs/s, 2 lanes 267, 3 lanes 298 - the kernels are sized to fill the GPU on "
+                        "their own, concurrent images only fight over the caches")
     opt, _ = p.parse_known_args(argv)
     return opt
 
@@ -117,13 +121,23 @@ def main(argv=None):
         else:
             model = MPIPredictor.from_checkpoint(opt.ckpt_path, opt.width, opt.height).to(dev)      # :52-60
             opt.planes = model.num_planes
-        if opt.model_engine == "hip":
-            from mpiflow_amd.model.engine import HipPredictor
-            hip_model = HipPredictor(model, encoder_dtype=amp, graph=True)
-    renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
+    use_hip_model = model is not None and opt.model_engine == "hip"
+
+    class Lane:
+        """Everything one in-flight image owns: its streams, the blended plane stack, the network graph and its static buffers."""
+
+        def __init__(self):
+            self.stream, self.tail_stream, self.tail_ready = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Event()
+            self.renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
+            self.fill_ws = torch.empty(int(_lib.load().mpf_fill_holes_workspace(opt.height, opt.width)), dtype=torch.uint8, device=dev)
+            self.hip_model = None
+            if use_hip_model:
+                from mpiflow_amd.model.engine import HipPredictor
+                self.hip_model = HipPredictor(model, encoder_dtype=amp, graph=True)
+
+    lanes = [Lane() for _ in range(max(1, opt.lanes))]
     dstats = pipeline.DeviceStats(dev)
     ring = io_formats.OutputRing(opt.height, opt.width, dev, slots=max(4, 2 * max(opt.writers, 1)), threads=max(opt.writers, 1))
-    fill_ws = torch.empty(int(_lib.load().mpf_fill_holes_workspace(opt.height, opt.width)), dtype=torch.uint8, device=dev)
     t_start = time.perf_counter()
     prof = {}
 
@@ -143,9 +157,8 @@ def main(argv=None):
                 prof[self.key] = prof.get(self.key, 0.0) + time.perf_counter() - self.t
 
     import torch.nn.functional as F
-    tail_stream, tail_ready = torch.cuda.Stream(device=dev), torch.cuda.Event()
     inputs = io_formats.InputPrefetcher(names, img_base, disp_base, mask_base, owned=lambda i: (i % world) == rank, pin=True)
-    n_pairs, t_first, n_first = 0, None, 0
+    n_pairs, t_first, n_first, n_owned = 0, None, 0, 0
     it = iter(inputs)
     while True:
         with lap("wait for decoded inputs"):
@@ -155,6 +168,11 @@ def main(argv=None):
         i, img, mask_max, ids_host, image_host, disp_host = item
         name = img.split(".")[0]
         mine = image_host is not None
+        lane = lanes[n_owned % len(lanes)]
+        n_owned += int(mine)
+        renderer, hip_model, tail_stream, tail_ready, fill_ws = lane.renderer, lane.hip_model, lane.tail_stream, lane.tail_ready, lane.fill_ws
+        lane_ctx = torch.cuda.stream(lane.stream)
+        lane_ctx.__enter__()                                      # everything this image enqueues goes to its lane's stream
         if mine:
             with lap("upload + resize image, disparity, mask"):
                 image = image_host.to(dev, non_blocking=True)[None]
@@ -216,8 +234,9 @@ def main(argv=None):
                     ring.submit_pair(res["flow_mix"], scan, os.path.join(out, "flows", f"{name}_{r}.flo"),            # :120
                                      os.path.join(out, "dst_images", f"{name}_{r}.png"))                              # :121
             n_pairs += 1
-        if mine and t_first is None:
-            t_first, n_first = time.perf_counter(), n_pairs       # start-up (graph capture, first MIOpen calls) ends with the first image
+        lane_ctx.__exit__(None, None, None)
+        if mine and t_first is None and n_owned >= len(lanes):
+            t_first, n_first = time.perf_counter(), n_pairs       # start-up (graph capture, first MIOpen calls) ends once every lane has run
     with lap("drain writers"):
         torch.cuda.synchronize()
         ring.close()

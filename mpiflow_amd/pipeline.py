@@ -182,7 +182,8 @@ class DeviceStats:
     def add(self, flow_mix, fill_mask):
         from . import ops
         if self.n % self.CHUNK == 0:
-            self.chunks.append(torch.zeros((self.CHUNK, ops.PAIR_STATS_SLICES, 4), dtype=torch.float64, device=self.device))
+            # empty, not zeros: rows are written whole by mpf_pair_stats, possibly from several streams, and only written rows are read
+            self.chunks.append(torch.empty((self.CHUNK, ops.PAIR_STATS_SLICES, 4), dtype=torch.float64, device=self.device))
         ops.pair_stats(flow_mix, fill_mask, self.chunks[-1][self.n % self.CHUNK])
         self.n += 1
 

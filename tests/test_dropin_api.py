@@ -233,6 +233,9 @@ def test_cli_two_ranks_write_the_files_of_one_rank(dev, tmp_path):
         Image.fromarray(m).save(base / "masks" / ("im%d.png" % i))
     args = ["--base", str(base), "--width", "64", "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "hip"]
     one, two = tmp_path / "one", tmp_path / "two"
+    lanes = tmp_path / "lanes"                      # two images in flight on one rank: same files again
+    r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--out", str(lanes), "--lanes", "2"] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--out", str(one)] + args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     env = dict(os.environ, MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
@@ -246,6 +249,7 @@ def test_cli_two_ranks_write_the_files_of_one_rank(dev, tmp_path):
         assert len(files) == 6 and files == sorted(os.listdir(two / sub))
         for f in files:
             assert open(one / sub / f, "rb").read() == open(two / sub / f, "rb").read(), "%s/%s differs between 1 and 2 ranks" % (sub, f)
+            assert open(one / sub / f, "rb").read() == open(lanes / sub / f, "rb").read(), "%s/%s differs between 1 and 2 lanes" % (sub, f)
 
 
 def test_cli_with_network_producer(dev, tmp_path):

@@ -20,6 +20,7 @@ for i in range(n_img):
     Image.fromarray(m).save(os.path.join(base, "masks", "%04d.png" % i))
 configs = [("hip engine, 16 writers (warm-up run)", ["--model-engine", "hip", "--writers", "16"]),
            ("hip engine, 16 writers", ["--model-engine", "hip", "--writers", "16"]),
+           ("hip engine, 16 writers, 2 lanes", ["--model-engine", "hip", "--writers", "16", "--lanes", "2"]),
            ("hip engine, 4 writers", ["--model-engine", "hip", "--writers", "4"])]
 if "--torch" in sys.argv:
     configs.append(("torch fp16, 16 writers", ["--model-engine", "torch", "--model-dtype", "fp16", "--writers", "16"]))

@@ -180,8 +180,8 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const __half2 h00 = as_h2(r00[i]), h01 = as_h2(r01[i]), h10 = as_h2(r10[i]), h11 = as_h2(r11[i]);
-                const float lo = fmaf(__low2float(h11), st.w11, fmaf(__low2float(h10), st.w10, fmaf(__low2float(h01), st.w01, __low2float(h00) * st.w00)));
-                const float hi = fmaf(__high2float(h11), st.w11, fmaf(__high2float(h10), st.w10, fmaf(__high2float(h01), st.w01, __high2float(h00) * st.w00)));
+                const float lo = fmaf(__low2float(h11), st.w11, fmaf(__low2float(h10), st.w10, fmaf(__low2float(h01), st.w01, fmaf(__low2float(h00), st.w00, 0.f))));
+                const float hi = fmaf(__high2float(h11), st.w11, fmaf(__high2float(h10), st.w10, fmaf(__high2float(h01), st.w01, fmaf(__high2float(h00), st.w00, 0.f))));
                 o[i] = pack2(lo, hi);
             }
             return select4(st.ok, o);

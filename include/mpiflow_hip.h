@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPF_VERSION 100
+#define MPF_VERSION 200
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)
@@ -94,6 +94,23 @@ int mpf_build_mask_quads(const float *d_obj_mask, int complement, int H, int W, 
 int mpf_warp_composite(const float *d_rgba, int interleaved, const float *d_mask_quads, const float *d_params,
                        int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask, float *d_tgt_mask,
                        uint8_t *d_rgb_u8_bgr, void *stream);
+
+/* Stage B for SEVERAL views of one stack in one launch.  The reference renders two poses of every stack
+ * (utils/utils.py:210-222 with obj_mask / cam_ext and :224-236 with 1 - obj_mask / cam_ext_dynamic) and `repeat` such
+ * pairs per image (gen_3dphoto_dynamic_v2.py:99-118); launched together, the views' workgroups walk the planes side by
+ * side and the stack is fetched from HBM once per launch instead of once per view.  Results are bit-identical to n_views
+ * calls of mpf_warp_composite.  `views` is a HOST array of n_views (<= MPF_MAX_VIEWS) descriptors holding DEVICE
+ * pointers with the meaning of the same-named mpf_warp_composite arguments; it is copied into the kernel arguments, so
+ * it may be reused or freed as soon as the call returns.  All views take a mask, or none does.  interleaved: 1 or 2. */
+#define MPF_MAX_VIEWS 16
+typedef struct MpfWarpView {
+    const float *d_params;
+    const float *d_mask_quads;
+    float *d_rgb, *d_depth, *d_objmask, *d_tgt_mask;
+    uint8_t *d_rgb_u8_bgr;
+} MpfWarpView;
+int mpf_warp_composite_views(const float *d_rgba, int interleaved, const MpfWarpView *views, int n_views, int S, int H,
+                             int W, void *stream);
 
 /* Stage D.  Replaces utils/utils.py:237-283 (uint8 BGR conversion, threshold, layer select, fill mask).
  * frames [3,H,W] RGB float, masks [H,W], flows [2,H,W], obj_mask [H,W] ->

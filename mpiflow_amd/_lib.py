@@ -35,6 +35,14 @@ class MpfConvArgs(ctypes.Structure):
                 ("fparams", c_f * 4), ("wlds", c_i)]
 
 
+class MpfWarpView(ctypes.Structure):
+    """struct MpfWarpView of include/mpiflow_hip.h: one view of mpf_warp_composite_views (device pointers)."""
+    _fields_ = [("d_params", c_p), ("d_mask_quads", c_p), ("d_rgb", c_p), ("d_depth", c_p), ("d_objmask", c_p),
+                ("d_tgt_mask", c_p), ("d_rgb_u8_bgr", c_p)]
+
+
+MAX_VIEWS = 16          # MPF_MAX_VIEWS
+
 # name -> (restype, argtypes); must list every symbol include/mpiflow_hip.h declares (tests/test_capi.py checks)
 SIGNATURES = {
     "mpf_version": (c_i, []),
@@ -43,6 +51,7 @@ SIGNATURES = {
     "mpf_src_blend_flow": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpf_build_mask_quads": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "mpf_warp_composite": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "mpf_warp_composite_views": (c_i, [c_p, c_i, ctypes.POINTER(MpfWarpView), c_i, c_i, c_i, c_i, c_p]),
     "mpf_merge": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),
     "mpf_fill_holes_workspace": (c_sz, [c_i, c_i]),
     "mpf_fill_holes": (c_i, [c_p, c_p, c_i, c_i, c_p, c_sz, c_p]),

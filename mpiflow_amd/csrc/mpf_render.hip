@@ -311,11 +311,11 @@ struct MpfAcc {
 template <bool HAS_MASK, int NL, int TW, int TH, bool KS, bool TP, int DBG = 0, bool AUX = true>
 MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
                           int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
-                          float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
+                          float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out,
+                          const unsigned tile)
 {
     const int64_t N = (int64_t)H * W;
     const unsigned tiles_x = (W + TW - 1) / TW;
-    const unsigned tile = mpf_xcd_remap(blockIdx.x, gridDim.x);
     const int x = (tile % tiles_x) * TW + (threadIdx.x % TW);
     const int y = (tile / tiles_x) * TH + (threadIdx.x / TW);
     const bool active = (x < W) && (y < H);
@@ -422,7 +422,24 @@ k_warp_composite_dbg(const float *__restrict__ rgba, const float *__restrict__ q
                      int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
                      float *__restrict__ om_out, float *__restrict__ tgt_mask_out)
 {
-    mpf_wc2_body<HAS_MASK, 2, TW, TH, true, true, DBG>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, nullptr);
+    mpf_wc2_body<HAS_MASK, 2, TW, TH, true, true, DBG>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, nullptr,
+                                                       mpf_xcd_remap(blockIdx.x, gridDim.x));
+}
+
+template <bool HAS_MASK, int NL, int TW, int TH, bool TP>
+MPF_DEV void mpf_wc2_select(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
+                            int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                            float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out,
+                            const unsigned tile)
+{
+    const bool pinhole = (params[1] == 0.0f) & (params[3] == 0.0f) & (params[6] == 0.0f) & (params[7] == 0.0f) & (params[8] == 1.0f);
+    const bool aux = (depth_out != nullptr) | (tgt_mask_out != nullptr);   // depth / validity count wanted at all?
+    if (pinhole && !aux)
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP, 0, false>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile);
+    else if (pinhole)
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP, 0, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile);
+    else
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, false, TP, 0, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile);
 }
 
 template <bool HAS_MASK, int NL, int TW, int TH, int WPS, bool TP>
@@ -431,14 +448,26 @@ k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ qu
                     int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
                     float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
 {
-    const bool pinhole = (params[1] == 0.0f) & (params[3] == 0.0f) & (params[6] == 0.0f) & (params[7] == 0.0f) & (params[8] == 1.0f);
-    const bool aux = (depth_out != nullptr) | (tgt_mask_out != nullptr);   // depth / validity count wanted at all?
-    if (pinhole && !aux)
-        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP, 0, false>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out);
-    else if (pinhole)
-        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP, 0, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out);
-    else
-        mpf_wc2_body<HAS_MASK, NL, TW, TH, false, TP, 0, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out);
+    mpf_wc2_select<HAS_MASK, NL, TW, TH, TP>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out,
+                                             mpf_xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Several views of ONE stack in one launch (the reference renders two poses of every stack, utils/utils.py:210-236, and
+// `repeat` such pairs per image, gen_3dphoto_dynamic_v2.py:99-118).  Logical block l = tile * V + view: the V workgroups of a
+// tile are dispatched back to back on the same XCD, walk the planes at the same pace and so find each other's texels in
+// that XCD's L2 (or in the Infinity Cache) - the 16*S*N-byte stack crosses the HBM interface once per launch instead of
+// once per view.  Same body, same registers, same occupancy as the single-view kernel; results are bit-identical.
+struct MpfViewSet { MpfWarpView v[MPF_MAX_VIEWS]; };
+
+template <bool HAS_MASK, int NL, int TW, int TH, int WPS, bool TP>
+__global__ void __launch_bounds__(TW *TH, WPS)
+k_warp_composite_views(const float *__restrict__ rgba, const MpfViewSet vs, const unsigned V, int S, int H, int W)
+{
+    const unsigned l = mpf_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned view = l % V, tile = l / V;
+    const MpfWarpView &w = vs.v[view];
+    mpf_wc2_select<HAS_MASK, NL, TW, TH, TP>(rgba, w.d_mask_quads, w.d_params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask,
+                                             w.d_rgb_u8_bgr, tile);
 }
 
 static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = v2 shapes
@@ -516,6 +545,43 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
     }
     if (d_mask_quads) return launch_warp_composite<false, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
     return launch_warp_composite<false, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, d_rgb_u8_bgr, st);
+}
+
+template <bool HAS_MASK>
+static int launch_views(bool tp, const float *rgba, const MpfViewSet &vs, int V, int S, int H, int W, hipStream_t st)
+{
+    constexpr int TW = 32, TH = 8, WPS = 5;
+    const unsigned tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    dim3 grid(tiles * (unsigned)V), block(TW * TH);
+#define MPF_WCV(NLv, TPv) hipLaunchKernelGGL((k_warp_composite_views<HAS_MASK, NLv, TW, TH, WPS, TPv>), grid, block, 0, st, rgba, vs, (unsigned)V, S, H, W)
+    if (S < 256) { if (tp) MPF_WCV(2, true); else MPF_WCV(2, false); }
+    else         { if (tp) MPF_WCV(3, true); else MPF_WCV(3, false); }
+#undef MPF_WCV
+    return mpf_launch_status("k_warp_composite_views");
+}
+
+extern "C" int mpf_warp_composite_views(const float *d_rgba, int interleaved, const MpfWarpView *views, int n_views, int S, int H,
+                                        int W, void *stream)
+{
+    MPF_REQUIRE(d_rgba && views, "mpf_warp_composite_views: null pointer");
+    MPF_REQUIRE(n_views >= 1 && n_views <= MPF_MAX_VIEWS, "mpf_warp_composite_views: n_views must be 1..%d (got %d)", MPF_MAX_VIEWS, n_views);
+    MPF_REQUIRE(interleaved == 1 || interleaved == 2, "mpf_warp_composite_views: the stack must be interleaved [S,H,W,4] (1, or 2 = tail-padded)");
+    MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_warp_composite_views: bad shape S=%d H=%d W=%d", S, H, W);
+    MPF_REQUIRE((int64_t)H * W < ((int64_t)1 << 27), "mpf_warp_composite_views: H*W too large for 32-bit byte offsets");
+    MPF_REQUIRE(mpf_aligned16(d_rgba), "mpf_warp_composite_views: the stack must be 16-byte aligned");
+    MpfViewSet vs;
+    memset(&vs, 0, sizeof(vs));
+    const bool has_mask = views[0].d_mask_quads != nullptr;
+    for (int v = 0; v < n_views; ++v) {
+        const MpfWarpView &w = views[v];
+        MPF_REQUIRE(w.d_params && w.d_rgb, "mpf_warp_composite_views: view %d: null params / rgb", v);
+        MPF_REQUIRE((w.d_mask_quads != nullptr) == has_mask, "mpf_warp_composite_views: all views of a call take a mask, or none does");
+        MPF_REQUIRE((w.d_mask_quads == nullptr) == (w.d_objmask == nullptr), "mpf_warp_composite_views: view %d: mask quads and objmask output go together", v);
+        MPF_REQUIRE(mpf_aligned16(w.d_mask_quads), "mpf_warp_composite_views: view %d: mask quads must be 16-byte aligned", v);
+        vs.v[v] = w;
+    }
+    if (has_mask) return launch_views<true>(interleaved == 2, d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
+    return launch_views<false>(interleaved == 2, d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
 }
 
 // mask quads ---------------------------------------------------------------------------------------------------

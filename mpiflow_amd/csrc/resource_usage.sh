@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel register / occupancy summary (hipcc -Rpass-analysis=kernel-resource-usage), one line per kernel.
 # usage: ./resource_usage.sh mpf_render.hip
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FLAGS -Rpass-analysis=kernel-resource-usage -c "$1" -o /dev/null 2>&1 | python3 -c '
 import sys,re,subprocess
 cur={}

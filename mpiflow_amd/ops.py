@@ -158,14 +158,41 @@ def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None
 
 
 @_on_device
-def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.99):
+def warp_composite_views(rgba, views, interleaved=2):
+    """Stage B for several views of one interleaved stack in ONE launch (mpf_warp_composite_views): the stack crosses the HBM
+    interface once instead of once per view.  views: list of dicts(dparams=, quads= | None, out=dict(rgb, objmask?, depth?,
+    tgt_mask?, rgb_u8?)) - every buffer preallocated.  Bit-identical to len(views) warp_composite calls."""
+    lib = _lib.load()
+    a = _dev(rgba, "rgba")
+    S, H, W, C = a.shape
+    assert C == 4 and interleaved in (1, 2) and 1 <= len(views) <= _lib.MAX_VIEWS
+    if interleaved == 2:
+        assert a.untyped_storage().nbytes() - a.storage_offset() * 4 >= a.numel() * 4 + (W + 1) * 16
+    arr = (_lib.MpfWarpView * len(views))()
+    for i, v in enumerate(views):
+        o = v["out"]
+        q = v.get("quads")
+        for t in [v["dparams"], q] + [o.get(k) for k in ("rgb", "depth", "objmask", "tgt_mask", "rgb_u8")]:
+            assert t is None or (t.is_cuda and t.is_contiguous() and t.device == a.device)
+        arr[i] = _lib.MpfWarpView(v["dparams"].data_ptr(), q.data_ptr() if q is not None else None, o["rgb"].data_ptr(),
+                                  *[(o[k].data_ptr() if o.get(k) is not None else None) for k in ("depth", "objmask", "tgt_mask", "rgb_u8")])
+    _lib.check(lib.mpf_warp_composite_views(_ptr(a), int(interleaved), arr, len(views), S, H, W, _stream()), "mpf_warp_composite_views")
+    return [v["out"] for v in views]
+
+
+@_on_device
+def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.99, out=None):
+    """Stage D.  out: optional preallocated (flow_mix [H,W,2] f32, frame_mix [H,W,3] u8, fill_mask [H,W] u8)."""
     lib = _lib.load()
     frame = _dev(frame, "frame")
     _, H, W = frame.shape
     dev = frame.device
-    flow_mix = torch.empty((H, W, 2), dtype=_f32, device=dev)
-    frame_mix = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-    fill = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    if out is not None:
+        flow_mix, frame_mix, fill = out
+    else:
+        flow_mix = torch.empty((H, W, 2), dtype=_f32, device=dev)
+        frame_mix = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        fill = torch.empty((H, W), dtype=torch.uint8, device=dev)
     args = [_dev(frame_dyn, "frame_dyn").reshape(3, H, W), _dev(mask, "mask").reshape(H, W),
             _dev(mask_dyn, "mask_dyn").reshape(H, W), _dev(flow, "flow").reshape(2, H, W),
             _dev(flow_dyn, "flow_dyn").reshape(2, H, W), _dev(obj_mask, "obj_mask").reshape(H, W)]

@@ -12,6 +12,7 @@ All buffers are allocated once per (S,H,W) and reused; per pair only ~10 KB of s
 per rank and never exchanges tensor data between GPUs: images are independent (reference loop
 gen_3dphoto_dynamic_v2.py:78-122), the only collective is one all-reduce of a ~10-float statistics vector per batch.
 """
+import os
 import random
 
 import numpy as np
@@ -38,6 +39,7 @@ class PairRenderer:
         self.quads = [torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)]    # obj_mask, 1 - obj_mask
         self.src_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         self.n_views = n_views
+        self.multi_view = True      # all Stage B views of a pair in ONE launch (mpf_warp_composite_views); False: one launch per view
 
     # -- host side: small matrices ---------------------------------------------------------------------------------
     def _constants(self, K, disparity):
@@ -82,9 +84,13 @@ class PairRenderer:
                            dparams=prep["blend"], P=P, src_u8=None if reuse_blend else self.src_u8, obj_mask=obj_mask,
                            quads=self.quads[0] if need_p else None, quads_complement=self.quads[1] if need_c else None,
                            cum_mask=cum_mask)
-        for v in range(P):
-            ops.warp_composite(self.rgba, self.quads[1 if complement[v] else 0], dparams=prep["warp"][v], out=self.views[v],
-                               interleaved=2)
+        if P > 1 and self.multi_view:
+            ops.warp_composite_views(self.rgba, [dict(dparams=prep["warp"][v], quads=self.quads[1 if complement[v] else 0], out=self.views[v])
+                                                 for v in range(P)], interleaved=2)
+        else:
+            for v in range(P):
+                ops.warp_composite(self.rgba, self.quads[1 if complement[v] else 0], dparams=prep["warp"][v], out=self.views[v],
+                                   interleaved=2)
         return self.flows, self.views
 
 
@@ -142,6 +148,31 @@ def pose_schedule(seed, n_pairs, ext_cz):
         cam = host_math.generate_random_pose(ext_cz, base_motions=(0, 0, 0), rng=rng)
         out.append((cam, dyn))
     return out
+
+
+def device_identity(local_index):
+    """A string that is equal for two processes iff they drive the same physical GPU of this node."""
+    import socket
+    props = torch.cuda.get_device_properties(local_index)
+    uid = getattr(props, "uuid", None)
+    if uid is None or not str(uid).strip("0-"):          # not populated by this runtime: visible-device list + index identifies it
+        uid = "%s|%s|%d" % (os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""), local_index)
+    return "%s/%s" % (socket.gethostname(), uid)
+
+
+def assert_distinct_devices(local_index, group=None):
+    """One process per GPU: every rank publishes the identity of its device through the process group's
+    key-value store (no collective, so it also works before the first RCCL communicator exists) and fails fast when two
+    ranks share one - RCCL would otherwise stall or abort deep inside its first all-reduce."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    store = dist.distributed_c10d._get_default_store()
+    store.set("mpiflow_dev_%d" % rank, device_identity(local_index))
+    ids = [store.get("mpiflow_dev_%d" % r).decode() for r in range(world)]      # get() blocks until the key exists
+    dup = sorted({i for i in ids if ids.count(i) > 1})
+    if dup:
+        raise RuntimeError("ranks share a GPU: %s (rank -> device: %s); launch one process per GPU" % (dup, dict(enumerate(ids))))
+    return ids
 
 
 STAT_NAMES = ["pairs", "sum_flow_mag", "hole_px", "kernel_seconds", "max_flow_mag", "wall_seconds", "neg_min_flow"]

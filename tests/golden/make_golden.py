@@ -175,8 +175,10 @@ def gen_small(name, S, H, W, kind, seed, pose_seed, full_intermediates):
     save(name, **arrays)
 
 
-def gen_big(name, S, H, W, kind, seed, pose_seed):
-    """Config-shape goldens: seeds + poses + values at a fixed pixel sample + packed bit masks."""
+def gen_big(name, S, H, W, kind, seed, pose_seed, stack_px=None):
+    """Config-shape goldens: seeds + poses + values at a fixed pixel sample + packed bit masks.
+    stack_px: keep the per-plane [S, ...] samples (blend weights, blended stack) at only the first `stack_px` sample
+    pixels (keeps the 128-plane file small)."""
     inp = synth.make_inputs(S, H, W, seed=seed, kind=kind)
     t0 = time.time()
     pair = run_pair(inp, pose_seed)
@@ -192,8 +194,8 @@ def gen_big(name, S, H, W, kind, seed, pose_seed):
                   fill_mask_bits=np.packbits(pair["fill_mask"].ravel()), fill_mask_count=int(pair["fill_mask"].sum()),
                   sha_frame_mix=sha(pair["frame_mix"]), sha_fill_mask=sha(pair["fill_mask"]), sha_src_np=sha(pair["src_np"]),
                   flow_mix_stats=np.array([pair["flow_mix"].min(), pair["flow_mix"].max(), pair["flow_mix"].astype(np.float64).sum()]),
-                  blend_weights_px=views["blend_weights"].reshape(S, -1)[:, px],
-                  rgb_blended_px=views["rgb_blended"].reshape(S, 3, -1)[:, :, px])
+                  blend_weights_px=views["blend_weights"].reshape(S, -1)[:, px[:stack_px]],
+                  rgb_blended_px=views["rgb_blended"].reshape(S, 3, -1)[:, :, px[:stack_px]])
     for tag in ("cam", "dyn"):
         v = views[tag]
         arrays["%s_rgb_px" % tag] = v["rgb"].reshape(3, -1)[:, px]
@@ -421,6 +423,8 @@ JOBS = {
                     gen_small("s1", 1, 16, 24, "white", 5, 11, False)),
     "c1": lambda: gen_big("c1_white", 32, 384, 512, "white", 11, 21),
     "c2": lambda: (gen_big("c2_white", 64, 640, 960, "white", 12, 22), gen_big("c2_smooth", 64, 640, 960, "smooth", 13, 23)),
+    # BASELINE configs[4] shape with the reference sampler's random poses (~40 GB peak, ~25 min on 8 threads)
+    "c5": lambda: gen_big("c5_white", 128, 1024, 1536, "white", 14, 24, stack_px=512),
     "fwarp": lambda: (gen_fwarp("fwarp_small", 96, 128, 31, True), gen_fwarp("fwarp_c2", 640, 960, 32, False),
                       gen_collision_stress()),
     "exp": gen_exp,

@@ -127,6 +127,16 @@ int mpf_merge(const float *d_frame, const float *d_frame_dyn, const float *d_mas
 size_t mpf_fill_holes_workspace(int H, int W);
 int mpf_fill_holes(uint8_t *d_img, uint8_t *d_hole, int H, int W, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The reference's own hole filling, on the HOST (host pointers, synchronous, re-entrant, no GPU involved): OpenCV's
+ * cv2.inpaint(img, mask, radius, flags) for flags = cv2.INPAINT_NS (utils/utils.py:284-286: frame_mix, fill_mask, radius 3)
+ * and cv2.INPAINT_TELEA (moving_obj.py:162: im1_raw, 1 - H, radius 3) - the fast-marching front of modules/photo/src/inpaint.cpp
+ * with its order of operations (third-party arithmetic: parity with cv2 itself is unpinned until a test has run next to a real
+ * cv2).  img u8 [H,W,C] (C = 1 or 3), mask u8 [H,W] (non-zero = fill), out u8 [H,W,C] (may not alias img).
+ * Filling is sequential by nature (every pixel reads pixels filled before it), so callers run one frame per host thread. */
+#define MPF_INPAINT_NS 0
+#define MPF_INPAINT_TELEA 1
+int mpf_inpaint_host(const uint8_t *img, const uint8_t *mask, int H, int W, int C, double radius, int method, uint8_t *out);
+
 /* End-of-batch statistics of one pair, without a host round trip: d_out holds
  * MPF_PAIR_STATS_SLICES rows of 4 doubles, one per fixed contiguous slice of the frame:
  * { sum |flow|, hole pixels, max |flow|, max(-flow) } of d_flow_mix [H,W,2] f32 / d_fill_mask [H,W] u8 (empty slices: 0, 0,

@@ -196,13 +196,18 @@ struct MpfConsts {
 //     1 * d is d - same bits, 6 fewer VALU ops per plane.
 // TP: the stack is followed by >= (W+1) texels of finite padding, so the east / south taps can always be read at
 //     +16 / +row bytes (immediate offsets); where they fall outside the image their weight is exactly 0.
-template <bool KS, bool TP, bool WANT_VALID = true>
-MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts &c, MpfGeom &g)
+// The arithmetic of one plane for one target pixel: source coordinate, bilinear weights, north-west texel (x0, y0) and the
+// warped xyz_tgt at the clamped coordinate.  Shared by the gather kernels and the LDS-staged kernel (and by the latter's
+// tile-corner evaluation), so every variant performs the identical IEEE op sequence.
+template <bool KS, bool WANT_VALID, class ParamPtr>
+MPF_DEV float mpf_geom_core(const ParamPtr params, int s, const MpfConsts &c, float &nw, float &ne, float &sw, float &se,
+                            float &X, float &Y, float &Z, int &x0, int &y0, float &qz_out)
 {
-    const float *rec = params + MPF_PARAMS_HEADER + MPF_PLANE_RECORD * s;
+    const ParamPtr rec = params + MPF_PARAMS_HEADER + MPF_PLANE_RECORD * s;
     float qx = mpf_row3_xy1(rec[0], rec[1], rec[2], c.fx, c.fy);
     float qy = mpf_row3_xy1(rec[3], rec[4], rec[5], c.fx, c.fy);
     float qz = mpf_row3_xy1(rec[6], rec[7], rec[8], c.fx, c.fy);
+    qz_out = qz;
     const float rz = mpf_rcp_nr(qz);
     float u = mpf_div_nr(qx, qz, rz), v = mpf_div_nr(qy, qz, rz);
     float valid = 0.0f;
@@ -219,8 +224,31 @@ MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts 
     // ix >= 0: x - floor(x) is exact and equals v_fract_f32(x); trunc == floor
     float w = __builtin_amdgcn_fractf(ix), e = 1.0f - w;
     float n = __builtin_amdgcn_fractf(iy), sgt = 1.0f - n;
-    g.nw = sgt * e; g.ne = sgt * w; g.sw = n * e; g.se = n * w;
-    const int x0 = (int)ix, y0 = (int)iy;
+    nw = sgt * e; ne = sgt * w; sw = n * e; se = n * w;
+    x0 = (int)ix; y0 = (int)iy;
+    const float d = rec[9];
+    float rx, ry, rzz;
+    if (KS) {
+        rx = (params[0] * ix + params[2]) * d;
+        ry = (params[4] * iy + params[5]) * d;
+        rzz = d;
+    } else {
+        rx = mpf_row3_xy1(params[0], params[1], params[2], ix, iy) * d;
+        ry = mpf_row3_xy1(params[3], params[4], params[5], ix, iy) * d;
+        rzz = mpf_row3_xy1(params[6], params[7], params[8], ix, iy) * d;
+    }
+    X = mpf_row4_xyz1(params[9], params[10], params[11], params[12], rx, ry, rzz);
+    Y = mpf_row4_xyz1(params[13], params[14], params[15], params[16], rx, ry, rzz);
+    Z = mpf_row4_xyz1(params[17], params[18], params[19], params[20], rx, ry, rzz);
+    return valid;
+}
+
+template <bool KS, bool TP, bool WANT_VALID = true>
+MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts &c, MpfGeom &g)
+{
+    int x0, y0;
+    float qz;
+    const float valid = mpf_geom_core<KS, WANT_VALID>(params, s, c, g.nw, g.ne, g.sw, g.se, g.X, g.Y, g.Z, x0, y0, qz);
     const unsigned o00 = __umul24((unsigned)y0, (unsigned)c.W) + (unsigned)x0;   // H*W < 2^27, W < 2^24
     g.b00 = o00 * 16u;
     if (TP) {
@@ -234,20 +262,6 @@ MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts 
         g.b10 = g.b00 + dy;
         g.b11 = g.b10 + dx;
     }
-    const float d = rec[9];
-    float rx, ry, rzz;
-    if (KS) {
-        rx = (params[0] * ix + params[2]) * d;
-        ry = (params[4] * iy + params[5]) * d;
-        rzz = d;
-    } else {
-        rx = mpf_row3_xy1(params[0], params[1], params[2], ix, iy) * d;
-        ry = mpf_row3_xy1(params[3], params[4], params[5], ix, iy) * d;
-        rzz = mpf_row3_xy1(params[6], params[7], params[8], ix, iy) * d;
-    }
-    g.X = mpf_row4_xyz1(params[9], params[10], params[11], params[12], rx, ry, rzz);
-    g.Y = mpf_row4_xyz1(params[13], params[14], params[15], params[16], rx, ry, rzz);
-    g.Z = mpf_row4_xyz1(params[17], params[18], params[19], params[20], rx, ry, rzz);
     return valid;
 }
 
@@ -263,7 +277,8 @@ MPF_DEV void mpf_fetch2(const char *__restrict__ plane, const char *__restrict__
     if (HAS_MASK) r.mq = *reinterpret_cast<const float4 *>(quads + g.b00);
 }
 
-MPF_DEV float mpf_tap4w(const MpfGeom &g, float a, float b, float c, float d)
+template <class Geom>
+MPF_DEV float mpf_tap4w(const Geom &g, float a, float b, float c, float d)
 {
     float o = a * g.nw;
     o = fmaf(b, g.ne, o);
@@ -283,7 +298,8 @@ struct MpfAcc {
         cw.init(); cd.init(); co.init(); c0.init(); c1.init(); c2.init();
     }
     // composite plane s (geometry g, fetched taps r) given the distance to plane s+1
-    MPF_DEV void step(const MpfGeom &g, const MpfRaw4 &r, float dist, int s)
+    template <class Geom>
+    MPF_DEV void step(const Geom &g, const MpfRaw4 &r, float dist, int s)
     {
         float cr = mpf_tap4w(g, r.t00.x, r.t01.x, r.t10.x, r.t11.x);
         float cg = mpf_tap4w(g, r.t00.y, r.t01.y, r.t10.y, r.t11.y);
@@ -470,7 +486,248 @@ k_warp_composite_views(const float *__restrict__ rgba, const MpfViewSet vs, cons
                                              w.d_rgb_u8_bgr, tile);
 }
 
-static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = v2 shapes
+// ---------------------------------------------------------------------------------------------------------------
+// Stage B, LDS-staged variant ("source-pixel neighbourhoods through LDS", tail-padded interleaved stack, S <= 256)
+//
+// The gather kernels issue 4 x 16-byte gathers per pixel and plane; neighbouring pixels re-fetch each other's texels
+// through the L1 / texture-address path (TA busy ~55 %, 3.07e6 VMEM instructions per launch at 64x640x960).  Here a 32x8
+// target tile's source FOOTPRINT on plane s (a bounding box of at most 48 x 16 texels) is fetched once per workgroup with
+// fully coalesced 16-byte buffer loads (<= 3 per wave and plane, usually 2.25), parked in LDS (two 12 KB buffers,
+// ping-pong, one barrier per plane), and every pixel takes its four taps from there with ds_read_b128 at immediate
+// offsets.  Same arithmetic (mpf_geom_core, MpfAcc), bit-identical results.
+//   * the footprint boxes of all S planes are computed once per workgroup from the tile's 4 corner pixels (a homography
+//     maps the tile's extremes to its corners; +-1 texel of margin covers rounding), S*4 corner evaluations on 256 threads
+//   * a plane whose box does not fit (extreme poses) or whose denominator comes near 0 on the tile falls back to direct
+//     gathers for that plane - a workgroup-uniform branch, so correctness never depends on the pose
+//   * staging costs no VALU: a thread's global offset (row*W + col)*16 and LDS slot are loop invariants, the box origin
+//     goes into the buffer instruction's scalar offset, out-of-box lanes are fetched too (in range: the buffer descriptor
+//     clips at the end of the padded plane) and simply never read
+// ---------------------------------------------------------------------------------------------------------------
+#define MPF_LT_PITCH 48
+#define MPF_LT_ROWS 16
+#define MPF_LT_TEXELS (MPF_LT_PITCH * MPF_LT_ROWS)     // 768 texels = 12 KB per buffer = 3 passes of 256 threads
+#define MPF_LT_PASSES 3
+#define MPF_LT_MAXS 256
+
+struct MpfGeomL {
+    float nw, ne, sw, se;
+    float X, Y, Z;
+    unsigned t;          // y0 * MPF_LT_PITCH + x0 : position in LDS pitch units (box origin subtracted at use)
+    unsigned b00;        // (y0 * W + x0) * 16     : byte offset inside a plane (mask quads, direct fallback)
+};
+
+struct MpfBox {          // wave-uniform (SGPRs)
+    unsigned goff;       // (ymin * W + xmin) * 16 : byte offset of the box origin inside a plane
+    unsigned lorg;       // (ymin * MPF_LT_PITCH + xmin) * 16
+    unsigned h;          // rows staged; 0 = this plane is not staged (direct gathers)
+};
+
+typedef unsigned mpf_v4u __attribute__((ext_vector_type(4)));
+
+// d_params is read-only for the whole launch.  Behind a workgroup barrier hipcc no longer proves that for a plain global
+// pointer (the fence of __syncthreads() counts as a clobber), and the per-plane records turn into VECTOR loads issued right
+// before their use - measured: 3 extra VMEM instructions and a full memory latency per wave and plane.  Reading them
+// through the constant address space keeps them on the scalar unit.
+typedef const __attribute__((address_space(4))) float *MpfConstParams;
+
+template <bool KS, bool AUX>
+MPF_DEV float mpf_geom_l(MpfConstParams params, int s, const MpfConsts &c, MpfGeomL &g)
+{
+    int x0, y0;
+    float qz;
+    const float valid = mpf_geom_core<KS, AUX>(params, s, c, g.nw, g.ne, g.sw, g.se, g.X, g.Y, g.Z, x0, y0, qz);
+    g.t = __umul24((unsigned)y0, (unsigned)MPF_LT_PITCH) + (unsigned)x0;
+    g.b00 = (__umul24((unsigned)y0, (unsigned)c.W) + (unsigned)x0) * 16u;
+    return valid;
+}
+
+template <bool HAS_MASK, int NL, bool KS, bool AUX>
+MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
+                          int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                          float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out,
+                          const unsigned tile, float4 *s_tex, uint2 *s_box)
+{
+    constexpr int TW = 32, TH = 8;
+    const int64_t N = (int64_t)H * W;
+    const unsigned tiles_x = (W + TW - 1) / TW;
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const unsigned tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = tx0 + (int)(tid % TW);
+    const int y = ty0 + (int)(tid / TW);
+    const bool active = (x < W) && (y < H);
+    MpfConsts c;
+    c.fx = (float)min(x, W - 1); c.fy = (float)min(y, H - 1);
+    c.W = W; c.H = H; c.Wf = (float)W; c.Hf = (float)H;
+    c.halfW = (float)W * 0.5f; c.halfH = (float)H * 0.5f;
+    c.rhalfW = mpf_rcp_nr(c.halfW); c.rhalfH = mpf_rcp_nr(c.halfH);
+    c.maxx = (float)(W - 1); c.maxy = (float)(H - 1);
+    c.row_bytes = (unsigned)W * 16u;
+    const char *qbase = reinterpret_cast<const char *>(quads);
+    const char *pbase = reinterpret_cast<const char *>(rgba);
+    const size_t plane_bytes = (size_t)N * 16;
+    char *lds = reinterpret_cast<char *>(s_tex);
+
+    // ---- footprint boxes of this tile on every plane --------------------------------------------------------------
+    int unfit = 0;
+    {
+        const int xa = min(tx0, W - 1), xb = min(tx0 + TW - 1, W - 1);
+        const int ya = min(ty0, H - 1), yb = min(ty0 + TH - 1, H - 1);
+        for (unsigned e = tid; e < (unsigned)S * 4u; e += TW * TH) {
+            const unsigned sp = e >> 2, k = e & 3u;
+            MpfConsts cc = c;
+            cc.fx = (float)((k & 1u) ? xb : xa);
+            cc.fy = (float)((k & 2u) ? yb : ya);
+            float w0, w1, w2, w3, X, Y, Z, qz;
+            int cx, cy;
+            mpf_geom_core<KS, false>(params, (int)sp, cc, w0, w1, w2, w3, X, Y, Z, cx, cy, qz);
+            int xmn = cx, xmx = cx, ymn = cy, ymx = cy;
+            float zmn = qz;
+#pragma unroll
+            for (int m = 1; m <= 2; m <<= 1) {          // the 4 corners sit in 4 adjacent lanes
+                xmn = min(xmn, __shfl_xor(xmn, m)); xmx = max(xmx, __shfl_xor(xmx, m));
+                ymn = min(ymn, __shfl_xor(ymn, m)); ymx = max(ymx, __shfl_xor(ymx, m));
+                zmn = fminf(zmn, __shfl_xor(zmn, m));
+            }
+            xmn = max(xmn - 1, 0); xmx = min(xmx + 2, W);      // +1 east tap, +-1 margin; column W / row H = the padding
+            ymn = max(ymn - 1, 0); ymx = min(ymx + 2, H);
+            const int bw = xmx - xmn + 1, bh = ymx - ymn + 1;
+            const bool ok = (bw <= MPF_LT_PITCH) && (bh <= MPF_LT_ROWS) && (zmn > 0.0625f);
+            unfit |= ok ? 0 : 1;
+            if (k == 0)
+                s_box[sp] = make_uint2((unsigned)ymn * (unsigned)W + (unsigned)xmn, ((unsigned)ymn * MPF_LT_PITCH + (unsigned)xmn) | ((unsigned)bh << 24));
+        }
+    }
+    // a plane whose footprint does not fit the LDS tile (extreme pose), or a denominator near 0 on the tile: the whole
+    // workgroup takes the gather path for this tile (uniform; the barrier doubles as the one publishing s_box)
+    if (__syncthreads_or(unfit | ((H >= 65536) | (W >= 65536)))) {
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, KS, true, 0, AUX>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile);
+        return;
+    }
+
+    auto box = [&](int s) -> MpfBox {
+        const uint2 b = s_box[s];
+        const unsigned b0 = __builtin_amdgcn_readfirstlane(b.x), b1 = __builtin_amdgcn_readfirstlane(b.y);
+        MpfBox r;
+        r.goff = b0 * 16u;
+        r.lorg = (b1 & 0xFFFFFFu) * 16u;
+        r.h = b1 >> 24;
+        return r;
+    };
+    // a thread's staging slots: texel idx = tid + 256 k of the 48-pitch box raster
+    unsigned gconst[MPF_LT_PASSES];
+#pragma unroll
+    for (int k = 0; k < MPF_LT_PASSES; ++k) {
+        const unsigned idx = tid + (unsigned)(TW * TH) * k;
+        gconst[k] = ((idx / MPF_LT_PITCH) * (unsigned)W + (idx % MPF_LT_PITCH)) * 16u;
+    }
+    // one descriptor per plane: [plane base, +(N + W + 1) texels) - row H / column W of the last plane are the tail padding
+    const unsigned span = (unsigned)(N + W + 1) * 16u;
+    mpf_v4u L[MPF_LT_PASSES];
+    auto issue = [&](int s, const MpfBox &b) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(pbase + (size_t)s * plane_bytes), 0, span, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < MPF_LT_PASSES; ++k)
+            if ((unsigned)(TW * TH) * k + 64u * wave < MPF_LT_PITCH * b.h)
+                L[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, gconst[k], b.goff, 0);
+    };
+    auto stage = [&](const MpfBox &b, const unsigned buf) {
+#pragma unroll
+        for (int k = 0; k < MPF_LT_PASSES; ++k)
+            if ((unsigned)(TW * TH) * k + 64u * wave < MPF_LT_PITCH * b.h)
+                *reinterpret_cast<mpf_v4u *>(lds + buf * (MPF_LT_TEXELS * 16) + (tid + (unsigned)(TW * TH) * k) * 16u) = L[k];
+    };
+    auto taps = [&](const MpfBox &b, const MpfGeomL &g, const unsigned buf, MpfRaw4 &r) {
+        const char *a = lds + ((g.t << 4) + (buf * (MPF_LT_TEXELS * 16) - b.lorg));
+        r.t00 = *reinterpret_cast<const float4 *>(a);
+        r.t01 = *reinterpret_cast<const float4 *>(a + 16);
+        r.t10 = *reinterpret_cast<const float4 *>(a + MPF_LT_PITCH * 16);
+        r.t11 = *reinterpret_cast<const float4 *>(a + MPF_LT_PITCH * 16 + 16);
+    };
+
+    MpfConstParams cparams = (MpfConstParams)params;
+    MpfAcc<NL, HAS_MASK, AUX> A;
+    A.init();
+    MpfGeomL ga, gb;
+    MpfRaw4 ra, rb;                                      // t00..t11 are filled from LDS in the step that uses them; .mq (a global gather) one step ahead
+    MpfBox bA = box(0), bB = box(min(1, S - 1));
+    issue(0, bA);
+    stage(bA, 0u);
+    if (S > 1) issue(1, bB);
+    A.nvalid += mpf_geom_l<KS, AUX>(cparams, 0, c, ga);
+    if (HAS_MASK) ra.mq = *reinterpret_cast<const float4 *>(qbase + ga.b00);
+    __syncthreads();
+
+    // plane s: geometry G_, box B_, LDS buffer BUF_, taps R_; its successor: geometry GN_, box BN_, taps RN_, loads in flight in L;
+    // once they are parked in the other buffer, L takes the loads of plane s+2 (box BF_, read here)
+#define MPF_WCL_STEP(s_, G_, GN_, B_, BN_, BF_, BUF_, R_, RN_)                                                        \
+    {                                                                                                                 \
+        taps(B_, G_, BUF_, R_);                                                                                       \
+        A.nvalid += mpf_geom_l<KS, AUX>(cparams, (s_) + 1, c, GN_);                                                   \
+        if (HAS_MASK) RN_.mq = *reinterpret_cast<const float4 *>(qbase + GN_.b00);                                    \
+        const float dist_ = mpf_norm3_nr(GN_.X - G_.X, GN_.Y - G_.Y, GN_.Z - G_.Z);                                   \
+        A.step(G_, R_, dist_, (s_));                                                                                  \
+        stage(BN_, 1u - (BUF_));                                                                                      \
+        if ((s_) + 2 < S) { BF_ = box((s_) + 2); issue((s_) + 2, BF_); }                                              \
+        __syncthreads();                                                                                              \
+    }
+    int s = 0;
+    while (s + 2 < S) {
+        MPF_WCL_STEP(s, ga, gb, bA, bB, bA, 0u, ra, rb)            // plane s   (buffer 0): parks s+1 in buffer 1, fetches s+2
+        MPF_WCL_STEP(s + 1, gb, ga, bB, bA, bB, 1u, rb, ra)        // plane s+1 (buffer 1): parks s+2 in buffer 0, fetches s+3
+        s += 2;
+    }
+    if (s + 1 < S) {
+        MPF_WCL_STEP(s, ga, gb, bA, bB, bA, 0u, ra, rb)
+        taps(bB, gb, 1u, rb);
+        A.step(gb, rb, 1e3f, s + 1);
+    } else {
+        taps(bA, ga, 0u, ra);
+        A.step(ga, ra, 1e3f, s);
+    }
+#undef MPF_WCL_STEP
+    if (active) {
+        const int64_t n = (int64_t)y * W + x;
+        const float fr = A.c0.final(), fg = A.c1.final(), fb = A.c2.final();
+        rgb_out[n] = fr;
+        rgb_out[N + n] = fg;
+        rgb_out[2 * N + n] = fb;
+        if (u8_out) { u8_out[3 * n] = mpf_to_u8(fb); u8_out[3 * n + 1] = mpf_to_u8(fg); u8_out[3 * n + 2] = mpf_to_u8(fr); }
+        if (AUX && depth_out) depth_out[n] = A.cd.final() / (A.cw.final() + 1e-5f);
+        if (HAS_MASK) om_out[n] = A.co.final();
+        if (AUX && tgt_mask_out) tgt_mask_out[n] = A.nvalid;
+    }
+}
+
+template <bool HAS_MASK, int NL>
+__global__ void __launch_bounds__(256, 4)
+k_warp_composite_lds(const float *__restrict__ rgba, const MpfViewSet vs, const unsigned V, int S, int H, int W)
+{
+    const unsigned l = mpf_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned view = l % V, tile = l / V;
+    const MpfWarpView &w = vs.v[view];
+    const float *params = w.d_params;
+    const bool pinhole = (params[1] == 0.0f) & (params[3] == 0.0f) & (params[6] == 0.0f) & (params[7] == 0.0f) & (params[8] == 1.0f);
+    const bool aux = (w.d_depth != nullptr) | (w.d_tgt_mask != nullptr);
+    __shared__ float4 s_tex[2 * MPF_LT_TEXELS];      // one set for the three bodies below
+    __shared__ uint2 s_box[MPF_LT_MAXS];
+    if (pinhole && !aux)
+        mpf_wcl_body<HAS_MASK, NL, true, false>(rgba, w.d_mask_quads, params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask, w.d_rgb_u8_bgr, tile, s_tex, s_box);
+    else if (pinhole)
+        mpf_wcl_body<HAS_MASK, NL, true, true>(rgba, w.d_mask_quads, params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask, w.d_rgb_u8_bgr, tile, s_tex, s_box);
+    else
+        mpf_wcl_body<HAS_MASK, NL, false, true>(rgba, w.d_mask_quads, params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask, w.d_rgb_u8_bgr, tile, s_tex, s_box);
+}
+
+static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = gather shapes, 20 = LDS-staged footprints
+
+template <bool HAS_MASK>
+static int launch_lds(const float *rgba, const MpfViewSet &vs, int V, int S, int H, int W, hipStream_t st)
+{
+    const unsigned tiles = ((W + 31) / 32) * ((H + 7) / 8);
+    hipLaunchKernelGGL((k_warp_composite_lds<HAS_MASK, 2>), dim3(tiles * (unsigned)V), dim3(256), 0, st, rgba, vs, (unsigned)V, S, H, W);
+    return mpf_launch_status("k_warp_composite_lds");
+}
+
 
 template <bool HAS_MASK, int TW, int TH, int WPS>
 static int launch_wc2(bool tail_padded, const float *rgba, const float *quads, const float *params, int S, int H, int W, float *rgb,
@@ -534,6 +791,13 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
     MPF_REQUIRE(!interleaved || mpf_aligned16(d_rgba), "mpf_warp_composite: interleaved stack must be 16-byte aligned");
     MPF_REQUIRE(!d_mask_quads || mpf_aligned16(d_mask_quads), "mpf_warp_composite: mask quads must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (interleaved == 2 && g_stage_b_variant == 20 && S <= MPF_LT_MAXS && (int64_t)H * W < ((int64_t)1 << 27)) {
+        MpfViewSet vs;
+        memset(&vs, 0, sizeof(vs));
+        vs.v[0] = MpfWarpView{d_params, d_mask_quads, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr};
+        if (d_mask_quads) return launch_lds<true>(d_rgba, vs, 1, S, H, W, st);
+        return launch_lds<false>(d_rgba, vs, 1, S, H, W, st);
+    }
     if (interleaved && g_stage_b_variant > 0 && (int64_t)H * W < ((int64_t)1 << 27)) {
         const bool tp = (interleaved == 2);
         if (d_mask_quads) return dispatch_wc2<true>(g_stage_b_variant, tp, d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
@@ -579,6 +843,10 @@ extern "C" int mpf_warp_composite_views(const float *d_rgba, int interleaved, co
         MPF_REQUIRE((w.d_mask_quads == nullptr) == (w.d_objmask == nullptr), "mpf_warp_composite_views: view %d: mask quads and objmask output go together", v);
         MPF_REQUIRE(mpf_aligned16(w.d_mask_quads), "mpf_warp_composite_views: view %d: mask quads must be 16-byte aligned", v);
         vs.v[v] = w;
+    }
+    if (g_stage_b_variant == 20 && interleaved == 2 && S <= MPF_LT_MAXS) {
+        if (has_mask) return launch_lds<true>(d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
+        return launch_lds<false>(d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
     }
     if (has_mask) return launch_views<true>(interleaved == 2, d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
     return launch_views<false>(interleaved == 2, d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);

@@ -59,20 +59,8 @@ def moveing_object_with_mask(depth_path, disp, rgb, K, inv_K, instance_mask, i, 
     masks = ops.warp_masks(warped)                                               # :133-150
     im1_raw = warped[:, :, 0:3]
     hole = (1 - masks["H"]).to(torch.uint8)
-    method = inpaint
-    if method == "auto":
-        try:
-            import cv2  # noqa: F401
-            method = "cv2"
-        except Exception:
-            method = "hip"
-    if method == "cv2":                                                          # :162 (third-party, parity unpinned)
-        import cv2
-        im1 = torch.from_numpy(cv2.inpaint(im1_raw.contiguous().cpu().numpy(), hole.cpu().numpy(), 3, cv2.INPAINT_TELEA))
-    elif method == "hip":
-        im1 = ops.fill_holes(im1_raw.contiguous(), hole)
-    else:
-        im1 = im1_raw
+    from .utils.utils import _inpaint                                            # :162 cv2.inpaint(im1_raw, 1 - H, 3, INPAINT_TELEA)
+    im1 = torch.from_numpy(np.ascontiguousarray(_inpaint(im1_raw.contiguous(), hole, inpaint, algo="telea"))).to(dev)
     out = dict(p1=p1, z1=z1, safe_x=safe_x, safe_y=safe_y, flow_01=flow_01, warped=warped, masks=masks, im1_raw=im1_raw, im1=im1)
     if write_debug_png:
         import os

@@ -220,6 +220,26 @@ def fill_holes(img_HW3_u8, hole_HW_u8, out=None, hole_out=None, workspace=None):
     return out
 
 
+INPAINT_NS, INPAINT_TELEA = 0, 1          # cv2.INPAINT_NS / cv2.INPAINT_TELEA (MPF_INPAINT_*)
+
+
+def inpaint_host(img_u8, mask_u8, radius=3, method=INPAINT_NS, out=None):
+    """The reference's hole filling, cv2.inpaint(img, mask, radius, method) (utils/utils.py:284-286 NS, moving_obj.py:162 TELEA),
+    as restated in libmpiflow_hip.so (mpf_inpaint_host): HOST numpy arrays in and out, like the reference's call; synchronous;
+    ctypes releases the GIL, so frames fill in parallel on the generator's writer threads.  img u8 [H,W,3] | [H,W], mask u8 [H,W]."""
+    import numpy as np
+    lib = _lib.load()
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    H, W = img.shape[:2]
+    C = 1 if img.ndim == 2 else img.shape[2]
+    mask = np.ascontiguousarray(mask_u8, dtype=np.uint8).reshape(H, W)
+    if out is None:
+        out = np.empty_like(img)
+    assert out.shape == img.shape and out.dtype == np.uint8 and out.flags.c_contiguous and out is not img
+    _lib.check(lib.mpf_inpaint_host(img.ctypes.data, mask.ctypes.data, H, W, C, float(radius), int(method), out.ctypes.data), "mpf_inpaint_host")
+    return out
+
+
 PAIR_STATS_SLICES = 64          # MPF_PAIR_STATS_SLICES
 
 

@@ -57,21 +57,39 @@ def have_cv2():
         return False
 
 
-def _inpaint(frame_mix_dev, fill_mask_dev, method):
-    """Row A13.  'cv2' = the reference's own call (third-party; used when OpenCV is installed), 'hip' = built-in
-    onion-peel fill (documented deviation), 'none' = leave holes white."""
+INPAINT_METHODS = ("auto", "cv2", "builtin", "ns", "telea", "peel", "hip", "none")
+
+
+def resolve_inpaint(method):
+    """auto -> 'cv2' when OpenCV is installed (the reference's own call), else 'builtin' (the same algorithm, restated)"""
+    if method not in INPAINT_METHODS:
+        raise ValueError("inpaint must be one of %s" % (INPAINT_METHODS,))
     if method == "auto":
-        try:
-            import cv2  # noqa: F401
-            method = "cv2"
-        except Exception:
-            method = "hip"
+        return "cv2" if have_cv2() else "builtin"
+    return "peel" if method == "hip" else method
+
+
+def _inpaint(frame_dev, hole_dev, method, algo="ns"):
+    """Row A13.  `algo` is the algorithm of the reference line being replaced: 'ns' for
+    cv2.inpaint(frame_mix, fill_mask, 3, cv2.INPAINT_NS) (utils/utils.py:284-286), 'telea' for
+    cv2.inpaint(im1_raw, 1 - H, 3, cv2.INPAINT_TELEA) (moving_obj.py:162).  `method`:
+      'cv2'      the reference's own call (third-party; needs OpenCV)
+      'builtin'  that algorithm as restated in libmpiflow_hip.so (mpf_inpaint_host; on the host, like the reference's call);
+                 'ns' / 'telea' force one of the two
+      'peel' (alias 'hip')  the onion-peel GPU kernel - NOT OpenCV's algorithm, an explicit opt-in only
+      'none'     leave the holes as they are."""
+    method = resolve_inpaint(method)
+    if method in ("ns", "telea"):
+        method, algo = "builtin", method
     if method == "cv2":
         import cv2
-        return cv2.inpaint(frame_mix_dev.cpu().numpy(), fill_mask_dev.cpu().numpy().astype(np.uint8), 3, cv2.INPAINT_NS)
-    if method == "hip":
-        return ops.fill_holes(frame_mix_dev, fill_mask_dev).cpu().numpy()
-    return frame_mix_dev.cpu().numpy()
+        return cv2.inpaint(frame_dev.cpu().numpy(), hole_dev.cpu().numpy().astype(np.uint8), 3,
+                           cv2.INPAINT_TELEA if algo == "telea" else cv2.INPAINT_NS)
+    if method == "builtin":
+        return ops.inpaint_host(frame_dev.cpu().numpy(), hole_dev.cpu().numpy(), 3, ops.INPAINT_TELEA if algo == "telea" else ops.INPAINT_NS)
+    if method == "peel":
+        return ops.fill_holes(frame_dev, hole_dev).cpu().numpy()
+    return frame_dev.cpu().numpy()
 
 
 def render_3dphoto_dynamic(opt, src_imgs, obj_mask, disp, mpi_all_src, disparity_all_src, k_src, k_tgt, data_path=None,

@@ -27,7 +27,7 @@ _f32p = ctypes.c_void_p
 def build(force=False):
     """gcc-compile liboracle.so (and oracle/_ref when the reference tree is present)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_math.c", "oracle_mpi.c", "oracle_fwarp.c", "oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_math.c", "oracle_mpi.c", "oracle_fwarp.c", "oracle_inpaint.c", "oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, capture_output=True)
@@ -389,3 +389,31 @@ def moving_object(disp_HW, rgb_HW3_u8, K33, inv_K33, inst_HW, T_obj_44):
     p1, z1, sx, sy, fl = select_truncate(ps, zs, po, zo, inst_HW)
     warped = forward_warping(_c(rgb_HW3_u8, np.uint8), sx, sy, z1, H, W)
     return dict(p1=p1, z1=z1, safe_x=sx, safe_y=sy, flow01=fl, warped=warped, masks=warp_masks(warped))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# cv2.inpaint / cv2.dilate restated (oracle_inpaint.c) - PARITY UNPINNED: third-party OpenCV, not installed here
+# --------------------------------------------------------------------------------------------------------------
+
+INPAINT_NS, INPAINT_TELEA = 0, 1
+
+
+def inpaint(img_u8, mask_u8, radius, method):
+    """cv2.inpaint(img, mask, radius, method) for u8 [H,W,3] / [H,W,1] / [H,W] images (utils/utils.py:284-286, moving_obj.py:162)"""
+    img = _c(img_u8, np.uint8)
+    H, W = img.shape[:2]
+    C = 1 if img.ndim == 2 else img.shape[2]
+    mask = _c(mask_u8, np.uint8).reshape(H, W)
+    out = np.empty_like(img)
+    rc = lib().orc_inpaint(_p(img), _p(mask), H, W, C, ctypes.c_double(radius), int(method), _p(out))
+    if rc != 0:
+        raise MemoryError("orc_inpaint")
+    return out
+
+
+def dilate3x3(img_u8):
+    img = _c(img_u8, np.uint8)
+    H, W = img.shape
+    out = np.empty_like(img)
+    lib().orc_dilate3x3(_p(img), H, W, _p(out))
+    return out

@@ -104,6 +104,13 @@ void orc_select_truncate(const float *p_static, const float *z_static, const flo
 void orc_warp_masks(const uint8_t *warped, int H, int W, uint8_t *Hm, uint8_t *M, uint8_t *Md, uint8_t *P,
                     uint8_t *Hp);
 
+/* ---- oracle_inpaint.c : cv2.inpaint (NS / Telea) and cv2.dilate(3x3) restated - PARITY UNPINNED (third-party OpenCV) --- */
+/* img u8 [rows,cols,C] (C = 1 or 3), mask u8 [rows,cols] (non-zero = fill), method 0 = INPAINT_NS, 1 = INPAINT_TELEA
+ * (reference: utils/utils.py:284-286, moving_obj.py:162).  Returns 0, -1 on allocation failure. */
+int orc_inpaint(const uint8_t *img, const uint8_t *mask, int rows, int cols, int C, double radius, int method, uint8_t *out);
+/* cv2.dilate(img, ones(3,3)) on one u8 channel (moving_obj.py:144-145) */
+void orc_dilate3x3(const uint8_t *img, int rows, int cols, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,163 @@
+"""Row A13 / N2: the reference's hole filling = OpenCV's cv2.inpaint (INPAINT_NS at utils/utils.py:284-286, INPAINT_TELEA at
+moving_obj.py:162) and cv2.dilate 3x3 (moving_obj.py:144-145).
+
+OpenCV is third-party and not installed in the build image, so parity with cv2 itself is UNPINNED; what these tests hold:
+  * the product's host implementation (mpf_inpaint_host in libmpiflow_hip.so - heap-ordered, restructured) equals the
+    independent plain-C restatement in oracle/ (linked-list queue, OpenCV's loop structure) byte for byte on random and
+    structured inputs, both methods, several radii, 1 and 3 channels, degenerate shapes;
+  * hand-checkable properties of the algorithm (known pixels untouched; NS of a constant image is that constant; Telea's
+    documented +0.5-then-round bias; a single-pixel hole equals the closed-form weighted mean; fill order = fast-marching
+    arrival order with FIFO ties);
+  * and - the pin - equality with the REAL cv2.inpaint / cv2.dilate whenever `import cv2` works (skipped otherwise).
+None of this needs a GPU: the reference does this step on the host, and so does the product."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+
+@pytest.fixture(scope="module")
+def prod():
+    import __graft_entry__ as ge
+    ge.build()
+    from mpiflow_amd import ops
+    return ops
+
+
+def _cases():
+    rs = np.random.RandomState(5)
+    out = []
+    for (H, W, C, frac) in [(40, 56, 3, 0.1), (64, 64, 3, 0.3), (33, 47, 1, 0.2), (2, 2, 3, 0.5), (1, 9, 3, 0.3), (9, 1, 1, 0.3),
+                            (3, 3, 3, 0.9), (96, 160, 3, 0.05)]:
+        img = (rs.rand(H, W, C) * 256).astype(np.uint8) if C > 1 else (rs.rand(H, W) * 256).astype(np.uint8)
+        mask = (rs.rand(H, W) < frac).astype(np.uint8)
+        if H > 8 and W > 8:
+            mask[H // 3: H // 2, W // 4: W // 2] = 1          # a solid hole many fronts deep
+            mask[0, :] = 1                                     # holes on the image border (OpenCV's km/kp/lm/lp index shifts)
+            mask[:, W - 1] = 1
+        out.append((img, mask))
+    yy, xx = np.mgrid[0:80, 0:120]
+    smooth = np.stack([xx * 2.0, yy * 3.0, 0.5 * (xx + yy) + 40], -1).clip(0, 255).astype(np.uint8)
+    m = np.zeros((80, 120), np.uint8)
+    m[20:50, 30:90] = 1
+    out.append((smooth, m))
+    return out
+
+
+@pytest.mark.parametrize("method", [0, 1])
+@pytest.mark.parametrize("radius", [3, 1, 5.4])
+def test_product_equals_oracle(prod, oracle, method, radius):
+    for img, mask in _cases():
+        want = oracle.inpaint(img, mask, radius, method)
+        got = prod.inpaint_host(img, mask, radius, method)
+        assert bits_equal(got, want) == 0, (img.shape, method, radius)
+        assert (got[mask == 0] == img[mask == 0]).all(), "known pixels must not change"
+
+
+def test_properties(prod, oracle):
+    H, W = 48, 64
+    mask = np.zeros((H, W), np.uint8)
+    mask[10:30, 20:44] = 1
+    const = np.full((H, W, 3), 77, np.uint8)
+    holed = const.copy()
+    holed[mask > 0] = 0
+    ns = prod.inpaint_host(holed, mask, 3, prod.INPAINT_NS)
+    assert (ns == 77).all()                                  # a weighted mean of equal values
+    te = prod.inpaint_host(holed, mask, 3, prod.INPAINT_TELEA)
+    assert (te[mask == 0] == 77).all() and abs(int(te[mask > 0].min()) - 77) <= 3 and abs(int(te[mask > 0].max()) - 77) <= 3
+    first = te[10, 20]                                       # first ring: zero image gradient -> 77 + 0.5, cvRound (to even) -> 78
+    assert (first == 78).all()
+    # empty mask: a copy; full mask: nothing known, nothing can be propagated, the input comes back (as OpenCV: empty band)
+    assert bits_equal(prod.inpaint_host(holed, np.zeros_like(mask), 3, 0), holed) == 0
+    assert bits_equal(prod.inpaint_host(holed, np.ones_like(mask), 3, 0), holed) == 0
+    # one missing pixel, NS: the closed form sum(w * I) / sum(w), w = dir / (|r|^4 + 1), evaluated here independently
+    rs = np.random.RandomState(2)
+    img = (rs.rand(H, W, 3) * 256).astype(np.uint8)
+    one = np.zeros((H, W), np.uint8)
+    one[20, 30] = 1
+    src = img.copy()
+    src[20, 30] = 0
+    got = prod.inpaint_host(src, one, 3, prod.INPAINT_NS)[20, 30]
+    I = src.astype(np.int32)
+    for c in range(3):
+        Ia, s = np.float32(0), np.float32(1e-20)
+        for k in range(20 - 3, 20 + 4):
+            for l in range(30 - 3, 30 + 4):
+                if (k, l) == (20, 30) or (k - 20) ** 2 + (l - 30) ** 2 > 9:
+                    continue
+                ry, rx = np.float32(k - 20), np.float32(l - 30)
+                def known(a, b):
+                    return (a, b) != (20, 30)
+                if known(k + 1, l):
+                    gx = np.float32(abs(I[k + 1, l, c] - I[k, l, c]) + abs(I[k, l, c] - I[k - 1, l, c])) if known(k - 1, l) else np.float32(abs(I[k + 1, l, c] - I[k, l, c])) * np.float32(2)
+                else:
+                    gx = np.float32(abs(I[k, l, c] - I[k - 1, l, c])) * np.float32(2)
+                if known(k, l + 1):
+                    gy = np.float32(abs(I[k, l + 1, c] - I[k, l, c]) + abs(I[k, l, c] - I[k, l - 1, c])) if known(k, l - 1) else np.float32(abs(I[k, l + 1, c] - I[k, l, c])) * np.float32(2)
+                else:
+                    gy = np.float32(abs(I[k, l, c] - I[k, l - 1, c])) * np.float32(2)
+                gx = -gx
+                r2 = rx * rx + ry * ry
+                dst = np.float32(1) / (r2 * r2 + np.float32(1))
+                d = rx * gx + ry * gy
+                if abs(d) <= 0.01:
+                    d = np.float32(0.000001)
+                else:
+                    d = np.float32(abs(d / np.sqrt(r2 * (gx * gx + gy * gy), dtype=np.float32)))
+                w = np.float32(dst * d)
+                Ia = np.float32(Ia + w * np.float32(I[k, l, c]))
+                s = np.float32(s + w)
+        want = int(np.clip(np.rint(np.float64(Ia) / np.float64(s)), 0, 255))
+        assert int(got[c]) == want
+
+
+def test_fill_order_is_arrival_time_with_fifo_ties(oracle):
+    """A 1-pixel-wide horizontal slit: every hole pixel is first reached from above (the band is seeded in raster order and
+    equal arrival times pop first-in-first-out), so each takes the mean pattern of its upper/lower neighbours and never
+    depends on a slit pixel to its right - changing a pixel right of x cannot change the fill left of x - 3."""
+    H, W = 9, 40
+    rs = np.random.RandomState(9)
+    img = (rs.rand(H, W, 3) * 256).astype(np.uint8)
+    mask = np.zeros((H, W), np.uint8)
+    mask[4, 5:35] = 1
+    a = oracle.inpaint(img, mask, 3, 0)
+    img2 = img.copy()
+    img2[:, 30:] = 255 - img2[:, 30:]
+    b = oracle.inpaint(img2, mask, 3, 0)
+    assert (a[4, 5:26] == b[4, 5:26]).all()
+
+
+def test_dilate3x3_vs_scipy(oracle):
+    from scipy.ndimage import grey_dilation
+    rs = np.random.RandomState(1)
+    m = (rs.rand(37, 53) < 0.1).astype(np.uint8)
+    assert bits_equal(oracle.dilate3x3(m), grey_dilation(m, footprint=np.ones((3, 3), bool), mode="constant", cval=0).astype(np.uint8)) == 0
+
+
+# ---- the pin: real OpenCV, whenever it is there ---------------------------------------------------------------------------
+
+def _cv2():
+    try:
+        import cv2
+        return cv2
+    except Exception:
+        pytest.skip("OpenCV (cv2) is not installed here: parity of rows A13 / N2 with cv2 itself stays unpinned")
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_against_real_cv2_inpaint(prod, oracle, method):
+    cv2 = _cv2()
+    flag = cv2.INPAINT_TELEA if method == 1 else cv2.INPAINT_NS
+    for img, mask in _cases():
+        if img.shape[0] < 3 or img.shape[1] < 3:
+            continue                                         # OpenCV reads out of bounds on 1- and 2-pixel-wide images
+        want = cv2.inpaint(img, mask, 3, flag)
+        assert bits_equal(oracle.inpaint(img, mask, 3, method), want) == 0
+        assert bits_equal(prod.inpaint_host(img, mask, 3, method), want) == 0
+
+
+def test_against_real_cv2_dilate(oracle):
+    cv2 = _cv2()
+    rs = np.random.RandomState(1)
+    m = (rs.rand(37, 53) < 0.1).astype(np.uint8)
+    assert bits_equal(oracle.dilate3x3(m), cv2.dilate(m, np.ones((3, 3)))) == 0

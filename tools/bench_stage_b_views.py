@@ -24,11 +24,10 @@ p.add_argument("--width", type=int, default=960)
 p.add_argument("--rounds", type=int, default=5)
 p.add_argument("--launches", type=int, default=10)
 p.add_argument("--images", type=int, default=3)
-p.add_argument("--variant", type=int, default=1, help="mpf_tune stage_b variant for both forms")
+p.add_argument("--variants", type=str, default="1,20", help="mpf_tune stage_b variants (1 = gather kernel, 20 = LDS-staged kernel)")
 a = p.parse_args()
 
 lib = _lib.load()
-_lib.check(lib.mpf_tune(b"stage_b", a.variant))
 dev = torch.device("cuda:0")
 S, H, W = a.planes, a.height, a.width
 g = torch.Generator(device=dev).manual_seed(0)
@@ -78,10 +77,13 @@ def timed(fn, V):
 alg = 16.0 * S * H * W
 res = {}
 print("Stage B, %dx%dx%d, V views of one stack: V launches vs one launch (us per VIEW, median of %d rounds x %d)" % (S, H, W, a.rounds, a.launches))
-for V in [int(v) for v in a.views.split(",")]:
-    separate(V, stacks[0])
-    torch.cuda.synchronize()
-    want = [{k: t.clone() for k, t in v["out"].items()} for v in views[:V]]
+_lib.check(lib.mpf_tune(b"stage_b", 1))
+separate(VMAX, stacks[0])
+torch.cuda.synchronize()
+want_all = [{k: t.clone() for k, t in v["out"].items()} for v in views[:VMAX]]       # variant 1, one launch per view = the pinned kernel
+for variant, V in [(int(x), int(v)) for x in a.variants.split(",") for v in a.views.split(",")]:
+    _lib.check(lib.mpf_tune(b"stage_b", variant))
+    want = want_all[:V]
     for v in views[:V]:
         for t in v["out"].values():
             t.zero_()
@@ -93,7 +95,7 @@ for V in [int(v) for v in a.views.split(",")]:
         ts.append(timed(separate, V))
         tt.append(timed(together, V))
     ms, mt = float(np.median(ts)) / V, float(np.median(tt)) / V
-    res[V] = dict(separate_us_per_view=ms, one_launch_us_per_view=mt, bit_identical=bool(same))
-    print("V=%2d  bit-identical=%s   separate %7.1f us/view (frac %.3f)   one launch %7.1f us/view (frac %.3f)   x%.2f" % (
-        V, same, ms, alg / ms / 1e6 / 8.0, mt, alg / mt / 1e6 / 8.0, ms / mt), flush=True)
+    res["v%d_V%d" % (variant, V)] = dict(separate_us_per_view=ms, one_launch_us_per_view=mt, bit_identical=bool(same))
+    print("variant %2d V=%2d  bit-identical=%s   separate %7.1f us/view (frac %.3f)   one launch %7.1f us/view (frac %.3f)   x%.2f" % (
+        variant, V, same, ms, alg / ms / 1e6 / 8.0, mt, alg / mt / 1e6 / 8.0, ms / mt), flush=True)
 print(json.dumps(res))

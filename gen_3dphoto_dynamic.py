@@ -16,15 +16,24 @@ What is different:
     reference's checkpoints: `--ckpt_path adampi_64p.pth`, or `--ckpt_path random:SEED` for deterministic random weights -
     the published weights are not in the reference tree); its raw last-layer output is handed to Stage A+C, which applies
     the activation epilogue in registers.  `--mpi-from npz` reads precomputed stacks from base/mpis/NAME.npz (arrays `mpi`
-    [S,4,H,W], `disparity` [S]); `--mpi-from disparity` (default) builds a hard-assignment MPI from the monocular disparity
-    map: every plane carries the image colours, the plane nearest to the pixel's disparity is opaque.  All three feed the
-    identical render path.
+    [S,4,H,W], `disparity` [S]); `--mpi-from disparity` builds a hard-assignment stand-in MPI from the monocular disparity
+    map (every plane carries the image colours, the plane nearest to the pixel's disparity is opaque) - for smoke runs only.
+    All three feed the identical render path.  The default is `model`, as in the reference; a missing checkpoint is an error.
+  * an image that cannot be processed (undecodable file, mask without instances - where the reference dies with
+    np.random.randint(0) -, a render error) is skipped and listed in out/skipped.txt instead of ending the batch; `--resume`
+    skips images whose outputs already exist.  Neither changes the poses / instance ids any other image gets.
+  * hole filling: cv2.inpaint when OpenCV is installed, else the same algorithm restated in libmpiflow_hip.so (host, on the
+    writer threads, overlapped with the GPU).
 """
 import argparse
 import os
 import random
 import sys
 import time
+
+# dmabuf IPC (the only mode this node pool's driver supports) for RCCL's peer-memory exchange between the per-GPU processes;
+# already exported by the launch environment, set here for a bare `torchrun gen_3dphoto_dynamic.py`
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -42,20 +51,28 @@ def parse(argv=None):
     p.add_argument("--height", type=int, default=384)
     p.add_argument("--seed", type=int, default=114514)
     p.add_argument("--ext_cz", type=float, default=0.15)
-    p.add_argument("--ckpt_path", type=str, default="adampiweight/adampi_64p.pth", help="accepted for CLI parity; unused")
+    p.add_argument("--ckpt_path", type=str, default="adampiweight/adampi_64p.pth",
+                   help="AdaMPI checkpoint {'num_planes', 'weight'} as the reference loads it (gen_3dphoto_dynamic_v2.py:52-58), or "
+                        "random:SEED for deterministic random weights (the published weights are not redistributable here)")
     p.add_argument("--repeat", type=int, default=5)
     p.add_argument("--base", type=str, required=True)
     p.add_argument("--out", type=str, required=True)
     p.add_argument("--poses", choices=["v2", "coco", "copy"], default="v2",
                    help="pose sampler constants: utils/utils.py (gen_3dphoto_dynamic_v2.py), utils/utils_coco.py or 'utils/utils copy.py'")
-    p.add_argument("--planes", type=int, default=64)
-    p.add_argument("--mpi-from", choices=["disparity", "npz", "model"], default="disparity")
+    p.add_argument("--planes", type=int, default=64, help="plane count for --mpi-from disparity / random weights (a checkpoint carries its own)")
+    p.add_argument("--mpi-from", choices=["model", "npz", "disparity"], default="model",
+                   help="model: the AdaMPI network from --ckpt_path, as the reference always does; npz: precomputed stacks base/mpis/NAME.npz; "
+                        "disparity: a hard-assignment stand-in built from the disparity map (NOT the reference's producer - for smoke runs)")
     p.add_argument("--model-dtype", choices=["fp32", "fp16", "bf16"], default="fp32", help="autocast dtype of the network's convolutions")
     p.add_argument("--model-engine", choices=["torch", "hip"], default="torch",
                    help="torch: every convolution on PyTorch/MIOpen (fp32 = the reference's CPU numerics); hip: the per-plane networks on "
                         "the MFMA convolution engine (fp16 storage, fp32 accumulate - the reference's GPU precision), one hipGraph per image")
-    p.add_argument("--inpaint", choices=["auto", "cv2", "hip", "none"], default="auto")
-    p.add_argument("--writers", type=int, default=8, help="writer threads (PNG encode + file I/O overlap the GPU); 0 = synchronous")
+    p.add_argument("--inpaint", choices=list(U.INPAINT_METHODS), default="auto",
+                   help="hole filling of the rendered frame (reference: cv2.inpaint NS radius 3).  auto = cv2 when OpenCV is installed, else "
+                        "builtin = the same algorithm restated in libmpiflow_hip.so, run on the writer threads; peel (alias hip) = the onion-peel "
+                        "GPU kernel, NOT OpenCV's algorithm; none = leave holes white")
+    p.add_argument("--resume", action="store_true", help="skip images whose outputs (all --repeat pairs) already exist; the RNG schedule is unaffected")
+    p.add_argument("--writers", type=int, default=8, help="writer threads (hole fill, PNG encode and file I/O overlap the GPU)")
     p.add_argument("--lanes", type=int, default=1,
                    help="images in flight on this GPU, each with its own streams, plane-stack buffer and network graph (same files for any "
                         "value).  Measured on MI355X: 1 lane 359 pairs/s, 2 lanes 267, 3 lanes 298 - the kernels are sized to fill the GPU on "
@@ -75,6 +92,16 @@ def mpi_from_disparity(image_3HW, disp_HW, S):
     return mpi, planes
 
 
+def outputs_exist(out, name, repeat):
+    """--resume: all three files of every pair of an image are there and non-empty"""
+    for r in range(repeat):
+        for sub, ext in (("flows", "flo"), ("dst_images", "png"), ("src_images", "png")):
+            p = os.path.join(out, sub, "%s_%d.%s" % (name, r, ext))
+            if not os.path.exists(p) or os.path.getsize(p) == 0:
+                return False
+    return True
+
+
 def main(argv=None):
     opt = parse(argv)
     print(opt)
@@ -83,7 +110,8 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # test hooks (multi-process path on a 1-GPU box): MPIFLOW_DIST_BACKEND=gloo, MPIFLOW_FORCE_DEVICE=0
     backend = os.environ.get("MPIFLOW_DIST_BACKEND", "nccl")
-    if "MPIFLOW_FORCE_DEVICE" in os.environ:
+    forced = "MPIFLOW_FORCE_DEVICE" in os.environ
+    if forced:
         local = int(os.environ["MPIFLOW_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -92,6 +120,8 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)        # RCCL over xGMI
+            if not forced:
+                pipeline.assert_distinct_devices(local)                   # one process per GPU, checked before the first collective
         else:
             dist.init_process_group(backend=backend)
 
@@ -112,32 +142,58 @@ def main(argv=None):
 
     img_base, disp_base, mask_base = (os.path.join(opt.base, d) for d in ("images", "disps", "masks"))
     names = sorted(os.listdir(img_base))
-    model = hip_model = None
+    model = None
     amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype)
-    if opt.mpi_from == "model":
+    if opt.mpi_from == "model":                                            # the reference's only producer (:52-60, :92-93)
         from mpiflow_amd.model import MPIPredictor
         if opt.ckpt_path.startswith("random:"):
             model = MPIPredictor(opt.width, opt.height, opt.planes).randomize_(int(opt.ckpt_path.split(":")[1])).eval().to(dev)
         else:
-            model = MPIPredictor.from_checkpoint(opt.ckpt_path, opt.width, opt.height).to(dev)      # :52-60
+            if not os.path.exists(opt.ckpt_path):
+                raise SystemExit("gen_3dphoto_dynamic: checkpoint %r not found.  The reference always runs the AdaMPI network from --ckpt_path "
+                                 "(gen_3dphoto_dynamic_v2.py:52-60); pass the checkpoint, or --ckpt_path random:SEED, or choose another "
+                                 "producer explicitly with --mpi-from npz|disparity." % opt.ckpt_path)
+            model = MPIPredictor.from_checkpoint(opt.ckpt_path, opt.width, opt.height).to(dev)
             opt.planes = model.num_planes
+    elif opt.mpi_from == "disparity" and rank == 0:
+        print("WARNING: --mpi-from disparity is a stand-in producer (hard depth assignment), not the reference's AdaMPI network", file=sys.stderr)
     use_hip_model = model is not None and opt.model_engine == "hip"
+    fill_mode = U.resolve_inpaint(opt.inpaint)
+    if fill_mode in ("ns", "telea"):
+        fill_mode, fill_algo = "builtin", fill_mode
+    else:
+        fill_algo = "ns"                                                   # utils/utils.py:284-286
+    if fill_mode == "cv2":
+        import cv2
+
+        def host_fill(frame, hole):
+            return cv2.inpaint(frame, hole, 3, cv2.INPAINT_TELEA if fill_algo == "telea" else cv2.INPAINT_NS)
+    elif fill_mode == "builtin":
+        def host_fill(frame, hole):
+            return ops.inpaint_host(frame, hole, 3, ops.INPAINT_TELEA if fill_algo == "telea" else ops.INPAINT_NS)
+    else:
+        host_fill = None
 
     class Lane:
-        """Everything one in-flight image owns: its streams, the blended plane stack, the network graph and its static buffers."""
+        """Everything one in-flight image owns: its streams, the blended plane stack, the network graph and its static buffers.
+        Built ON the lane's stream, so that the zero-fill of the stack and the packed weights are ordered before its first use."""
 
         def __init__(self):
             self.stream, self.tail_stream, self.tail_ready = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Event()
-            self.renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
-            self.fill_ws = torch.empty(int(_lib.load().mpf_fill_holes_workspace(opt.height, opt.width)), dtype=torch.uint8, device=dev)
-            self.hip_model = None
-            if use_hip_model:
-                from mpiflow_amd.model.engine import HipPredictor
-                self.hip_model = HipPredictor(model, encoder_dtype=amp, graph=True)
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self.stream):
+                self.renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
+                self.fill_ws = torch.empty(int(_lib.load().mpf_fill_holes_workspace(opt.height, opt.width)), dtype=torch.uint8, device=dev)
+                self.inputs = dict(image=torch.empty((3, opt.height, opt.width), device=dev), disp=torch.empty((opt.height, opt.width), device=dev))
+                self.hip_model = None
+                if use_hip_model:
+                    from mpiflow_amd.model.engine import HipPredictor
+                    self.hip_model = HipPredictor(model, encoder_dtype=amp, graph=True)
+            self.tail_stream.wait_stream(self.stream)
 
     lanes = [Lane() for _ in range(max(1, opt.lanes))]
     dstats = pipeline.DeviceStats(dev)
-    ring = io_formats.OutputRing(opt.height, opt.width, dev, slots=max(4, 2 * max(opt.writers, 1)), threads=max(opt.writers, 1))
+    ring = io_formats.OutputRing(opt.height, opt.width, dev, slots=max(4, 2 * max(opt.writers, 1)), threads=max(opt.writers, 1), host_fill=host_fill)
     t_start = time.perf_counter()
     prof = {}
 
@@ -156,86 +212,59 @@ def main(argv=None):
                     torch.cuda.synchronize()
                 prof[self.key] = prof.get(self.key, 0.0) + time.perf_counter() - self.t
 
-    import torch.nn.functional as F
-    inputs = io_formats.InputPrefetcher(names, img_base, disp_base, mask_base, owned=lambda i: (i % world) == rank, pin=True)
+    # mask.max() of every image (the instance-id draws need it): decoded once on rank 0 and broadcast; single rank: read off the
+    # masks as they are decoded
+    table = pipeline.mask_max_table(names, mask_base, rank, world)
+    owned = [i for i in range(len(names)) if (i % world) == rank]
+    done_before = set(i for i in owned if opt.resume and outputs_exist(out, names[i].split(".")[0], opt.repeat))
+    inputs = iter(io_formats.InputPrefetcher(names, img_base, disp_base, mask_base, [i for i in owned if i not in done_before]))
+    skipped, n_resumed = [], 0                       # (image name, reason) of the images this rank owned and could not render
     n_pairs, t_first, n_first, n_owned = 0, None, 0, 0
-    it = iter(inputs)
-    while True:
-        with lap("wait for decoded inputs"):
-            item = next(it, None)
-        if item is None:
-            break
-        i, img, mask_max, ids_host, image_host, disp_host = item
+    for i, img in enumerate(names):
         name = img.split(".")[0]
-        mine = image_host is not None
-        lane = lanes[n_owned % len(lanes)]
-        n_owned += int(mine)
-        renderer, hip_model, tail_stream, tail_ready, fill_ws = lane.renderer, lane.hip_model, lane.tail_stream, lane.tail_ready, lane.fill_ws
-        lane_ctx = torch.cuda.stream(lane.stream)
-        lane_ctx.__enter__()                                      # everything this image enqueues goes to its lane's stream
-        if mine:
-            with lap("upload + resize image, disparity, mask"):
-                image = image_host.to(dev, non_blocking=True)[None]
-                disp = disp_host.to(dev, non_blocking=True)[None]
-                ids = ids_host.to(dev, non_blocking=True)
-                image = F.interpolate(image, size=(opt.height, opt.width), mode="bilinear", align_corners=True)   # :86-89
-                disp = F.interpolate(disp, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
-            cum_mask = None
-            with lap("MPI producer + blend"):
-                if opt.mpi_from == "npz":
-                    z = np.load(os.path.join(opt.base, "mpis", name + ".npz"))
-                    mpi, planes = torch.from_numpy(z["mpi"]).to(dev), torch.from_numpy(z["disparity"]).to(dev)
-                elif hip_model is not None:
-                    mpi, cum_mask, planes = hip_model(image, disp)             # static buffers: consumed by blend() below
-                elif model is not None:
-                    with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):      # :92-93
-                        raw, cm, pd = model(image, disp, raw=True)
-                    mpi, cum_mask, planes = raw[0].float().contiguous(), cm[0].float().contiguous(), pd[0].float()
-                else:
-                    mpi, planes = mpi_from_disparity(image[0], disp[0, 0], opt.planes)
-                renderer.blend(mpi, image[0], K, planes, cum_mask=cum_mask)      # once per image; the `repeat` pairs below reuse it
-                ring.submit_source(ops.png_scanlines(renderer.src_u8), [os.path.join(out, "src_images", f"{name}_{r}.png") for r in range(opt.repeat)])  # :122
-        # every rank draws for every pair, so the stream position is identical to a single-process run.  The reference interleaves
-        # an np.random draw (instance id, :101) with 24 `random` draws (two poses, utils.py:207-208) per pair; the two generators
-        # are independent, so the image's draws are taken in that order here and its 2 x repeat poses built in one batched call
+        mine = (i % world) == rank
+        item = None
+        if mine and i not in done_before:
+            with lap("wait for decoded inputs"):
+                item = next(inputs)
+            assert item["i"] == i
+        # ---- the draws of this image, on every rank (RNG schedule contract: an image consumes its 2 x repeat pose draws and its
+        #      `repeat` instance-id draws iff its mask decodes and holds at least one instance - the reference dies on such an image,
+        #      np.random.randint(0) at :101, before drawing anything.  Nothing else about an image - a broken picture, a render error,
+        #      --resume - changes what the other images get.)
+        if table is not None:
+            mask_max = table[i]
+        elif item is not None and item["error"] is None:
+            mask_max = int(item["ids_u8"].max())
+        else:                                                              # single rank, image resumed or undecodable: the mask alone
+            mask_max = io_formats.mask_max_of_file(os.path.join(mask_base, img))
+        if mask_max <= 0:
+            if mine:
+                skipped.append((name, "mask unreadable" if mask_max < 0 else "mask holds no instance (the reference raises here: np.random.randint(0))"))
+            continue
         with lap("pose draws"):
             obj_indices, pose_params = [], []
             for r in range(opt.repeat):
-                obj_indices.append(np.random.randint(mask_max) + 1)
-                pose_params.append(host_math.draw_pose_parameters(opt.ext_cz, profile=opt.poses))
-                pose_params.append(host_math.draw_pose_parameters(opt.ext_cz, base_motions=[0, 0, 0], profile=opt.poses))
-            poses = host_math.poses_from_parameters(pose_params) if mine else None
-        for r in range(opt.repeat):
-            if not mine:
-                continue
-            obj_index, cam_ext_dynamic, cam_ext = obj_indices[r], poses[2 * r], poses[2 * r + 1]
-            with lap("instance mask"):
-                obj_mask = (ids == obj_index).to(torch.float32)[None, None]                                       # :102-105
-                obj_mask = F.interpolate(obj_mask, size=(opt.height, opt.width), mode="bilinear", align_corners=True)
-            with lap("render pair"):
-                res = pipeline.render_pair(image[0], obj_mask[0, 0], mpi, planes, K, cam_ext, cam_ext_dynamic, renderer=renderer,
-                                           cum_mask=cum_mask, reuse_blend=True)
-            # the tail of a pair (hole fill: one workgroup; scanlines; statistics; copies to the host) runs on a second stream, so
-            # it overlaps the next pair's render instead of serialising a one-CU kernel into the main stream
-            tail_ready.record()
-            for tns in (res["frame_mix"], res["fill_mask"], res["flow_mix"]):
-                tns.record_stream(tail_stream)
-            with torch.cuda.stream(tail_stream):
-                tail_stream.wait_event(tail_ready)
-                with lap("hole fill + PNG scanlines"):
-                    if opt.inpaint == "hip" or (opt.inpaint == "auto" and not U.have_cv2()):
-                        frame = ops.fill_holes(res["frame_mix"], res["fill_mask"], workspace=fill_ws)
-                        scan = ops.png_scanlines(frame)
-                    else:                                                                                         # :284-286 on the host
-                        frame = U._inpaint(res["frame_mix"], res["fill_mask"], opt.inpaint)
-                        scan = torch.from_numpy(io_formats.filter_up_rgb(np.asarray(frame)[:, :, ::-1]))
-                with lap("statistics + hand-off to the writers"):
-                    dstats.add(res["flow_mix"], res["fill_mask"])
-                    ring.submit_pair(res["flow_mix"], scan, os.path.join(out, "flows", f"{name}_{r}.flo"),            # :120
-                                     os.path.join(out, "dst_images", f"{name}_{r}.png"))                              # :121
-            n_pairs += 1
-        lane_ctx.__exit__(None, None, None)
-        if mine and t_first is None and n_owned >= len(lanes):
+                obj_indices.append(np.random.randint(mask_max) + 1)                                                 # :101
+                pose_params.append(host_math.draw_pose_parameters(opt.ext_cz, profile=opt.poses))                     # utils.py:207
+                pose_params.append(host_math.draw_pose_parameters(opt.ext_cz, base_motions=[0, 0, 0], profile=opt.poses))   # :208
+        if not mine:
+            continue
+        if i in done_before:
+            n_resumed += 1
+            continue
+        if item["error"] is not None:
+            skipped.append((name, "input: %r" % (item["error"],)))
+            continue
+        lane = lanes[n_owned % len(lanes)]
+        n_owned += 1
+        try:
+            n_pairs += render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, model, amp, ring, dstats, fill_mode, lap)
+        except Exception as e:                                             # noqa: BLE001 - isolate the image, keep the batch going
+            torch.cuda.synchronize()
+            skipped.append((name, "render: %r" % (e,)))
+            continue
+        if t_first is None and n_owned >= len(lanes):
             t_first, n_first = time.perf_counter(), n_pairs       # start-up (graph capture, first MIOpen calls) ends once every lane has run
     with lap("drain writers"):
         torch.cuda.synchronize()
@@ -249,13 +278,75 @@ def main(argv=None):
     if t_first is not None and n_pairs > n_first and rank == 0:
         print("steady state after the first image: %.1f pairs/s on this rank" % ((n_pairs - n_first) / (t_end - t_first)))
     total = pipeline.reduce_stats(stats)
+    all_skipped, resumed = pipeline.gather_reports(skipped, n_resumed)
     if rank == 0:
         print("pairs %d  mean|flow| %.3f px  max|flow| %.2f px  hole px/pair %.0f  wall %.1f s  (%d rank%s)" % (
             total["pairs"], total["sum_flow_mag"] / max(total["pairs"], 1) / (opt.height * opt.width), total["max_flow_mag"],
             total["hole_px"] / max(total["pairs"], 1), total["wall_seconds"], world, "s" if world > 1 else ""))
+        if resumed:
+            print("resume: %d image(s) already complete, skipped" % resumed)
+        with open(os.path.join(out, "skipped.txt"), "w") as f:
+            for nm, why in all_skipped:
+                f.write("%s\t%s\n" % (nm, why))
+        if all_skipped:
+            print("skipped %d image(s) (listed in %s):" % (len(all_skipped), os.path.join(out, "skipped.txt")))
+            for nm, why in all_skipped[:20]:
+                print("  %s: %s" % (nm, why))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, model, amp, ring, dstats, fill_mode, lap):
+    """One owned image: upload, input stage, MPI producer + blend (once), then `repeat` pairs.  Returns the pairs rendered."""
+    renderer, hip_model, tail_stream, tail_ready, fill_ws = lane.renderer, lane.hip_model, lane.tail_stream, lane.tail_ready, lane.fill_ws
+    H, W = opt.height, opt.width
+    with torch.cuda.stream(lane.stream):                                  # everything this image enqueues goes to its lane's stream
+        with lap("upload + resize image, disparity"):
+            rgb8 = item["rgb_u8"].to(dev, non_blocking=True)
+            dsp8 = item["disp_u8"].to(dev, non_blocking=True)
+            ids = item["ids_u8"].to(dev, non_blocking=True)
+            pre = ops.prepare_inputs(rgb_u8=rgb8, disp_u8=dsp8, size=(H, W), out=lane.inputs)         # :82-89 in one launch
+            image, disp = pre["image"][None], pre["disp"][None, None]
+        cum_mask = None
+        with lap("MPI producer + blend"):
+            if opt.mpi_from == "npz":
+                z = np.load(os.path.join(opt.base, "mpis", name + ".npz"))
+                mpi, planes = torch.from_numpy(z["mpi"]).to(dev), torch.from_numpy(z["disparity"]).to(dev)
+            elif hip_model is not None:
+                mpi, cum_mask, planes = hip_model(image, disp)             # static buffers: consumed by blend() below
+            elif model is not None:
+                with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):      # :92-93
+                    raw, cm, pd = model(image, disp, raw=True)
+                mpi, cum_mask, planes = raw[0].float().contiguous(), cm[0].float().contiguous(), pd[0].float()
+            else:
+                mpi, planes = mpi_from_disparity(image[0], disp[0, 0], opt.planes)
+            renderer.blend(mpi, image[0], K, planes, cum_mask=cum_mask)      # once per image; the `repeat` pairs below reuse it
+            ring.submit_source(ops.png_scanlines(renderer.src_u8), [os.path.join(out, "src_images", f"{name}_{r}.png") for r in range(opt.repeat)])  # :122
+        poses = host_math.poses_from_parameters(pose_params)               # the image's 2 x repeat poses in one batched evaluation
+        for r in range(opt.repeat):
+            obj_index, cam_ext_dynamic, cam_ext = obj_indices[r], poses[2 * r], poses[2 * r + 1]
+            with lap("instance mask"):
+                obj_mask = ops.prepare_inputs(ids_u8=ids, obj_index=obj_index, size=(H, W))["mask"]             # :102-105
+            with lap("render pair"):
+                res = pipeline.render_pair(image[0], obj_mask, mpi, planes, K, cam_ext, cam_ext_dynamic, renderer=renderer,
+                                           cum_mask=cum_mask, reuse_blend=True)
+            # the tail of a pair (scanlines / hole fill hand-off, statistics, copies to the host) runs on a second stream, so it
+            # overlaps the next pair's render
+            tail_ready.record()
+            for tns in (res["frame_mix"], res["fill_mask"], res["flow_mix"]):
+                tns.record_stream(tail_stream)
+            with torch.cuda.stream(tail_stream):
+                tail_stream.wait_event(tail_ready)
+                flo_path, png_path = os.path.join(out, "flows", f"{name}_{r}.flo"), os.path.join(out, "dst_images", f"{name}_{r}.png")   # :120-121
+                with lap("hole fill / PNG scanlines + hand-off to the writers"):
+                    dstats.add(res["flow_mix"], res["fill_mask"])
+                    if fill_mode in ("cv2", "builtin"):                    # :284-286 on the host, on a writer thread
+                        ring.submit_pair_fill(res["flow_mix"], res["frame_mix"], res["fill_mask"], flo_path, png_path)
+                    else:
+                        frame = ops.fill_holes(res["frame_mix"], res["fill_mask"], workspace=fill_ws) if fill_mode == "peel" else res["frame_mix"]
+                        ring.submit_pair(res["flow_mix"], ops.png_scanlines(frame), flo_path, png_path)
+    return opt.repeat
 
 
 if __name__ == "__main__":

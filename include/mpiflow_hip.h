@@ -152,6 +152,14 @@ int mpf_png_filter_up(const uint8_t *d_bgr, int H, int W, uint8_t *d_scanlines, 
 /* [3,H,W] float RGB -> [H,W,3] u8 BGR, clip(rint(x*255))  (utils/utils.py:174-177) */
 int mpf_to_u8_bgr(const float *d_img, int H, int W, uint8_t *d_out, void *stream);
 
+/* Input stage.  Replaces, for one image: image_to_tensor / disparity_to_tensor after the file decode (utils/utils.py:35-52:
+ * u8 / 255 in fp32 for the image, u8 / 255 in fp64 cast to fp32 for the disparity), the instance mask (ids == obj_index) as
+ * float (gen_3dphoto_dynamic_v2.py:101-103) and the three F.interpolate(size=(H,W), mode='bilinear', align_corners=True) calls
+ * (:86-89, :104-105), bit for bit as ATen's CPU kernels compute them.  d_rgb_u8 [h,w,3] -> d_image [3,H,W];
+ * d_disp_u8 [h,w] -> d_disp [H,W]; d_ids_u8 [h,w] -> d_mask [H,W]; each pair optional (both NULL to skip). */
+int mpf_prepare_inputs(const uint8_t *d_rgb_u8, const uint8_t *d_disp_u8, const uint8_t *d_ids_u8, int obj_index, int h, int w,
+                       int H, int W, float *d_image, float *d_disp, float *d_mask, void *stream);
+
 /* ================= generic (materialised-tensor) ops behind the utils/mpi function signatures ==================== */
 
 /* get_src_xyz_from_plane_disparity (utils/mpi/mpi_rendering.py:213-239): params header K^-1 + S records (depth) */

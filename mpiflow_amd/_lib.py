@@ -55,6 +55,7 @@ SIGNATURES = {
     "mpf_merge": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),
     "mpf_fill_holes_workspace": (c_sz, [c_i, c_i]),
     "mpf_fill_holes": (c_i, [c_p, c_p, c_i, c_i, c_p, c_sz, c_p]),
+    "mpf_prepare_inputs": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "mpf_inpaint_host": (c_i, [c_p, c_p, c_i, c_i, c_i, ctypes.c_double, c_i, c_p]),
     "mpf_png_filter_up": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "mpf_pair_stats": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),

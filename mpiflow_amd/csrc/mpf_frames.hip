@@ -170,3 +170,87 @@ extern "C" int mpf_png_filter_up(const uint8_t *d_bgr, int H, int W, uint8_t *d_
     hipLaunchKernelGGL(k_png_filter_up, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_bgr, H, W, d_scanlines);
     return mpf_launch_status("k_png_filter_up");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Input stage: uploaded uint8 buffers -> the float tensors the path consumes, resized.
+//   image  : transforms.ToTensor()(PIL RGB) = u8 / 255 in fp32 (utils/utils.py:35-39), then
+//            F.interpolate(size=(H,W), mode='bilinear', align_corners=True) (gen_3dphoto_dynamic_v2.py:86-87)
+//   disp   : cv2.imread(path, 0) / 255 in float64, cast to fp32 (utils/utils.py:42-52), same resize (:88-89)
+//   mask   : (ids == obj_index) as float (:101-103), same resize (:104-105)
+// The resize reproduces ATen's CPU kernels bit for bit (established against torch 2.10 here, tests/golden/input_stage.npz):
+//   scale = float(in-1)/(out-1); src = scale*dst; i0 = min(int(src), in-1); l1 = clamp(src - i0, 0, 1); l0 = 1 - l1;
+//   i1 = i0 + (i0 < in-1)  (in == out: i0 = i1 = dst, l0 = 1, l1 = 0), then
+//   out_H + out_W > 128 ("generic" kernel):  t_y = fma(v[y][x0], lx0, v[y][x1]*lx1);  out = fma(t_0, ly0, t_1*ly1)
+//   out_H + out_W <= 128 (channels-last kernel): w_ab = ly_a*lx_b;  out = fma(v11,w11, fma(v10,w10, fma(v00,w00, v01*w01)))
+// (ATen also takes the second form for 3-channel inputs when torch runs with ONE thread; the reference's host has more.)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct AxisTap { int i0, i1; float l0, l1; };
+
+__device__ __forceinline__ AxisTap axis_tap(int dst, int in, int out, float scale)
+{
+    AxisTap t;
+    if (in == out) { t.i0 = t.i1 = dst; t.l0 = 1.0f; t.l1 = 0.0f; return t; }
+    const float src = scale * (float)dst;
+    t.i0 = min((int)src, in - 1);                       // src >= 0: trunc == floor
+    t.l1 = fminf(fmaxf(src - (float)t.i0, 0.0f), 1.0f);
+    t.l0 = 1.0f - t.l1;
+    t.i1 = t.i0 + ((t.i0 < in - 1) ? 1 : 0);
+    return t;
+}
+
+__device__ __forceinline__ float bilerp_ac(float v00, float v01, float v10, float v11, const AxisTap &ty, const AxisTap &tx, bool small)
+{
+    if (small) {
+        float acc = v01 * (ty.l0 * tx.l1);
+        acc = fmaf(v00, ty.l0 * tx.l0, acc);
+        acc = fmaf(v10, ty.l1 * tx.l0, acc);
+        return fmaf(v11, ty.l1 * tx.l1, acc);
+    }
+    const float t0 = fmaf(v00, tx.l0, v01 * tx.l1);
+    const float t1 = fmaf(v10, tx.l0, v11 * tx.l1);
+    return fmaf(t0, ty.l0, t1 * ty.l1);
+}
+
+__global__ __launch_bounds__(256) void k_prepare_inputs(const uint8_t *__restrict__ rgb, const uint8_t *__restrict__ disp,
+                                                       const uint8_t *__restrict__ ids, int obj_index, int h, int w, int H, int W,
+                                                       float sy, float sx, float *__restrict__ image_out, float *__restrict__ disp_out,
+                                                       float *__restrict__ mask_out)
+{
+    const int64_t N = (int64_t)H * W, n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int Y = (int)(n / W), X = (int)(n - (int64_t)Y * W);
+    const AxisTap ty = axis_tap(Y, h, H, sy), tx = axis_tap(X, w, W, sx);
+    const bool small = (H + W) <= 128;
+    const int64_t o00 = (int64_t)ty.i0 * w + tx.i0, o01 = (int64_t)ty.i0 * w + tx.i1, o10 = (int64_t)ty.i1 * w + tx.i0, o11 = (int64_t)ty.i1 * w + tx.i1;
+    if (rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            image_out[(int64_t)c * N + n] = bilerp_ac((float)rgb[3 * o00 + c] / 255.0f, (float)rgb[3 * o01 + c] / 255.0f,
+                                                      (float)rgb[3 * o10 + c] / 255.0f, (float)rgb[3 * o11 + c] / 255.0f, ty, tx, small);
+    }
+    if (disp)
+        disp_out[n] = bilerp_ac((float)((double)disp[o00] / 255.0), (float)((double)disp[o01] / 255.0), (float)((double)disp[o10] / 255.0),
+                                (float)((double)disp[o11] / 255.0), ty, tx, small);
+    if (ids)
+        mask_out[n] = bilerp_ac(ids[o00] == obj_index ? 1.0f : 0.0f, ids[o01] == obj_index ? 1.0f : 0.0f, ids[o10] == obj_index ? 1.0f : 0.0f,
+                                ids[o11] == obj_index ? 1.0f : 0.0f, ty, tx, small);
+}
+
+}   // namespace
+
+extern "C" int mpf_prepare_inputs(const uint8_t *d_rgb_u8, const uint8_t *d_disp_u8, const uint8_t *d_ids_u8, int obj_index, int h, int w,
+                                  int H, int W, float *d_image, float *d_disp, float *d_mask, void *stream)
+{
+    MPF_REQUIRE(h >= 1 && w >= 1 && H >= 1 && W >= 1 && (int64_t)h * w < ((int64_t)1 << 31) && (int64_t)H * W < ((int64_t)1 << 31), "mpf_prepare_inputs: bad shape");
+    MPF_REQUIRE((d_rgb_u8 == nullptr) == (d_image == nullptr) && (d_disp_u8 == nullptr) == (d_disp == nullptr) && (d_ids_u8 == nullptr) == (d_mask == nullptr),
+                "mpf_prepare_inputs: every input goes with its output");
+    MPF_REQUIRE(d_rgb_u8 || d_disp_u8 || d_ids_u8, "mpf_prepare_inputs: nothing to do");
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;       // area_pixel_compute_scale, align_corners = True
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_prepare_inputs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rgb_u8, d_disp_u8, d_ids_u8,
+                       obj_index, h, w, H, W, sy, sx, d_image, d_disp, d_mask);
+    return mpf_launch_status("k_prepare_inputs");
+}

@@ -79,6 +79,45 @@ def write_bytes(path, data):
         f.write(data)
 
 
+# ---- decoding a disparity file the way cv2.imread(path, 0) does (reference utils/utils.py:42-43) -----------------------------
+# cv2.imread(path, cv2.IMREAD_GRAYSCALE) always returns 8-bit single-channel data:
+#   8-bit grey           the stored bytes
+#   16-bit grey          the HIGH byte (libpng png_set_strip_16: value >> 8) - MiDaS' default output, the tool the reference's
+#                        README recommends.  (PIL's .convert("L") SATURATES 16-bit data instead: everything above 255 -> 255.)
+#   colour PNG           libpng's png_set_rgb_to_gray fixed point: (R*9798 + G*19235 + B*3735 + 16384) >> 15   [coefficients
+#                        0.299 / 0.587 scaled by 32768, blue = the remainder]
+#   colour JPEG / other  OpenCV's BGR2GRAY fixed point: (R*4899 + G*9617 + B*1868 + 8192) >> 14
+#   alpha is dropped, palettes are expanded first, 1-bit images become 0 / 255.
+# OpenCV is third-party and absent here: this follows its documented behaviour and is compared with the real cv2.imread by
+# tests/test_host_logic.py whenever OpenCV is importable (parity of this decoder is otherwise unpinned).
+def grey_like_cv2_imread(pil_image, is_png=True):
+    im = pil_image
+    if im.mode in ("I;16", "I;16L", "I;16B", "I;16N"):
+        return (np.asarray(im).astype(np.uint16) >> 8).astype(np.uint8)
+    if im.mode == "I":                                   # 32-bit container PIL uses for 16-bit PNGs on some versions
+        return ((np.asarray(im).astype(np.int64) & 0xFFFF) >> 8).astype(np.uint8)
+    if im.mode == "F":
+        raise ValueError("floating-point image files are not a cv2.imread(path, 0) input")
+    if im.mode == "1":
+        return np.where(np.asarray(im), 255, 0).astype(np.uint8)
+    if im.mode in ("L",):
+        return np.asarray(im).copy()
+    if im.mode == "LA":
+        return np.asarray(im)[..., 0].copy()
+    rgb = np.asarray(im.convert("RGB")).astype(np.uint32)     # P, RGBA, CMYK, YCbCr ... -> RGB first
+    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    if is_png:
+        return ((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8)
+    return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+def read_disparity_u8(path):
+    """cv2.imread(path, 0) -> u8 [h,w]"""
+    from PIL import Image
+    im = Image.open(path)
+    return grey_like_cv2_imread(im, is_png=(im.format or "").upper() == "PNG")
+
+
 class AsyncWriter:
     """Bounded pool of writer threads so that PNG encoding (zlib, ~20 ms per 640x960 frame) and file I/O overlap the GPU
     instead of capping pairs/s.  Jobs are plain host arrays; submit() blocks when `max_pending` jobs
@@ -125,30 +164,61 @@ class OutputRing:
     flight (back-pressure).  The source frame of an image is the same for all its pairs: submit_source() encodes it once
     and writes it under every pair's name."""
 
-    def __init__(self, H, W, device, slots=16, threads=8, png_level=1):
+    def __init__(self, H, W, device, slots=16, threads=8, png_level=1, host_fill=None):
+        """host_fill: None, or a function (frame_bgr u8 [H,W,3], hole u8 [H,W]) -> filled frame, run on the writer thread before
+        the PNG is encoded - the reference's cv2.inpaint step (utils/utils.py:284-286), which is sequential host work by nature
+        and is overlapped here with the GPU render of the following pairs (submit_pair_fill)."""
         import concurrent.futures
         import queue
         import torch
-        self.H, self.W, self.level = H, W, png_level
+        self.H, self.W, self.level, self._host_fill = H, W, png_level, host_fill
         self._free = queue.Queue()
         for _ in range(slots):
-            self._free.put(dict(flow=torch.empty((H, W, 2), dtype=torch.float32).pin_memory(),
-                                scan=torch.empty((H, 3 * W + 1), dtype=torch.uint8).pin_memory()))
+            slot = dict(flow=torch.empty((H, W, 2), dtype=torch.float32).pin_memory(),
+                        scan=torch.empty((H, 3 * W + 1), dtype=torch.uint8).pin_memory())
+            if host_fill is not None:
+                slot.update(frame=torch.empty((H, W, 3), dtype=torch.uint8).pin_memory(), hole=torch.empty((H, W), dtype=torch.uint8).pin_memory())
+            self._free.put(slot)
         self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=threads)
         self._futures = []
         self._torch = torch
 
-    def _finish(self, slot, event, flo_path, png_paths):
+    def _finish(self, slot, event, flo_path, png_paths, fill=False):
         try:
             event.synchronize()
             if flo_path is not None:
                 write_flo(flo_path, slot["flow"].numpy())
             if png_paths:
-                data = png_from_scanlines(slot["scan"].numpy(), self.level)
+                if fill:
+                    frame = self._host_fill(slot["frame"].numpy(), slot["hole"].numpy())
+                    scan = filter_up_rgb(np.asarray(frame)[:, :, ::-1])               # cv2.imwrite: BGR array -> RGB file
+                else:
+                    scan = slot["scan"].numpy()
+                data = png_from_scanlines(scan, self.level)
                 for p in png_paths:
                     write_bytes(p, data)
         finally:
             self._free.put(slot)
+
+    def submit_pair_fill(self, flow_HW2_dev, frame_bgr_dev, hole_dev, flo_path, png_path):
+        """Like submit_pair, but the frame leaves the GPU unfilled together with its hole mask and the writer thread runs
+        `host_fill` on it before encoding."""
+        assert self._host_fill is not None
+        slot = self._free.get()
+        slot["flow"].copy_(flow_HW2_dev, non_blocking=True)
+        slot["frame"].copy_(frame_bgr_dev, non_blocking=True)
+        slot["hole"].copy_(hole_dev, non_blocking=True)
+        ev = self._torch.cuda.Event()
+        ev.record()
+        self._track(self._pool.submit(self._finish, slot, ev, flo_path, [png_path], True))
+
+    def _track(self, fut):
+        self._futures.append(fut)
+        if len(self._futures) > 1024:
+            done = [f for f in self._futures if f.done()]
+            for f in done:
+                f.result()
+            self._futures = [f for f in self._futures if not f.done()]
 
     def _submit(self, flow_dev, scan_dev, flo_path, png_paths):
         slot = self._free.get()
@@ -157,12 +227,7 @@ class OutputRing:
         slot["scan"].copy_(scan_dev, non_blocking=True)
         ev = self._torch.cuda.Event()
         ev.record()
-        self._futures.append(self._pool.submit(self._finish, slot, ev, flo_path, png_paths))
-        if len(self._futures) > 1024:
-            done = [f for f in self._futures if f.done()]
-            for f in done:
-                f.result()
-            self._futures = [f for f in self._futures if not f.done()]
+        self._track(self._pool.submit(self._finish, slot, ev, flo_path, png_paths))
 
     def submit_pair(self, flow_HW2_dev, frame_scanlines_dev, flo_path, png_path):
         self._submit(flow_HW2_dev, frame_scanlines_dev, flo_path, [png_path])
@@ -178,24 +243,27 @@ class OutputRing:
 
 
 class InputPrefetcher:
-    """Decodes the PNGs of upcoming images on background threads so that the GPU never waits for
-    PIL: yields (index, name, mask ids u8 [h,w], image [3,h,w] f32 in [0,1] or None, disparity [1,h,w] f32 or None) in
-    listing order; image and disparity are only decoded for the images this rank owns (every rank needs every mask: the
-    instance id draw depends on mask.max(), gen_3dphoto_dynamic_v2.py:101).  pin=True returns torch tensors in page-locked
-    memory (pinned on the worker thread), ready for an asynchronous upload."""
+    """Decodes the three PNGs of the images THIS RANK OWNS on background threads, so the GPU never waits
+    for a decoder.  Iterating yields, in listing order of `indices`, dicts
+        {i, name, error: None | Exception, rgb_u8 [h,w,3], disp_u8 [h,w], ids_u8 [h,w]}
+    - the uint8 arrays exactly as the reference's loaders see them before their `/255` (image: PIL RGB, utils/utils.py:35-39;
+    disparity: cv2.imread(path, 0), :42-43; mask: PIL "L", gen_3dphoto_dynamic_v2.py:83) - as torch tensors in page-locked
+    memory (pin=True) ready for an asynchronous upload; the float conversion and the resize happen on the GPU
+    (mpf_prepare_inputs).  A file that cannot be decoded does not raise here: its item carries `error`, and the driver skips
+    that image and carries on."""
 
-    def __init__(self, names, img_dir, disp_dir, mask_dir, owned, depth=8, threads=4, pin=False):
+    def __init__(self, names, img_dir, disp_dir, mask_dir, indices, depth=8, threads=4, pin=True):
         import collections
         import concurrent.futures
-        self._names, self._dirs, self._owned, self._pin = list(names), (img_dir, disp_dir, mask_dir), owned, pin
+        self._names, self._dirs, self._todo, self._pin = list(names), (img_dir, disp_dir, mask_dir), list(indices), pin
         self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=threads)
         self._pending = collections.deque()
         self._next, self._depth = 0, depth
         self._fill()
 
     def _fill(self):
-        while self._next < len(self._names) and len(self._pending) < self._depth:
-            self._pending.append(self._pool.submit(self._load, self._next))
+        while self._next < len(self._todo) and len(self._pending) < self._depth:
+            self._pending.append(self._pool.submit(self._load, self._todo[self._next]))
             self._next += 1
 
     def _load(self, i):
@@ -203,24 +271,35 @@ class InputPrefetcher:
         from PIL import Image
         img_dir, disp_dir, mask_dir = self._dirs
         n = self._names[i]
-        mask = np.array(Image.open(os.path.join(mask_dir, n)).convert("L"))
-        image = disp = None
-        if self._owned(i):
-            image = np.asarray(Image.open(os.path.join(img_dir, n)).convert("RGB")).transpose(2, 0, 1).astype(np.float32) / np.float32(255)
-            disp = (np.asarray(Image.open(os.path.join(disp_dir, n)).convert("L")).astype(np.float64) / 255).astype(np.float32)[None]
+        try:
+            ids = np.array(Image.open(os.path.join(mask_dir, n)).convert("L"))
+            rgb = np.array(Image.open(os.path.join(img_dir, n)).convert("RGB"))
+            disp = read_disparity_u8(os.path.join(disp_dir, n))
+            if not (rgb.shape[:2] == disp.shape == ids.shape):
+                raise ValueError("image %s, disparity %s and mask %s differ in size" % (rgb.shape[:2], disp.shape, ids.shape))
+            out = dict(i=i, name=n, error=None, rgb_u8=rgb, disp_u8=disp, ids_u8=ids)
             if self._pin:
                 import torch
-                image, disp = torch.from_numpy(image).pin_memory(), torch.from_numpy(disp).pin_memory()
-        if self._pin:
-            import torch
-            return i, n, int(mask.max()), torch.from_numpy(mask).pin_memory(), image, disp
-        return i, n, mask, image, disp
+                for k in ("rgb_u8", "disp_u8", "ids_u8"):
+                    out[k] = torch.from_numpy(np.ascontiguousarray(out[k])).pin_memory()
+            return out
+        except Exception as e:                      # noqa: BLE001 - reported per image by the driver
+            return dict(i=i, name=n, error=e)
 
     def __iter__(self):
         try:
             while self._pending:
-                item = self._pending.popleft().result()          # re-raises a worker's exception here
+                item = self._pending.popleft().result()
                 self._fill()
                 yield item
         finally:
             self._pool.shutdown(wait=False, cancel_futures=True)
+
+
+def mask_max_of_file(path):
+    """np.array(Image.open(path).convert("L")).max() (gen_3dphoto_dynamic_v2.py:83, :101), or -1 when the file cannot be decoded"""
+    from PIL import Image
+    try:
+        return int(np.array(Image.open(path).convert("L")).max())
+    except Exception:                               # noqa: BLE001
+        return -1

@@ -220,6 +220,31 @@ def fill_holes(img_HW3_u8, hole_HW_u8, out=None, hole_out=None, workspace=None):
     return out
 
 
+@_on_device
+def prepare_inputs(rgb_u8=None, disp_u8=None, ids_u8=None, obj_index=0, size=None, out=None):
+    """Input stage in one launch (mpf_prepare_inputs): uploaded u8 buffers -> resized float tensors, bit-identical to the
+    reference's ToTensor / `/255` / (ids == k).float() followed by F.interpolate(bilinear, align_corners=True).
+    rgb_u8 [h,w,3], disp_u8 [h,w], ids_u8 [h,w] on the device (any subset); size = (H, W).
+    Returns dict(image [3,H,W], disp [H,W], mask [H,W]) (None for absent inputs); `out` may carry preallocated tensors."""
+    lib = _lib.load()
+    H, W = size
+    first = next(t for t in (rgb_u8, disp_u8, ids_u8) if t is not None)
+    h, w = first.shape[:2]
+    dev = first.device
+    out = dict(out or {})
+    rgb = _dev(rgb_u8, "rgb", torch.uint8) if rgb_u8 is not None else None
+    dsp = _dev(disp_u8, "disp", torch.uint8) if disp_u8 is not None else None
+    ids = _dev(ids_u8, "ids", torch.uint8) if ids_u8 is not None else None
+    for t in (rgb, dsp, ids):
+        assert t is None or tuple(t.shape[:2]) == (h, w)
+    image = (out.get("image") if out.get("image") is not None else torch.empty((3, H, W), dtype=_f32, device=dev)) if rgb is not None else None
+    disp = (out.get("disp") if out.get("disp") is not None else torch.empty((H, W), dtype=_f32, device=dev)) if dsp is not None else None
+    mask = (out.get("mask") if out.get("mask") is not None else torch.empty((H, W), dtype=_f32, device=dev)) if ids is not None else None
+    _lib.check(lib.mpf_prepare_inputs(_ptr(rgb), _ptr(dsp), _ptr(ids), int(obj_index), h, w, H, W, _ptr(image), _ptr(disp), _ptr(mask), _stream()),
+               "mpf_prepare_inputs")
+    return dict(image=image, disp=disp, mask=mask)
+
+
 INPAINT_NS, INPAINT_TELEA = 0, 1          # cv2.INPAINT_NS / cv2.INPAINT_TELEA (MPF_INPAINT_*)
 
 

@@ -150,6 +150,40 @@ def pose_schedule(seed, n_pairs, ext_cz):
     return out
 
 
+def mask_max_table(names, mask_dir, rank, world, group=None, threads=8):
+    """The instance-id draw of every pair needs mask.max() of ITS image (gen_3dphoto_dynamic_v2.py:101), and every rank replays
+    the draws of every image to stay on the reference's RNG stream.  Instead of every rank decoding every mask (N ranks x the
+    whole masks/ directory), rank 0 decodes each mask once, and the table of maxima - one int32 per image, -1 = unreadable -
+    is broadcast (RCCL under nccl, gloo on CPU).  Ranks then decode only the masks of the images they own."""
+    import concurrent.futures
+    import torch.distributed as dist
+    from . import io_formats
+    n = len(names)
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return None                                   # single rank: the maxima come from the decoded masks themselves
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    if rank == 0:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as pool:
+            vals = list(pool.map(lambda nm: io_formats.mask_max_of_file(os.path.join(mask_dir, nm)), names))
+        table = torch.tensor(vals, dtype=torch.int32, device=dev)
+    else:
+        table = torch.empty((n,), dtype=torch.int32, device=dev)
+    dist.broadcast(table, src=0, group=group)
+    return table.cpu().tolist()
+
+
+def gather_reports(skipped, n_resumed, group=None):
+    """End of batch: every rank's list of (image, reason) it could not render, and its count of resumed images, on rank 0."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(skipped), n_resumed
+    world = dist.get_world_size(group)
+    box = [None] * world
+    dist.all_gather_object(box, (list(skipped), int(n_resumed)), group=group)
+    merged = sorted(x for lst, _ in box for x in lst)
+    return merged, sum(n for _, n in box)
+
+
 def device_identity(local_index):
     """A string that is equal for two processes iff they drive the same physical GPU of this node."""
     import socket

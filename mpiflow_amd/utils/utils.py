@@ -25,8 +25,8 @@ def image_to_tensor(img_path, unsqueeze=True):
 
 def disparity_to_tensor(disp_path, unsqueeze=True):
     """grey-scale disparity file -> [1,1,h,w] float in [0,1]   (reference :42-52; cv2.imread(path, 0) / 255)"""
-    from PIL import Image
-    disp = np.asarray(Image.open(disp_path).convert("L")).astype(np.float64) / 255
+    from ..io_formats import read_disparity_u8
+    disp = read_disparity_u8(disp_path).astype(np.float64) / 255      # 16-bit files: high byte, as cv2 - not PIL's saturating convert("L")
     disp = torch.from_numpy(disp)[None, ...]
     if unsqueeze:
         disp = disp.unsqueeze(0)

@@ -417,3 +417,32 @@ def dilate3x3(img_u8):
     out = np.empty_like(img)
     lib().orc_dilate3x3(_p(img), H, W, _p(out))
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# input stage (utils/utils.py:35-52, gen_3dphoto_dynamic_v2.py:82-89, :101-105)
+# --------------------------------------------------------------------------------------------------------------
+
+def resize_bilinear_ac(x_CHW, H, W):
+    """F.interpolate(x[None], size=(H,W), mode='bilinear', align_corners=True)[0] for fp32 [C,h,w]"""
+    x = _c(x_CHW)
+    C, h, w = x.shape
+    out = np.empty((C, H, W), np.float32)
+    lib().orc_resize_bilinear_ac(_p(x), C, h, w, H, W, _p(out))
+    return out
+
+
+def prepare_inputs(rgb_u8_hw3=None, disp_u8_hw=None, ids_u8_hw=None, obj_index=0, size=None):
+    """u8 arrays as decoded from the files -> the resized float tensors of gen_3dphoto_dynamic_v2.py:82-89 / :101-105"""
+    H, W = size
+    out = dict(image=None, disp=None, mask=None)
+    if rgb_u8_hw3 is not None:
+        img = np.ascontiguousarray(np.asarray(rgb_u8_hw3, np.uint8).transpose(2, 0, 1)).astype(np.float32) / np.float32(255)   # ToTensor
+        out["image"] = resize_bilinear_ac(img, H, W)
+    if disp_u8_hw is not None:
+        d = (np.asarray(disp_u8_hw, np.uint8) / 255).astype(np.float32)                    # float64 division, then .float()
+        out["disp"] = resize_bilinear_ac(d[None], H, W)[0]
+    if ids_u8_hw is not None:
+        m = (np.asarray(ids_u8_hw) == obj_index).astype(np.float32)
+        out["mask"] = resize_bilinear_ac(m[None], H, W)[0]
+    return out

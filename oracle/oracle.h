@@ -104,6 +104,9 @@ void orc_select_truncate(const float *p_static, const float *z_static, const flo
 void orc_warp_masks(const uint8_t *warped, int H, int W, uint8_t *Hm, uint8_t *M, uint8_t *Md, uint8_t *P,
                     uint8_t *Hp);
 
+/* F.interpolate(size=(H,W), mode='bilinear', align_corners=True) on fp32 [C,h,w] -> [C,H,W] (gen_3dphoto_dynamic_v2.py:86-89,104-105) */
+void orc_resize_bilinear_ac(const float *src, int C, int h, int w, int H, int W, float *out);
+
 /* ---- oracle_inpaint.c : cv2.inpaint (NS / Telea) and cv2.dilate(3x3) restated - PARITY UNPINNED (third-party OpenCV) --- */
 /* img u8 [rows,cols,C] (C = 1 or 3), mask u8 [rows,cols] (non-zero = fill), method 0 = INPAINT_NS, 1 = INPAINT_TELEA
  * (reference: utils/utils.py:284-286, moving_obj.py:162).  Returns 0, -1 on allocation failure. */

@@ -455,3 +455,58 @@ void orc_merge(const float *frame, const float *frame_dyn, const float *mask, co
         fill_mask[n] = (f < th) ? 1 : 0;
     }
 }
+
+
+/* ---- input stage ------------------------------------------------------------------------------------
+ * F.interpolate(x, size=(H,W), mode='bilinear', align_corners=True) as torch-CPU computes it for fp32 NCHW input with more
+ * than one thread (gen_3dphoto_dynamic_v2.py:86-89, :104-105).  ATen has two kernels: out_H + out_W <= 128 takes the
+ * "channels-last" one (combined weights, 4-term fma chain), everything larger the generic one (row interpolation, then
+ * column).  Both established against torch 2.10 in this container (tests/golden/make_golden.py: input_stage). */
+typedef struct { int i0, i1; float l0, l1; } OrcAxisTap;
+
+static OrcAxisTap orc_axis_tap(int dst, int in, int out, float scale)
+{
+    OrcAxisTap t;
+    if (in == out) { t.i0 = t.i1 = dst; t.l0 = 1.0f; t.l1 = 0.0f; return t; }
+    const float src = scale * (float)dst;
+    t.i0 = (int)floorf(src);
+    if (t.i0 > in - 1) t.i0 = in - 1;
+    t.l1 = src - (float)t.i0;
+    if (t.l1 < 0.0f) t.l1 = 0.0f;
+    if (t.l1 > 1.0f) t.l1 = 1.0f;
+    t.l0 = 1.0f - t.l1;
+    t.i1 = t.i0 + ((t.i0 < in - 1) ? 1 : 0);
+    return t;
+}
+
+void orc_resize_bilinear_ac(const float *src, int C, int h, int w, int H, int W, float *out)
+{
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    const int small = (H + W) <= 128;
+    for (int c = 0; c < C; ++c) {
+        const float *s = src + (int64_t)c * h * w;
+        float *o = out + (int64_t)c * H * W;
+#pragma omp parallel for
+        for (int Y = 0; Y < H; ++Y) {
+            const OrcAxisTap ty = orc_axis_tap(Y, h, H, sy);
+            for (int X = 0; X < W; ++X) {
+                const OrcAxisTap tx = orc_axis_tap(X, w, W, sx);
+                const float v00 = s[(int64_t)ty.i0 * w + tx.i0], v01 = s[(int64_t)ty.i0 * w + tx.i1];
+                const float v10 = s[(int64_t)ty.i1 * w + tx.i0], v11 = s[(int64_t)ty.i1 * w + tx.i1];
+                float r;
+                if (small) {
+                    r = v01 * (ty.l0 * tx.l1);
+                    r = fmaf(v00, ty.l0 * tx.l0, r);
+                    r = fmaf(v10, ty.l1 * tx.l0, r);
+                    r = fmaf(v11, ty.l1 * tx.l1, r);
+                } else {
+                    const float t0 = fmaf(v00, tx.l0, v01 * tx.l1);
+                    const float t1 = fmaf(v10, tx.l0, v11 * tx.l1);
+                    r = fmaf(t0, ty.l0, t1 * ty.l1);
+                }
+                o[(int64_t)Y * W + X] = r;
+            }
+        }
+    }
+}

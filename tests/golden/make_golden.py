@@ -415,6 +415,46 @@ def gen_model(S=4, H=128, W=128, seed=0):
          n_state=len(ref.state_dict()), sha_keys=np.array(sha(np.frombuffer("|".join(sorted(ref.state_dict())).encode(), np.uint8))))
 
 
+def gen_input_stage(seed=41):
+    """The input stage as the reference runs it (gen_3dphoto_dynamic_v2.py:82-89, :101-105 with utils/utils.py:35-52):
+    image_to_tensor / disparity_to_tensor on PNG files, the three F.interpolate(bilinear, align_corners=True) calls and the
+    (ids == k) instance mask.  cv2.imread is third-party and absent; for an 8-BIT GREY PNG `cv2.imread(path, 0)` returns the
+    stored bytes, so the stub decodes exactly that case with PIL (other encodings of a disparity file are not pinned here).
+    Two output sizes: 96 x 160 (out_H + out_W > 128: ATen's generic kernel, as every real size) and 40 x 72 (<= 128: its
+    channels-last kernel)."""
+    import sys as _sys
+    import tempfile
+    import torch.nn.functional as F
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    h, w = 90, 150
+    rgb = (rs.rand(h, w, 3) * 256).astype(np.uint8)
+    dsp = (synth._upsample(rs.rand(6, 10), h, w) * 255).astype(np.uint8)
+    ids = np.zeros((h, w), np.uint8)
+    ids[10:40, 20:70] = 1
+    ids[30:80, 90:140] = 2
+    ids[60:75, 10:60] = 3
+    arrays = dict(rgb_u8=rgb, disp_u8=dsp, ids_u8=ids, torch_threads=torch.get_num_threads())
+    _sys.modules["cv2"].imread = lambda path, flag=1: np.array(Image.open(path).convert("L"))
+    with tempfile.TemporaryDirectory() as d:
+        Image.fromarray(rgb).save(os.path.join(d, "i.png"))
+        Image.fromarray(dsp).save(os.path.join(d, "d.png"))
+        Image.fromarray(ids).save(os.path.join(d, "m.png"))
+        image = R.utils.image_to_tensor(os.path.join(d, "i.png"))                          # [1,3,h,w]
+        obj_mask_np = np.array(Image.open(os.path.join(d, "m.png")).convert("L"))
+        disp = R.utils.disparity_to_tensor(os.path.join(d, "d.png"))                        # [1,1,h,w]
+    arrays.update(image_tensor=image[0].numpy(), disp_tensor=disp[0, 0].numpy(), mask_max=int(obj_mask_np.max()))
+    for tag, (H, W) in (("big", (96, 160)), ("small", (40, 72))):
+        im = F.interpolate(image, size=(H, W), mode="bilinear", align_corners=True)
+        dp = F.interpolate(disp, size=(H, W), mode="bilinear", align_corners=True)
+        arrays["image_" + tag], arrays["disp_" + tag] = im[0].numpy(), dp[0, 0].numpy()
+        for k in (1, 2, 3):
+            om = torch.FloatTensor(obj_mask_np == k).unsqueeze(0).unsqueeze(0)
+            om = F.interpolate(om, size=(H, W), mode="bilinear", align_corners=True)
+            arrays["mask%d_%s" % (k, tag)] = om[0, 0].numpy()
+    save("input_stage", **arrays)
+
+
 JOBS = {
     "tiny": lambda: (gen_small("tiny_white", 8, 32, 48, "white", 1, 7, True),
                      gen_small("tiny_smooth", 8, 32, 48, "smooth", 2, 8, True)),
@@ -430,6 +470,7 @@ JOBS = {
     "c5": lambda: gen_big("c5q_white", 128, 512, 768, "white", 14, 24, stack_px=1024),
     "fwarp": lambda: (gen_fwarp("fwarp_small", 96, 128, 31, True), gen_fwarp("fwarp_c2", 640, 960, 32, False),
                       gen_collision_stress()),
+    "inputs": gen_input_stage,
     "exp": gen_exp,
     "pose": gen_pose_schedule,
     "alpha": gen_alpha,

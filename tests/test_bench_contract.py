@@ -47,3 +47,34 @@ def test_two_rank_path_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6     # all ranks' pairs / max time
+
+
+def test_batch_mode_two_ranks_over_gloo():
+    """--mode batch (BASELINE configs[3], strong scaling): a fixed batch sharded i % world == rank; value = batch pairs / max time."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "batch", "--batch", "7"] + SMALL,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["mode"] == "batch" and d["config"]["batch_images"] == 7
+    assert d["config"]["pairs_rank0_per_step"] == 4                       # images 0, 2, 4, 6 of 7
+    assert abs(d["value"] - 7 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
+    assert "c3" not in d["config"]["workload"] and "dynamic pair" in d["config"]["workload"]
+
+
+def test_single_gpu_line_has_sub_records_and_names_the_dynamic_pair():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--images", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert "configs[2]" in d["config"]["workload"] and "dynamic pair" in d["config"]["workload"]
+    assert d["roofline"]["views_per_pair"] == 2 and 0.05 < d["roofline"]["frac"] < 1.0
+    names = [s_["workload"] for s_ in d["sub"]]
+    assert any(n.startswith("c2") for n in names) and any(n.startswith("c1") for n in names) and any(n.startswith("c5") for n in names)
+    for s_ in d["sub"]:
+        assert s_["stage_b"]["frac"] > 0 and s_["stage_ac"]["frac"] > 0

@@ -202,7 +202,7 @@ def test_cli_end_to_end(dev, tmp_path):
     for run in range(2):
         out = tmp_path / ("out%d" % run)
         r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--base", str(base), "--out", str(out), "--width", "64",
-                            "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "hip"], capture_output=True, text=True, timeout=600)
+                            "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "hip", "--mpi-from", "disparity"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(out)
     for sub, ext in (("flows", "flo"), ("dst_images", "png"), ("src_images", "png")):
@@ -231,7 +231,7 @@ def test_cli_two_ranks_write_the_files_of_one_rank(dev, tmp_path):
         Image.fromarray((255 * (0.2 + 0.6 * xx / 56)).astype(np.uint8)).save(base / "disps" / ("im%d.png" % i))
         m = np.zeros((40, 56), np.uint8); m[10:25, 15:35] = 1; m[28:36, 5:20] = 2 + (i % 2)
         Image.fromarray(m).save(base / "masks" / ("im%d.png" % i))
-    args = ["--base", str(base), "--width", "64", "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "hip"]
+    args = ["--base", str(base), "--width", "64", "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "hip", "--mpi-from", "disparity"]
     one, two = tmp_path / "one", tmp_path / "two"
     lanes = tmp_path / "lanes"                      # two images in flight on one rank: same files again
     r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--out", str(lanes), "--lanes", "2"] + args, capture_output=True, text=True, timeout=600)
@@ -250,6 +250,106 @@ def test_cli_two_ranks_write_the_files_of_one_rank(dev, tmp_path):
         for f in files:
             assert open(one / sub / f, "rb").read() == open(two / sub / f, "rb").read(), "%s/%s differs between 1 and 2 ranks" % (sub, f)
             assert open(one / sub / f, "rb").read() == open(lanes / sub / f, "rb").read(), "%s/%s differs between 1 and 2 lanes" % (sub, f)
+
+
+def _toy_dataset(base, names, empty_mask=(), corrupt=()):
+    from PIL import Image
+    for d in ("images", "disps", "masks"):
+        (base / d).mkdir(parents=True, exist_ok=True)
+    for n in names:
+        rs = np.random.RandomState(sum(map(ord, n)))              # content depends on the name only
+        Image.fromarray((rs.rand(40, 56, 3) * 255).astype(np.uint8)).save(base / "images" / (n + ".png"))
+        yy, xx = np.mgrid[0:40, 0:56]
+        Image.fromarray((255 * (0.2 + 0.6 * xx / 56)).astype(np.uint8)).save(base / "disps" / (n + ".png"))
+        m = np.zeros((40, 56), np.uint8)
+        if n not in empty_mask:
+            m[10:25, 15:35] = 1
+            m[28:36, 5:20] = 2
+        Image.fromarray(m).save(base / "masks" / (n + ".png"))
+        if n in corrupt:
+            (base / "images" / (n + ".png")).write_bytes(b"\x89PNG this is not an image")
+
+
+def _run_cli(root, args, env=None, nproc=1, port=29551):
+    import subprocess, sys, os
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    return subprocess.run(cmd + [os.path.join(root, "gen_3dphoto_dynamic.py")] + args, capture_output=True, text=True, timeout=900, env=env)
+
+
+def test_cli_skips_bad_images_without_disturbing_the_others(dev, tmp_path):
+    """Failure isolation (the reference dies on a mask without instances, gen_3dphoto_dynamic_v2.py:101): an image whose mask holds no
+    instance consumes NO draws, a corrupt picture is skipped after its draws - either way every other image gets the files it would
+    get if the bad ones were not in the listing / were fine; out/skipped.txt lists them; one rank and two ranks agree."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--width", "64", "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "none", "--mpi-from", "disparity"]
+    _toy_dataset(tmp_path / "full", ["a", "b", "c", "d"], empty_mask=("b",), corrupt=("c",))
+    _toy_dataset(tmp_path / "clean", ["a", "c", "d"])                                   # b absent; c intact (its draws are consumed either way)
+    r = _run_cli(root, ["--base", str(tmp_path / "full"), "--out", str(tmp_path / "o_full")] + common)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "skipped 2 image(s)" in r.stdout
+    listed = dict(l.split("\t", 1) for l in open(tmp_path / "o_full" / "skipped.txt").read().splitlines())
+    assert set(listed) == {"b", "c"} and "no instance" in listed["b"] and listed["c"].startswith("input:")
+    r = _run_cli(root, ["--base", str(tmp_path / "clean"), "--out", str(tmp_path / "o_clean")] + common)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for sub, ext in (("flows", "flo"), ("dst_images", "png"), ("src_images", "png")):
+        assert sorted(os.listdir(tmp_path / "o_full" / sub)) == ["%s_%d.%s" % (n, k, ext) for n in ("a", "d") for k in (0, 1)]
+        for n in ("a", "d"):
+            for k in (0, 1):
+                f = "%s_%d.%s" % (n, k, ext)
+                assert open(tmp_path / "o_full" / sub / f, "rb").read() == open(tmp_path / "o_clean" / sub / f, "rb").read(), f
+    env = dict(os.environ, MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = _run_cli(root, ["--base", str(tmp_path / "full"), "--out", str(tmp_path / "o_two")] + common, env=env, nproc=2, port=29552)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert sorted(open(tmp_path / "o_two" / "skipped.txt").read().splitlines()) == sorted(open(tmp_path / "o_full" / "skipped.txt").read().splitlines())
+    for sub in ("flows", "dst_images", "src_images"):
+        for f in os.listdir(tmp_path / "o_full" / sub):
+            assert open(tmp_path / "o_full" / sub / f, "rb").read() == open(tmp_path / "o_two" / sub / f, "rb").read(), f
+
+
+def test_cli_resume_and_defaults(dev, tmp_path):
+    """--resume re-renders only what is missing and reproduces the same bytes; the default producer is the network, and a missing
+    checkpoint is an error, not a silent switch to another data generator."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _toy_dataset(tmp_path / "data", ["a", "b", "c"])
+    common = ["--base", str(tmp_path / "data"), "--width", "64", "--height", "48", "--repeat", "2", "--planes", "16", "--mpi-from", "disparity"]
+    out = tmp_path / "out"
+    r = _run_cli(root, common + ["--out", str(out)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    want = {(sub, f): open(out / sub / f, "rb").read() for sub in ("flows", "dst_images", "src_images") for f in os.listdir(out / sub)}
+    assert len(want) == 18
+    os.remove(out / "flows" / "b_1.flo")                                   # image b is incomplete now
+    stamp = os.path.getmtime(out / "flows" / "a_0.flo")
+    r = _run_cli(root, common + ["--out", str(out), "--resume"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "resume: 2 image(s) already complete" in r.stdout and "pairs 2 " in r.stdout
+    assert os.path.getmtime(out / "flows" / "a_0.flo") == stamp            # untouched
+    for (sub, f), data in want.items():
+        assert open(out / sub / f, "rb").read() == data, (sub, f)
+    r = _run_cli(root, ["--base", str(tmp_path / "data"), "--out", str(tmp_path / "o2"), "--width", "64", "--height", "48"])
+    assert r.returncode != 0 and "checkpoint" in (r.stderr + r.stdout) and "--mpi-from" in (r.stderr + r.stdout)
+
+
+def test_cli_builtin_inpaint_on_the_writer_threads(dev, tmp_path, oracle):
+    """--inpaint builtin: the frame leaves the GPU unfilled and a writer thread runs the restated cv2.inpaint (NS, radius 3) before
+    encoding.  The written frame equals the oracle's NS fill of the --inpaint none frame, with the holes being the white pixels the
+    merge left (utils/utils.py:273-286)."""
+    import os
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _toy_dataset(tmp_path / "data", ["a"])
+    common = ["--base", str(tmp_path / "data"), "--width", "64", "--height", "48", "--repeat", "1", "--planes", "16", "--mpi-from", "disparity"]
+    for mode in ("none", "builtin"):
+        r = _run_cli(root, common + ["--out", str(tmp_path / mode), "--inpaint", mode])
+        assert r.returncode == 0, r.stderr[-3000:]
+    raw = np.array(Image.open(tmp_path / "none" / "dst_images" / "a_0.png"))[:, :, ::-1].copy()          # file is RGB, the frame BGR
+    filled = np.array(Image.open(tmp_path / "builtin" / "dst_images" / "a_0.png"))[:, :, ::-1].copy()
+    hole = (raw != filled).any(-1)
+    assert hole.sum() > 0 and (raw[hole] == 255).all()                     # only white (unrendered) pixels were changed
+    assert open(tmp_path / "none" / "flows" / "a_0.flo", "rb").read() == open(tmp_path / "builtin" / "flows" / "a_0.flo", "rb").read()
 
 
 def test_cli_with_network_producer(dev, tmp_path):

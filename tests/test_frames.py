@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import bits_equal, load_golden
+
 
 def _rgb(h, w, seed=0):
     rs = np.random.RandomState(seed)
@@ -28,7 +30,9 @@ def test_png_writer_round_trips_through_pillow(tmp_path, shape):
     assert data[:8] == b"\x89PNG\r\n\x1a\n"
 
 
-def test_input_prefetcher_matches_the_loaders(tmp_path):
+def test_input_prefetcher_yields_what_the_reference_loaders_decode(tmp_path):
+    """u8 arrays of the OWNED images, in listing order: image = PIL RGB (utils/utils.py:36), disparity = cv2.imread(path, 0)
+    (:43; here 8-bit grey files, where that is the stored bytes), mask = PIL "L" (gen_3dphoto_dynamic_v2.py:83)."""
     from PIL import Image
     from mpiflow_amd import io_formats
     from mpiflow_amd.utils import utils as U
@@ -42,23 +46,96 @@ def test_input_prefetcher_matches_the_loaders(tmp_path):
         Image.fromarray(_rgb(20, 30, 10 + k)[..., 0]).save(dirs["disps"] / n)
         Image.fromarray((_rgb(20, 30, 20 + k)[..., 0] // 100).astype(np.uint8)).save(dirs["masks"] / n)
     order = sorted(names)
-    got = list(io_formats.InputPrefetcher(order, str(dirs["images"]), str(dirs["disps"]), str(dirs["masks"]), owned=lambda i: i != 1))
-    assert [g[1] for g in got] == order and [g[0] for g in got] == [0, 1, 2]
-    for i, n, mask, image, disp in got:
-        assert np.array_equal(mask, np.array(Image.open(dirs["masks"] / n).convert("L")))
-        if i == 1:
-            assert image is None and disp is None
-            continue
-        assert np.array_equal(image, U.image_to_tensor(str(dirs["images"] / n))[0].numpy())
-        assert np.array_equal(disp, U.disparity_to_tensor(str(dirs["disps"] / n))[0].numpy())
+    got = list(io_formats.InputPrefetcher(order, str(dirs["images"]), str(dirs["disps"]), str(dirs["masks"]), [0, 2], pin=False))
+    assert [g["i"] for g in got] == [0, 2] and [g["name"] for g in got] == [order[0], order[2]]
+    for g in got:
+        n = g["name"]
+        assert g["error"] is None
+        assert np.array_equal(g["ids_u8"], np.array(Image.open(dirs["masks"] / n).convert("L")))
+        assert np.array_equal(g["rgb_u8"], np.array(Image.open(dirs["images"] / n).convert("RGB")))
+        assert np.array_equal(g["disp_u8"], np.array(Image.open(dirs["disps"] / n)))
+        # the float tensors of the reference's loaders are these bytes / 255
+        assert np.array_equal(U.image_to_tensor(str(dirs["images"] / n))[0].numpy(), g["rgb_u8"].transpose(2, 0, 1).astype(np.float32) / np.float32(255))
+        assert np.array_equal(U.disparity_to_tensor(str(dirs["disps"] / n))[0, 0].numpy(), (g["disp_u8"] / 255).astype(np.float32))
 
 
-def test_input_prefetcher_surfaces_errors(tmp_path):
+def test_input_prefetcher_reports_errors_per_image(tmp_path):
+    from PIL import Image
     from mpiflow_amd import io_formats
-    with pytest.raises(FileNotFoundError):
-        list(io_formats.InputPrefetcher(["missing.png"], str(tmp_path), str(tmp_path), str(tmp_path), owned=lambda i: True))
+    for d in ("images", "disps", "masks"):
+        (tmp_path / d).mkdir()
+        Image.fromarray(_rgb(8, 9, 1)[..., 0]).save(tmp_path / d / "ok.png")
+    Image.fromarray(_rgb(8, 9, 1)).save(tmp_path / "images" / "ok.png")
+    (tmp_path / "masks" / "bad.png").write_bytes(b"not a png")
+    got = list(io_formats.InputPrefetcher(["bad.png", "missing.png", "ok.png"], str(tmp_path / "images"), str(tmp_path / "disps"),
+                                          str(tmp_path / "masks"), [0, 1, 2], pin=False))
+    assert got[0]["error"] is not None and got[1]["error"] is not None and got[2]["error"] is None
+    assert io_formats.mask_max_of_file(str(tmp_path / "masks" / "bad.png")) == -1
 
 
+def test_disparity_decode_follows_cv2_imread_grayscale(tmp_path):
+    """cv2.imread(path, 0) (utils/utils.py:43): 16-bit grey -> high byte (PIL's convert("L") would saturate), colour PNG -> libpng's
+    fixed-point grey, 8-bit grey -> stored bytes.  Compared with the real cv2 when it is installed."""
+    from PIL import Image
+    from mpiflow_amd import io_formats
+    ramp = (np.arange(300 * 200, dtype=np.uint32).reshape(200, 300) * 65535 // (300 * 200 - 1)).astype(np.uint16)
+    Image.fromarray(ramp).save(tmp_path / "d16.png")
+    got = io_formats.read_disparity_u8(str(tmp_path / "d16.png"))
+    assert got.dtype == np.uint8 and np.array_equal(got, (ramp >> 8).astype(np.uint8))
+    assert (got == 255).mean() < 0.01                      # not saturated: the ADVICE.md failure mode (99.6 % of pixels at 255)
+    g8 = _rgb(40, 50, 3)[..., 0]
+    Image.fromarray(g8).save(tmp_path / "d8.png")
+    assert np.array_equal(io_formats.read_disparity_u8(str(tmp_path / "d8.png")), g8)
+    rgb = _rgb(40, 50, 4)
+    Image.fromarray(rgb).save(tmp_path / "dc.png")
+    c = rgb.astype(np.uint32)
+    assert np.array_equal(io_formats.read_disparity_u8(str(tmp_path / "dc.png")),
+                          ((c[..., 0] * 9798 + c[..., 1] * 19235 + c[..., 2] * 3735 + 16384) >> 15).astype(np.uint8))
+    try:
+        import cv2
+    except Exception:
+        return                                             # OpenCV absent: the decoder's parity with cv2 stays unpinned
+    for f in ("d16.png", "d8.png", "dc.png"):
+        assert np.array_equal(io_formats.read_disparity_u8(str(tmp_path / f)), cv2.imread(str(tmp_path / f), 0)), f
+
+
+def test_input_stage_oracle_matches_the_reference_golden(oracle):
+    """ToTensor / `/255` / (ids == k) + F.interpolate(bilinear, align_corners=True): the oracle's restatement vs what the
+    reference's own loaders and torch-CPU produced (tests/golden/make_golden.py: inputs), bit for bit, for both ATen kernels."""
+    g = load_golden("input_stage")
+    for tag, size in (("big", (96, 160)), ("small", (40, 72))):
+        out = oracle.prepare_inputs(g["rgb_u8"], g["disp_u8"], size=size)
+        assert bits_equal(out["image"], g["image_" + tag]) == 0 and bits_equal(out["disp"], g["disp_" + tag]) == 0
+        for k in (1, 2, 3):
+            m = oracle.prepare_inputs(ids_u8_hw=g["ids_u8"], obj_index=k, size=size)["mask"]
+            assert bits_equal(m, g["mask%d_%s" % (k, tag)]) == 0
+    assert int(g["mask_max"]) == int(g["ids_u8"].max())
+
+
+@pytest.mark.gpu
+def test_input_stage_kernel_matches_the_reference_golden(oracle):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mpiflow_amd import ops
+    dev = torch.device("cuda:0")
+    g = load_golden("input_stage")
+    rgb, dsp, ids = (torch.from_numpy(g[k]).to(dev) for k in ("rgb_u8", "disp_u8", "ids_u8"))
+    for tag, size in (("big", (96, 160)), ("small", (40, 72))):
+        out = ops.prepare_inputs(rgb_u8=rgb, disp_u8=dsp, size=size)
+        assert bits_equal(out["image"].cpu().numpy(), g["image_" + tag]) == 0
+        assert bits_equal(out["disp"].cpu().numpy(), g["disp_" + tag]) == 0
+        for k in (1, 2, 3):
+            m = ops.prepare_inputs(ids_u8=ids, obj_index=k, size=size)["mask"]
+            assert bits_equal(m.cpu().numpy(), g["mask%d_%s" % (k, tag)]) == 0
+    # a KITTI-sized frame against the oracle (itself pinned above and against torch in the build container)
+    rs = np.random.RandomState(7)
+    rgb = (rs.rand(375, 1242, 3) * 256).astype(np.uint8)
+    dsp = (rs.rand(375, 1242) * 256).astype(np.uint8)
+    ids = (rs.rand(375, 1242) * 4).astype(np.uint8)
+    want = oracle.prepare_inputs(rgb, dsp, ids, obj_index=2, size=(384, 1280))
+    got = ops.prepare_inputs(torch.from_numpy(rgb).to(dev), torch.from_numpy(dsp).to(dev), torch.from_numpy(ids).to(dev), obj_index=2, size=(384, 1280))
+    for k in ("image", "disp", "mask"):
+        assert bits_equal(got[k].cpu().numpy(), want[k]) == 0, k
 def _peel_reference(img, hole):
     """Plain restatement of the onion peel: repeat full-image passes on a copy of the previous state."""
     img, hole = img.astype(np.int64).copy(), hole.astype(bool).copy()

@@ -72,7 +72,7 @@ def parse(argv=None):
                         "builtin = the same algorithm restated in libmpiflow_hip.so, run on the writer threads; peel (alias hip) = the onion-peel "
                         "GPU kernel, NOT OpenCV's algorithm; none = leave holes white")
     p.add_argument("--resume", action="store_true", help="skip images whose outputs (all --repeat pairs) already exist; the RNG schedule is unaffected")
-    p.add_argument("--writers", type=int, default=8, help="writer threads (hole fill, PNG encode and file I/O overlap the GPU)")
+    p.add_argument("--writers", type=int, default=max(8, min(32, (os.cpu_count() or 8) // 4)), help="writer threads (hole fill, PNG encode and file I/O overlap the GPU)")
     p.add_argument("--lanes", type=int, default=1,
                    help="images in flight on this GPU, each with its own streams, plane-stack buffer and network graph (same files for any "
                         "value).  Measured on MI355X: 1 lane 359 pairs/s, 2 lanes 267, 3 lanes 298 - the kernels are sized to fill the GPU on "

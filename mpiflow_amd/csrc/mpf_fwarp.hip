@@ -27,6 +27,15 @@
 
 // ---- moving_obj.py:29-30 : depth = 1/(disp + 0.005), clamped to 100 --------------------------------------------------
 
+// `p1.cpu().long()` (moving_obj.py:121) is an x86 cvttss2si: values that do not fit an int64 - NaN, +-inf, |v| >= 2^63, reachable
+// when q.z + 1e-7 comes near 0 in Project3D - become INT64_MIN, which the following clamp turns into 0.  The GPU's conversion
+// saturates instead (+huge -> INT64_MAX -> clamped to w-1), so the out-of-range case is spelled out.
+__device__ __forceinline__ int64_t mpf_trunc_like_x86(float v)
+{
+    return (v >= -9223372036854775808.0f && v < 9223372036854775808.0f) ? (int64_t)v : INT64_MIN;
+}
+
+
 __global__ void __launch_bounds__(256)
 k_disp_to_depth(const float *__restrict__ disp, int64_t N, float *__restrict__ depth)
 {
@@ -60,7 +69,7 @@ k_select_truncate(const float *__restrict__ p_static, const float *__restrict__ 
     const float px = (nx + 1.0f) / 2.0f * (float)(W - 1);               // :115-117
     const float py = (ny + 1.0f) / 2.0f * (float)(H - 1);
     p1[2 * n] = px; p1[2 * n + 1] = py;
-    int64_t tx = (int64_t)px, ty = (int64_t)py;                         // .long() truncates toward zero, :121-122
+    int64_t tx = mpf_trunc_like_x86(px), ty = mpf_trunc_like_x86(py);   // .long() truncates toward zero, :121-122
     tx = tx > W - 1 ? W - 1 : tx; tx = tx < 0 ? 0 : tx;
     ty = ty > H - 1 ? H - 1 : ty; ty = ty < 0 ? 0 : ty;
     safe_x[n] = tx; safe_y[n] = ty;
@@ -120,7 +129,7 @@ k_moving_object_project(const float *__restrict__ disp, MpfMoProj m, const float
     const float px = (nx + 1.0f) / 2.0f * (float)(W - 1);               // :115-117
     const float py = (ny + 1.0f) / 2.0f * (float)(H - 1);
     p1[2 * n] = px; p1[2 * n + 1] = py;
-    int64_t tx = (int64_t)px, ty = (int64_t)py;                         // :121-122
+    int64_t tx = mpf_trunc_like_x86(px), ty = mpf_trunc_like_x86(py);   // :121-122
     tx = tx > W - 1 ? W - 1 : tx; tx = tx < 0 ? 0 : tx;
     ty = ty > H - 1 ? H - 1 : ty; ty = ty < 0 ? 0 : ty;
     safe_x[n] = tx; safe_y[n] = ty;

@@ -46,6 +46,14 @@ void orc_backproject_project(const float *depth, const float *inv_k, const float
         }
 }
 
+/* torch's float -> int64 on the reference's x86 host is cvttss2si: NaN, +-inf and |v| >= 2^63 give INT64_MIN (clamped to 0 next).
+ * Written out so that the oracle does not lean on undefined behaviour (checked against torch-CPU: tests/test_oracle_golden.py). */
+static int64_t trunc_like_x86(float v)
+{
+    return (v >= -9223372036854775808.0f && v < 9223372036854775808.0f) ? (int64_t)v : INT64_MIN;
+}
+
+
 /* moving_obj.py:108-124 and :153 */
 void orc_select_truncate(const float *p_static, const float *z_static, const float *p_obj, const float *z_obj,
                          const float *inst, int H, int W,
@@ -60,7 +68,7 @@ void orc_select_truncate(const float *p_static, const float *z_static, const flo
         float px = (nx + 1.0f) / 2.0f * (float)(W - 1);              /* :115-117 */
         float py = (ny + 1.0f) / 2.0f * (float)(H - 1);
         p1[2 * n] = px; p1[2 * n + 1] = py;
-        int64_t tx = (int64_t)px, ty = (int64_t)py;                  /* .long(): truncation toward zero, :121-122 */
+        int64_t tx = trunc_like_x86(px), ty = trunc_like_x86(py);   /* .long(): truncation toward zero, :121-122 */
         if (tx > W - 1) tx = W - 1;
         if (tx < 0) tx = 0;
         if (ty > H - 1) ty = H - 1;

@@ -8,12 +8,14 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-sub"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub > $OUT/pmc_write.log 2>&1
 cd $REPO
 find $OUT -type f | head -50
 python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+python profiles/update_traffic.py $OUT > $OUT/traffic.log 2>&1
+cat $OUT/traffic.log

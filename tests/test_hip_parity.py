@@ -514,3 +514,35 @@ def test_alpha_composition_and_xyz_from_depth(dev, oracle):
     got = ops.alpha_composite(torch.from_numpy(al[:, 0, 0]).to(dev), torch.from_numpy(val[:, :, 0]).to(dev), want_cumprod_eps=True)
     assert bits_equal(got["out"].cpu().numpy(), ref["out"][:, 0]) == 0 and bits_equal(got["weights"].cpu().numpy(), ref["weights"][:, 0]) == 0
     assert bits_equal(got["cumprod_eps"].cpu().numpy(), ref["cumprod_eps"][:, 0]) == 0
+
+
+def test_select_truncate_degenerate_points(dev, oracle):
+    """NaN / +-inf / |p| >= 2^63 projected coordinates (z ~ 0 in Project3D): the kernel reproduces the x86 `.long()` + clamp of
+    moving_obj.py:121-122 (the GPU's own conversion saturates +huge to INT64_MAX -> w-1; the reference's gives INT64_MIN -> 0)."""
+    from mpiflow_amd import ops
+    H, W = 8, 16
+    vals = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 9.3e18, -9.3e18, 9.2e18, 3.7, -3.7, 5.0, 2.0e9, -2.0e9, 0.0, 1e-9, 4.999], np.float32)
+    rs = np.random.RandomState(3)
+    nrm = rs.choice(vals, size=(H, W, 2)).astype(np.float32)
+    nrm2 = rs.choice(vals, size=(H, W, 2)).astype(np.float32)
+    z = rs.rand(H, W).astype(np.float32)
+    inst = (rs.rand(H, W) < 0.5).astype(np.float32)
+    want = oracle.select_truncate(nrm, z, nrm2, z, inst)
+    got = ops.select_truncate(T(nrm, dev), T(z, dev), T(nrm2, dev), T(z, dev), T(inst, dev))
+    for a, b in zip(got, want):
+        a = N(a)
+        assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b)
+    # and through the fused projection kernel: a disparity map whose depth lands the projection on z + 1e-7 == 0
+    import torch
+    K = np.array([[0.58 * W, 0, 0.5 * W], [0, 0.58 * H, 0.5 * H], [0, 0, 1]], np.float32)
+    iK = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    disp = np.full((H, W), 0.5, np.float32)
+    depth = np.float32(1.0) / (disp + np.float32(0.005))
+    Pobj = np.concatenate([K, np.zeros((3, 1), np.float32)], 1)
+    Pobj[2, 3] = -depth[0, 0] - np.float32(1e-7)                         # object pose translating every point onto z + eps = 0
+    Pst = np.concatenate([K, np.zeros((3, 1), np.float32)], 1)
+    instm = np.ones((H, W), np.float32)
+    p1, z1, sx, sy, fl = ops.moving_object_project(T(disp, dev), iK, torch.from_numpy(Pst), torch.from_numpy(Pobj), T(instm, dev))
+    px = N(p1)[..., 0]
+    bad = ~np.isfinite(px) | (np.abs(px) >= 9.2e18)
+    assert (N(sx)[bad] == 0).all() and (N(sy)[~np.isfinite(N(p1)[..., 1]) | (np.abs(N(p1)[..., 1]) >= 9.2e18)] == 0).all()

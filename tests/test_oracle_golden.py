@@ -267,3 +267,24 @@ def test_alpha_composition_against_reference(oracle):
     d = oracle.alpha_composition(sigma, xyz[:, 2:3])
     assert bits_equal(d["out"], g["depth"][0]) == 0
     assert str(g["render_use_alpha_raises"]) == "UnboundLocalError"
+
+
+def test_select_truncate_degenerate_points_follow_torch_long(oracle):
+    """moving_obj.py:121-122 `torch.clamp(p1.cpu().long(), 0, w-1)`: NaN, +-inf and |p| >= 2^63 (q.z + 1e-7 near 0 in Project3D)
+    become INT64_MIN on the reference's x86 host and are clamped to 0 - checked against torch-CPU itself."""
+    import torch
+    H, W = 4, 6
+    vals = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 9.3e18, -9.3e18, 9.2e18, 3.7, -3.7, 5.0, 2.0e9, -2.0e9, 0.0, 1e-9, 4.999], np.float32)
+    px = np.resize(vals, H * W).astype(np.float32)
+    py = np.resize(vals[::-1], H * W).astype(np.float32)
+    # invert the pixel-unit mapping of :115-117 so that select_truncate reproduces px, py exactly where that is possible
+    p = np.stack([px, py], -1).reshape(H, W, 2)
+    with np.errstate(all="ignore"):
+        nrm = np.stack([p[..., 0] / np.float32(W - 1) * 2 - 1, p[..., 1] / np.float32(H - 1) * 2 - 1], -1).astype(np.float32)
+    z = np.ones((H, W), np.float32)
+    p1, z1, sx, sy, fl = oracle.select_truncate(nrm, z, nrm, z, np.zeros((H, W), np.float32))
+    t = torch.from_numpy(p1.copy())
+    want_x = torch.clamp(t[..., 0].long(), 0, W - 1).numpy()
+    want_y = torch.clamp(t[..., 1].long(), 0, H - 1).numpy()
+    assert np.array_equal(sx, want_x) and np.array_equal(sy, want_y)
+    assert (sx[~np.isfinite(p1[..., 0])] == 0).all()

@@ -18,17 +18,19 @@ for i in range(n_img):
     Image.fromarray((255 * (0.1 + 0.8 * yy / 375)).astype(np.uint8)).save(os.path.join(base, "disps", "%04d.png" % i))
     m = np.zeros((375, 1242), np.uint8); m[150:300, 300:600] = 1; m[200:330, 800:1000] = 2
     Image.fromarray(m).save(os.path.join(base, "masks", "%04d.png" % i))
-configs = [("hip engine, 16 writers (warm-up run)", ["--model-engine", "hip", "--writers", "16"]),
-           ("hip engine, 16 writers", ["--model-engine", "hip", "--writers", "16"]),
-           ("hip engine, 16 writers, 2 lanes", ["--model-engine", "hip", "--writers", "16", "--lanes", "2"]),
-           ("hip engine, 4 writers", ["--model-engine", "hip", "--writers", "4"])]
+configs = [("hip engine, peel fill on the GPU, 16 writers (warm-up run)", ["--model-engine", "hip", "--writers", "16", "--inpaint", "peel"]),
+           ("hip engine, peel fill on the GPU, 16 writers", ["--model-engine", "hip", "--writers", "16", "--inpaint", "peel"]),
+           ("hip engine, no fill, 16 writers", ["--model-engine", "hip", "--writers", "16", "--inpaint", "none"]),
+           ("hip engine, cv2.inpaint NS restated on 8 writer threads", ["--model-engine", "hip", "--writers", "8", "--inpaint", "builtin"]),
+           ("hip engine, cv2.inpaint NS restated on 32 writer threads", ["--model-engine", "hip", "--writers", "32", "--inpaint", "builtin"]),
+           ("hip engine, cv2.inpaint NS restated on 96 writer threads", ["--model-engine", "hip", "--writers", "96", "--inpaint", "builtin"])]
 if "--torch" in sys.argv:
-    configs.append(("torch fp16, 16 writers", ["--model-engine", "torch", "--model-dtype", "fp16", "--writers", "16"]))
+    configs.append(("torch fp16, 16 writers", ["--model-engine", "torch", "--model-dtype", "fp16", "--writers", "16", "--inpaint", "peel"]))
 for label, extra in configs:
     out = os.path.join(tmp, "out_" + label.replace(" ", "_").replace(",", ""))
     t0 = time.perf_counter()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "gen_3dphoto_dynamic.py"), "--base", base, "--out", out, "--repeat", "5", "--mpi-from", "model",
-                        "--ckpt_path", "random:0", "--inpaint", "hip"] + extra, capture_output=True, text=True)
+                        "--ckpt_path", "random:0"] + extra, capture_output=True, text=True)
     dt = time.perf_counter() - t0
     last = [l for l in r.stdout.splitlines() if l.startswith("pairs")]
     print("%-34s process %.1f s | %s" % (label, dt, last[-1] if last else r.stderr[-400:]))

@@ -324,20 +324,20 @@ def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, m
             renderer.blend(mpi, image[0], K, planes, cum_mask=cum_mask)      # once per image; the `repeat` pairs below reuse it
             ring.submit_source(ops.png_scanlines(renderer.src_u8), [os.path.join(out, "src_images", f"{name}_{r}.png") for r in range(opt.repeat)])  # :122
         poses = host_math.poses_from_parameters(pose_params)               # the image's 2 x repeat poses in one batched evaluation
-        for r in range(opt.repeat):
-            obj_index, cam_ext_dynamic, cam_ext = obj_indices[r], poses[2 * r], poses[2 * r + 1]
-            with lap("instance mask"):
-                obj_mask = ops.prepare_inputs(ids_u8=ids, obj_index=obj_index, size=(H, W))["mask"]             # :102-105
-            with lap("render pair"):
-                res = pipeline.render_pair(image[0], obj_mask, mpi, planes, K, cam_ext, cam_ext_dynamic, renderer=renderer,
-                                           cum_mask=cum_mask, reuse_blend=True)
-            # the tail of a pair (scanlines / hole fill hand-off, statistics, copies to the host) runs on a second stream, so it
-            # overlaps the next pair's render
-            tail_ready.record()
-            for tns in (res["frame_mix"], res["fill_mask"], res["flow_mix"]):
-                tns.record_stream(tail_stream)
-            with torch.cuda.stream(tail_stream):
-                tail_stream.wait_event(tail_ready)
+        with lap("instance masks"):
+            obj_masks = [ops.prepare_inputs(ids_u8=ids, obj_index=k, size=(H, W))["mask"] for k in obj_indices]      # :102-105
+        with lap("render pairs"):
+            # utils.py:207-208 draws the dynamic pose first; the camera pose renders with obj_mask, the dynamic one with 1 - obj_mask
+            results = renderer.run_pairs(mpi, image[0], K, planes, obj_masks, [(poses[2 * r + 1], poses[2 * r]) for r in range(opt.repeat)],
+                                         cum_mask=cum_mask)
+        # the tail of the pairs (scanlines / hole-fill hand-off, statistics, copies to the host) runs on a second stream, so it
+        # overlaps the next image's network and render
+        tail_ready.record()
+        with torch.cuda.stream(tail_stream):
+            tail_stream.wait_event(tail_ready)
+            for r, res in enumerate(results):
+                for tns in (res["frame_mix"], res["fill_mask"], res["flow_mix"]):
+                    tns.record_stream(tail_stream)
                 flo_path, png_path = os.path.join(out, "flows", f"{name}_{r}.flo"), os.path.join(out, "dst_images", f"{name}_{r}.png")   # :120-121
                 with lap("hole fill / PNG scanlines + hand-off to the writers"):
                     dstats.add(res["flow_mix"], res["fill_mask"])

@@ -39,7 +39,11 @@ class PairRenderer:
         self.quads = [torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)]    # obj_mask, 1 - obj_mask
         self.src_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         self.n_views = n_views
-        self.multi_view = True      # all Stage B views of a pair in ONE launch (mpf_warp_composite_views); False: one launch per view
+        # all Stage B views of a pair in ONE launch (mpf_warp_composite_views) where that wins: measured x1.06-1.09 per pair up to
+        # 64 x 640 x 960 (x1.24 for the 10 views of a `repeat` loop at 64 x 384 x 1280), x0.97 at 128 x 1024 x 1536 (25 MB per plane:
+        # the two views no longer meet in the caches) - profiles/r2/stage_b_views_shapes.log
+        self.multi_view = H * W * 16 <= (16 << 20)
+        self._pair_bufs = []
 
     # -- host side: small matrices ---------------------------------------------------------------------------------
     def _constants(self, K, disparity):
@@ -92,6 +96,42 @@ class PairRenderer:
                 ops.warp_composite(self.rgba, self.quads[1 if complement[v] else 0], dparams=prep["warp"][v], out=self.views[v],
                                    interleaved=2)
         return self.flows, self.views
+
+
+    # -- all pairs of one image --------------------------------------------------------------------------------------------
+    def _pair_buffers(self, n):
+        f32, dev, H, W = torch.float32, self.device, self.H, self.W
+        while len(self._pair_bufs) < n:
+            self._pair_bufs.append(dict(
+                flows=torch.empty((2, 2, H, W), dtype=f32, device=dev), quads=[torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)],
+                views=[dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), objmask=torch.empty((H, W), dtype=f32, device=dev)) for _ in range(2)]))
+        return self._pair_bufs[:n]
+
+    def run_pairs(self, mpi, image, K, disparity, obj_masks, poses, cum_mask=None, thresh=MASK_THRESH):
+        """The `repeat` pairs of ONE image (gen_3dphoto_dynamic_v2.py:99-118) whose blended stack is already in self.rgba (blend()):
+        per pair a flow-only Stage A+C (both flows + the mask quads), then ALL their posed views - 2 per pair - in as few Stage B
+        launches as 16 views per launch allow, then a merge per pair.  obj_masks: R tensors [H,W]; poses: R (G_cam, G_dyn) tuples.
+        Same results, bit for bit, as R calls of render_pair(..., reuse_blend=True).  Returns R dicts(flow_mix, frame_mix, fill_mask)."""
+        R = len(obj_masks)
+        bufs = self._pair_buffers(R)
+        views = []
+        for om, (G_cam, G_dyn), b in zip(obj_masks, poses, bufs):
+            prep = self.prepare(K, disparity, [G_cam, G_dyn])
+            ops.src_blend_flow(mpi, image, out_rgba=None, want_rgba=False, out_flows=b["flows"], dparams=prep["blend"], P=2, obj_mask=om,
+                               quads=b["quads"][0], quads_complement=b["quads"][1], cum_mask=cum_mask)
+            views += [dict(dparams=prep["warp"][v], quads=b["quads"][v], out=b["views"][v]) for v in range(2)]
+        if self.multi_view:
+            for i in range(0, len(views), 16):
+                ops.warp_composite_views(self.rgba, views[i:i + 16], interleaved=2)
+        else:
+            for v in views:
+                ops.warp_composite(self.rgba, v["quads"], dparams=v["dparams"], out=v["out"], interleaved=2)
+        out = []
+        for om, b in zip(obj_masks, bufs):
+            v = b["views"]
+            flow_mix, frame_mix, fill = ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"][0], b["flows"][1], om, thresh)
+            out.append(dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill))
+        return out
 
 
 def hard_flows(mpi_S4HW, disparity_S, K, poses):

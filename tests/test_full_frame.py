@@ -268,6 +268,33 @@ def test_lds_staged_variant_bit_identical(dev, S, H, W, V, mask, aux, extreme):
         _lib.check(lib.mpf_tune(b"stage_b", 1))
 
 
+@pytest.mark.parametrize("S,H,W,R", [(8, 32, 48, 3), (16, 40, 72, 9)])
+def test_run_pairs_equals_render_pair(dev, oracle, S, H, W, R):
+    """PairRenderer.run_pairs (every view of an image's `repeat` pairs in one Stage B launch, 16 per launch) == R x render_pair."""
+    from mpiflow_amd import host_math, pipeline, synth
+    inp = synth.make_inputs(S, H, W, seed=S + R, kind="white")
+    rng = random.Random(R)
+    img, mpi = T(inp["image"], dev), T(inp["mpi"], dev)
+    masks = [T(np.roll(inp["obj_mask"], 3 * r, axis=1), dev) for r in range(R)]
+    poses = []
+    for r in range(R):
+        dyn = host_math.generate_random_pose(0.15, rng=rng)
+        cam = host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng)
+        poses.append((cam, dyn))
+    ra, rb = pipeline.PairRenderer(S, H, W, dev), pipeline.PairRenderer(S, H, W, dev)
+    want = []
+    for r in range(R):
+        o = pipeline.render_pair(img, masks[r], mpi, inp["disparity"], inp["K"], poses[r][0], poses[r][1], renderer=ra)
+        want.append({k: N(o[k]) for k in ("flow_mix", "frame_mix", "fill_mask")})
+    rb.blend(mpi, img, inp["K"], inp["disparity"])
+    for mv in (True, False):
+        rb.multi_view = mv
+        got = rb.run_pairs(mpi, img, inp["K"], inp["disparity"], masks, poses)
+        for r in range(R):
+            for k in want[r]:
+                assert bits_equal(N(got[r][k]), want[r][k]) == 0, (mv, r, k)
+
+
 def test_views_launch_rejects_bad_arguments(dev):
     from mpiflow_amd import _lib, ops
     S, H, W = 4, 8, 16

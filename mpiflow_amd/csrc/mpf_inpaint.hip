@@ -79,20 +79,33 @@ inline float arrival(Field &g, const std::vector<uint8_t> &flags, int i, int j)
     return std::min(std::min(a, b), std::min(c, d));
 }
 
+// grey dilation with a (2r+1)-cross (r = 1 only) or a (2r+1)^2 box; pixels outside the array never win.  The box is separable:
+// a running maximum along the rows, then along the columns.
 void dilate(const std::vector<uint8_t> &src, std::vector<uint8_t> &dst, int er, int ec, int r, bool cross)
 {
+    if (cross) {
+        for (int i = 0; i < er; ++i)
+            for (int j = 0; j < ec; ++j) {
+                uint8_t m = src[(size_t)i * ec + j];
+                if (i > 0) m = std::max(m, src[(size_t)(i - 1) * ec + j]);
+                if (i + 1 < er) m = std::max(m, src[(size_t)(i + 1) * ec + j]);
+                if (j > 0) m = std::max(m, src[(size_t)i * ec + j - 1]);
+                if (j + 1 < ec) m = std::max(m, src[(size_t)i * ec + j + 1]);
+                dst[(size_t)i * ec + j] = m;
+            }
+        return;
+    }
+    std::vector<uint8_t> tmp((size_t)er * ec);
     for (int i = 0; i < er; ++i)
         for (int j = 0; j < ec; ++j) {
             uint8_t m = 0;
-            for (int di = -r; di <= r; ++di) {
-                const int y = i + di;
-                if (y < 0 || y >= er) continue;
-                for (int dj = -r; dj <= r; ++dj) {
-                    const int x = j + dj;
-                    if (x < 0 || x >= ec || (cross && di != 0 && dj != 0)) continue;
-                    m = std::max(m, src[(size_t)y * ec + x]);
-                }
-            }
+            for (int x = std::max(j - r, 0); x <= std::min(j + r, ec - 1); ++x) m = std::max(m, src[(size_t)i * ec + x]);
+            tmp[(size_t)i * ec + j] = m;
+        }
+    for (int i = 0; i < er; ++i)
+        for (int j = 0; j < ec; ++j) {
+            uint8_t m = 0;
+            for (int y = std::max(i - r, 0); y <= std::min(i + r, er - 1); ++y) m = std::max(m, tmp[(size_t)y * ec + j]);
             dst[(size_t)i * ec + j] = m;
         }
 }
@@ -171,9 +184,12 @@ void fill(const uint8_t *img, const uint8_t *mask_in, int rows, int cols, int ra
             offs.push_back(o);
         }
     std::vector<uint8_t> &f = hole;                  // KNOWN / INSIDE, BAND once filled: the flags the fill rules test
+    const bool tiny = rows < 2 || cols < 2;                  // only then can OpenCV's index arithmetic leave the image (it reads out of bounds there)
     auto px = [&](int r, int c, int ch) -> int {
-        r = r < 0 ? 0 : (r > rows - 1 ? rows - 1 : r);     // only ever clamps for 1-pixel-wide images
-        c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+        if (__builtin_expect(tiny, 0)) {
+            r = r < 0 ? 0 : (r > rows - 1 ? rows - 1 : r);
+            c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+        }
         return out[((size_t)r * cols + c) * C + ch];
     };
     int ii, jj;

@@ -403,9 +403,10 @@ def test_cli_with_network_on_hip_engine(dev, tmp_path):
     assert not np.array_equal(flows[0], flows[1])                         # the replay really saw the second image
 
 
-def test_hard_flow_entry_point(dev):
-    """hard_flow=True: flow of the arg-max-weight plane.  A 1-ulp exp difference can move an arg-max between two planes with
-    (nearly) equal weights, so a small fraction of pixels may legitimately pick a different plane; the rest must match closely."""
+def test_hard_flow_entry_point(dev, oracle):
+    """hard_flow=True: flow of the arg-max-weight plane (mpi_rendering.py:126-130).  A 1-ulp exp difference (the reference's exp is MKL's)
+    can move the arg-max between two planes whose weights are equal to within rounding; every pixel that differs from the reference's
+    golden must be such a PROVEN near-tie (top-2 source-frame weights within 2e-6 relative), and there may be only a handful."""
     from mpiflow_amd import synth
     from mpiflow_amd.utils import utils as U
     g = load_golden("hard_flow")
@@ -420,7 +421,15 @@ def test_hard_flow_entry_point(dev):
     flow_mix, _, _, _ = U.render_3dphoto_dynamic(Opt, T(inp["image"], dev)[None], T(inp["obj_mask"], dev)[None, None], None, T(inp["mpi"], dev)[None],
                                                  T(inp["disparity"], dev)[None], K, K, name="g.png", hard_flow=True, inpaint="none")
     err = np.abs(flow_mix - g["flow_mix"]).max(axis=-1)
-    assert (err < 1e-4).mean() > 0.995, "hard flow differs at %.2f%% of pixels" % (100 * (err >= 1e-4).mean())
+    bad = err >= 1e-4
+    d = oracle.plane_depths(inp["disparity"])
+    w = oracle.volume_render(None, inp["mpi"][:, 3:], oracle.src_xyz(oracle.k_inverse(inp["K"]), d, H, W))["weights"]      # [S,H,W]
+    top2 = np.sort(w, axis=0)[-2:]
+    near_tie = (top2[1] - top2[0]) <= 2e-6 * np.maximum(top2[1], 1e-30)
+    assert (bad & ~near_tie).sum() == 0, "hard flow differs at %d pixels that are not arg-max ties" % int((bad & ~near_tie).sum())
+    assert bad.sum() <= max(4, int(0.005 * H * W)), "hard flow differs at %d of %d pixels" % (int(bad.sum()), H * W)
+    print("\n[hard_flow] %d of %d pixels pick another plane than the reference; all are arg-max near-ties (%d near-tie pixels in the frame)"
+          % (int(bad.sum()), H * W, int(near_tie.sum())))
 
 
 def test_pipeline_is_deterministic_and_graph_capturable(dev):

@@ -267,13 +267,27 @@ MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts 
 
 struct MpfRaw4 { float4 t00, t01, t10, t11, mq; };
 
-template <bool HAS_MASK>
-MPF_DEV void mpf_fetch2(const char *__restrict__ plane, const char *__restrict__ quads, const MpfGeom &g, MpfRaw4 &r)
+typedef unsigned mpf_v4u __attribute__((ext_vector_type(4)));
+
+// TP (tail-padded stack): the four taps are ONE address computation - raw buffer loads take the tap's +16 as the instruction's
+// immediate offset and the +row as its scalar offset, where flat/global loads would need three more 32-bit VALU adds per plane
+// (the compiler cannot fold them: a wrapped 32-bit offset would address differently).
+template <bool HAS_MASK, bool TP>
+MPF_DEV void mpf_fetch2(const char *__restrict__ plane, const char *__restrict__ quads, const MpfGeom &g, MpfRaw4 &r, const unsigned row_bytes,
+                        const unsigned span)
 {
-    r.t00 = *reinterpret_cast<const float4 *>(plane + g.b00);
-    r.t01 = *reinterpret_cast<const float4 *>(plane + g.b01);
-    r.t10 = *reinterpret_cast<const float4 *>(plane + g.b10);
-    r.t11 = *reinterpret_cast<const float4 *>(plane + g.b11);
+    if (TP) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(plane), 0, span, 0x00020000);
+        r.t00 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.b00, 0, 0));
+        r.t01 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.b00 + 16u, 0, 0));
+        r.t10 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.b00, row_bytes, 0));
+        r.t11 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.b00 + 16u, row_bytes, 0));
+    } else {
+        r.t00 = *reinterpret_cast<const float4 *>(plane + g.b00);
+        r.t01 = *reinterpret_cast<const float4 *>(plane + g.b01);
+        r.t10 = *reinterpret_cast<const float4 *>(plane + g.b10);
+        r.t11 = *reinterpret_cast<const float4 *>(plane + g.b11);
+    }
     if (HAS_MASK) r.mq = *reinterpret_cast<const float4 *>(quads + g.b00);
 }
 
@@ -345,6 +359,7 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
     const char *qbase = reinterpret_cast<const char *>(quads);
     const char *pbase = reinterpret_cast<const char *>(rgba);
     const size_t plane_bytes = (size_t)N * 16;
+    const unsigned span = (unsigned)(N + W + 1) * 16u;        // a plane plus the row / texel the south-east taps may touch (next plane or tail padding)
 
     MpfAcc<NL, HAS_MASK, AUX> A;
     A.init();
@@ -391,28 +406,28 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
     } else if (DBG == 2) {
         float acc4 = 0.0f;
         for (int s = 0; s < S; ++s) {
-            mpf_fetch2<HAS_MASK>(pbase + (size_t)s * plane_bytes, qbase, ga, ra);
+            mpf_fetch2<HAS_MASK, TP>(pbase + (size_t)s * plane_bytes, qbase, ga, ra, c.row_bytes, span);
             acc4 += mpf_tap4w(ga, ra.t00.x, ra.t01.x, ra.t10.x, ra.t11.x) + mpf_tap4w(ga, ra.t00.y, ra.t01.y, ra.t10.y, ra.t11.y) +
                     mpf_tap4w(ga, ra.t00.z, ra.t01.z, ra.t10.z, ra.t11.z) + mpf_tap4w(ga, ra.t00.w, ra.t01.w, ra.t10.w, ra.t11.w);
             if (HAS_MASK) acc4 += mpf_tap4w(ga, ra.mq.x, ra.mq.y, ra.mq.z, ra.mq.w);
         }
         A.c0.a[0] = acc4;
     } else {
-    mpf_fetch2<HAS_MASK>(pbase, qbase, ga, ra);
+    mpf_fetch2<HAS_MASK, TP>(pbase, qbase, ga, ra, c.row_bytes, span);
 
     int s = 0;
     while (s + 2 < S) {
         A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 1, c, gb);
-        mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb);
+        mpf_fetch2<HAS_MASK, TP>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb, c.row_bytes, span);
         A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
         A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 2, c, ga);
-        mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 2) * plane_bytes, qbase, ga, ra);
+        mpf_fetch2<HAS_MASK, TP>(pbase + (size_t)(s + 2) * plane_bytes, qbase, ga, ra, c.row_bytes, span);
         A.step(gb, rb, mpf_norm3_nr(ga.X - gb.X, ga.Y - gb.Y, ga.Z - gb.Z), s + 1);
         s += 2;
     }
     if (s + 1 < S) {
         A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 1, c, gb);
-        mpf_fetch2<HAS_MASK>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb);
+        mpf_fetch2<HAS_MASK, TP>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb, c.row_bytes, span);
         A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
         A.step(gb, rb, 1e3f, s + 1);
     } else {
@@ -522,7 +537,6 @@ struct MpfBox {          // wave-uniform (SGPRs)
     unsigned h;          // rows staged; 0 = this plane is not staged (direct gathers)
 };
 
-typedef unsigned mpf_v4u __attribute__((ext_vector_type(4)));
 
 // d_params is read-only for the whole launch.  Behind a workgroup barrier hipcc no longer proves that for a plain global
 // pointer (the fence of __syncthreads() counts as a clobber), and the per-plane records turn into VECTOR loads issued right

@@ -85,18 +85,22 @@ MPF_DEV float mpf_div_nr(float n, float d, float r /* = mpf_rcp_nr(d) */)
     e = fmaf(-d, q, n);
     return fmaf(e, r, q);
 }
-// correctly rounded sqrt for normal-range x: v_sqrt_f32 then the +-1 ulp residual test hipcc itself emits, without the
-// denormal pre-scaling and the class fix-up
+// correctly rounded sqrt for x in 2^-102 .. 2^127: v_rsq_f32, one coupled Newton step on (sqrt, 1/(2 sqrt)) and one residual
+// correction - 1 transcendental, 2 multiplies, 5 fmas, all of them full-rate ops.  (Round 1 used v_sqrt_f32 followed by the +-1 ulp
+// residual test hipcc emits for an IEEE sqrt: 2 integer adds, 2 compares and 2 selects, which issue at little more than half the
+// rate of an fma on gfx950.)  tools/sqrt_exhaustive.hip compares both with the double-precision square root rounded to float on
+// EVERY float: identical and correctly rounded on all 2^23 values of every binade from 2^-102 up; below that the residual
+// underflows in both (the guarded library sqrt pre-scales there) - the kernels take square roots of squared plane distances, 1e-4 .. 1e7.
 MPF_DEV float mpf_sqrt_nr(float x)
 {
-    float s = __builtin_amdgcn_sqrtf(x);
-    float sm = __int_as_float(__float_as_int(s) - 1);
-    float sp = __int_as_float(__float_as_int(s) + 1);
-    float rm = fmaf(-sm, s, x);
-    float rp = fmaf(-sp, s, x);
-    s = (rm <= 0.0f) ? sm : s;
-    s = (rp > 0.0f) ? sp : s;
-    return s;
+    const float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r;
+    float h = 0.5f * r;
+    const float e = fmaf(-h, g, 0.5f);
+    h = fmaf(h, e, h);
+    g = fmaf(g, e, g);
+    const float d = fmaf(-g, g, x);
+    return fmaf(d, h, g);
 }
 MPF_DEV float mpf_norm3_nr(float x, float y, float z)
 {

@@ -282,13 +282,17 @@ MPF_DEV void mpf_fetch2(const char *__restrict__ plane, const char *__restrict__
         r.t01 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.b00 + 16u, 0, 0));
         r.t10 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.b00, row_bytes, 0));
         r.t11 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.b00 + 16u, row_bytes, 0));
+        if (HAS_MASK) {
+            __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(quads), 0, span, 0x00020000);
+            r.mq = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rq, g.b00, 0, 0));
+        }
     } else {
         r.t00 = *reinterpret_cast<const float4 *>(plane + g.b00);
         r.t01 = *reinterpret_cast<const float4 *>(plane + g.b01);
         r.t10 = *reinterpret_cast<const float4 *>(plane + g.b10);
         r.t11 = *reinterpret_cast<const float4 *>(plane + g.b11);
+        if (HAS_MASK) r.mq = *reinterpret_cast<const float4 *>(quads + g.b00);
     }
-    if (HAS_MASK) r.mq = *reinterpret_cast<const float4 *>(quads + g.b00);
 }
 
 template <class Geom>

@@ -225,13 +225,12 @@ def gather_reports(skipped, n_resumed, group=None):
 
 
 def device_identity(local_index):
-    """A string that is equal for two processes iff they drive the same physical GPU of this node."""
+    """A string that is equal for two processes of this job iff they drive the same GPU: host name, the visible-device lists the
+    process was started with, and the device index it selected.  (Deliberately not the runtime's uuid field, which some ROCm
+    builds leave empty or identical: a false alarm here would abort a healthy multi-GPU run.)"""
     import socket
-    props = torch.cuda.get_device_properties(local_index)
-    uid = getattr(props, "uuid", None)
-    if uid is None or not str(uid).strip("0-"):          # not populated by this runtime: visible-device list + index identifies it
-        uid = "%s|%s|%d" % (os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""), local_index)
-    return "%s/%s" % (socket.gethostname(), uid)
+    env = "|".join(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    return "%s|%s|%d" % (socket.gethostname(), env, int(local_index))
 
 
 def assert_distinct_devices(local_index, group=None):

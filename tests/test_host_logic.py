@@ -127,6 +127,60 @@ def test_stats_all_reduce_world_size_2_gloo(tmp_path):
     assert pairs == 11 and sflow == sum(range(11)) and holes == 2 * sum(range(11)) and mx == 10 and wall == 2.0 and negmin == 0.0
 
 
+_WORKER2 = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from PIL import Image
+import numpy as np
+from mpiflow_amd import pipeline
+dist.init_process_group(backend="gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+# (1) one process per GPU: distinct indices pass, a shared index is reported by every rank
+ids = pipeline.assert_distinct_devices(r)
+assert len(set(ids)) == w
+try:
+    pipeline.assert_distinct_devices(0)
+    shared = "not detected"
+except RuntimeError as e:
+    shared = "detected" if "share a GPU" in str(e) else repr(e)
+# (2) mask.max() table: decoded on rank 0 only, broadcast
+names = sorted(os.listdir(sys.argv[2]))
+if r != 0:
+    real_open = Image.open
+    def guarded(path, *a, **k):
+        raise AssertionError("rank %d decoded %s" % (r, path))
+    Image.open = guarded
+table = pipeline.mask_max_table(names, sys.argv[2], r, w)
+# (3) skip lists and resume counts meet on every rank
+merged, resumed = pipeline.gather_reports([("img%d" % r, "reason %d" % r)], r + 1)
+print("RESULT", r, shared, table, merged, resumed)
+dist.destroy_process_group()
+'''
+
+
+def test_multi_rank_contract_world_size_2_gloo(tmp_path):
+    """Two gloo ranks on CPU: the one-process-per-GPU check, the rank-0 mask-max table + broadcast, and the end-of-batch gather of
+    skip lists (the N > 1 host logic of gen_3dphoto_dynamic.py; RCCL itself needs the 8-GPU node)."""
+    from PIL import Image
+    masks = tmp_path / "masks"
+    masks.mkdir()
+    for n, mx in (("a.png", 3), ("b.png", 0), ("c.png", 7)):
+        m = np.zeros((6, 8), np.uint8)
+        m[1, 1] = mx
+        Image.fromarray(m).save(masks / n)
+    (masks / "d.png").write_bytes(b"broken")
+    script = tmp_path / "worker2.py"
+    script.write_text(_WORKER2)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29642", str(script), ROOT, str(masks)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = sorted(l for l in r.stdout.splitlines() if l.startswith("RESULT"))
+    assert len(lines) == 2
+    for k, l in enumerate(lines):
+        assert l.startswith("RESULT %d detected [3, 0, 7, -1] [('img0', 'reason 0'), ('img1', 'reason 1')] 3" % k), l
+
+
 def test_flo_round_trip_and_layout(tmp_path):
     from mpiflow_amd import io_formats
     rs = np.random.RandomState(0)

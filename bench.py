@@ -181,7 +181,7 @@ def measured_traffic():
     tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     try:
         rec = json.load(open(tp))
-        src = open(os.path.join(ROOT, "mpiflow_amd", "csrc", "mpf_render.hip"), "rb").read()
+        src = b"".join(open(os.path.join(ROOT, "mpiflow_amd", "csrc", f), "rb").read() for f in ("mpf_render.hip", "mpf_math.h"))
         if rec.get("kernel_source_sha256") == hashlib.sha256(src).hexdigest():
             return rec.get("stage_b_hbm_bytes_per_launch"), rec.get("source")
     except Exception:

@@ -36,7 +36,7 @@ S, H, W = 64, 640, 960
 N = H * W
 views = 2 if "views" in kb else 1
 alg_b = 16.0 * S * N * views
-src = open(os.path.join(repo, "mpiflow_amd", "csrc", "mpf_render.hip"), "rb").read()
+src = b"".join(open(os.path.join(repo, "mpiflow_amd", "csrc", f), "rb").read() for f in ("mpf_render.hip", "mpf_math.h"))
 rec = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `bench.py --steps 2` (profiles/run_profile.sh), this round",
     "kernel": kb, "views_per_launch": views,

@@ -233,15 +233,21 @@ def device_identity(local_index):
     return "%s|%s|%d" % (socket.gethostname(), env, int(local_index))
 
 
+_identity_round = 0
+
+
 def assert_distinct_devices(local_index, group=None):
     """One process per GPU: every rank publishes the identity of its device through the process group's
     key-value store (no collective, so it also works before the first RCCL communicator exists) and fails fast when two
     ranks share one - RCCL would otherwise stall or abort deep inside its first all-reduce."""
     import torch.distributed as dist
+    global _identity_round
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     store = dist.distributed_c10d._get_default_store()
-    store.set("mpiflow_dev_%d" % rank, device_identity(local_index))
-    ids = [store.get("mpiflow_dev_%d" % r).decode() for r in range(world)]      # get() blocks until the key exists
+    _identity_round += 1                                                         # fresh keys per call: never read a previous call's entry
+    key = "mpiflow_dev_%d_%%d" % _identity_round
+    store.set(key % rank, device_identity(local_index))
+    ids = [store.get(key % r).decode() for r in range(world)]                   # get() blocks until the key exists
     dup = sorted({i for i in ids if ids.count(i) > 1})
     if dup:
         raise RuntimeError("ranks share a GPU: %s (rank -> device: %s); launch one process per GPU" % (dup, dict(enumerate(ids))))

@@ -153,7 +153,9 @@ if r != 0:
 table = pipeline.mask_max_table(names, sys.argv[2], r, w)
 # (3) skip lists and resume counts meet on every rank
 merged, resumed = pipeline.gather_reports([("img%d" % r, "reason %d" % r)], r + 1)
-print("RESULT", r, shared, table, merged, resumed)
+dist.barrier()
+sys.stdout.write("RESULT %d %s %s %s %s\n" % (r, shared, table, merged, resumed))      # one write per line: the two ranks share the pipe
+sys.stdout.flush()
 dist.destroy_process_group()
 '''
 

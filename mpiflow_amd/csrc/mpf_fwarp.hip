@@ -12,15 +12,19 @@
 //      winner(target) = max j with cond(j)                (atomicMax on a per-target word)
 //   4. the last slot of each segment writes the 5 output bytes of its target
 //
-// Integer/byte work, bandwidth-trivial (N = h*w <= a few million 4-byte keys, 3 radix passes): the design goal is
+// Round 2: the single-workgroup scan over all RADIX*tiles counters (34 us per pass - half of the 189 us total) is gone (per-digit
+// row scan + digit bases rebuilt in the scatter), the two fill launches are folded into the key kernel, and digits are 8..11 bits
+// wide so that 640 x 960 needs two passes: 88 us, 9 launches (profiles/r2/forward_warp_kernels.txt).  Smaller tiles (512 keys per
+// workgroup) were slower (112 us): the digit-major counter table makes every workgroup touch RADIX separate cache lines.
+// Integer/byte work, bandwidth-trivial (N = h*w <= a few million 4-byte keys, 2-3 radix passes): the design goal is
 // bit-exact equality with the serial C, with bounded cost for pathological pile-ups (thousands of sources clamped onto
 // one border pixel), which is what the global sort buys over per-target lists.
 #include <string.h>
 #include "mpf_common.h"
 #include "mpf_math.h"
 
-#define RADIX_BITS 8
-#define RADIX 256
+#define RADIX_BITS_MAX 11              // digits of 8..11 bits: 20-bit keys (640 x 960 targets) sort in two passes, up to 33 bits in three
+#define RADIX_MAX (1 << RADIX_BITS_MAX)
 #define SORT_THREADS 256
 #define SORT_ITEMS 8
 #define SORT_TILE (SORT_THREADS * SORT_ITEMS)
@@ -155,13 +159,20 @@ extern "C" int mpf_moving_object_project(const float *d_disp, const float *h_inv
 
 // ---- sort -------------------------------------------------------------------------------------------------------
 
+// Also clears the per-target winner word and, for the device entry point, the output image (unvisited targets read 0:
+// moving_obj.py:123 zero-initialises `warped_arr`) - one pass over N instead of two separate fill launches.
 __global__ void __launch_bounds__(256)
 k_fw_keys(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy, int h, int w, uint32_t *__restrict__ keys,
-          uint32_t *__restrict__ vals)
+          uint32_t *__restrict__ vals, uint32_t *__restrict__ win, uint8_t *__restrict__ warped_to_clear)
 {
     const int64_t N = (int64_t)h * w;
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    win[n] = 0u;
+    if (warped_to_clear) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) warped_to_clear[5 * n + k] = 0;
+    }
     int64_t x = idx[n], y = idy[n];
     // the reference does no bounds check (caller pre-clamps, moving_obj.py:121-122); clamp instead of scribbling
     x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
@@ -170,11 +181,14 @@ k_fw_keys(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy, int 
     vals[n] = (uint32_t)n;
 }
 
+template <int BITS>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t nb, uint32_t *__restrict__ hist)
 {
+    constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS;
     __shared__ uint32_t h[RADIX];
-    h[threadIdx.x] = 0;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) h[threadIdx.x + k * SORT_THREADS] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * SORT_TILE;
 #pragma unroll
@@ -183,79 +197,74 @@ k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t 
         if (i < N) atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];      // digit-major, so one linear scan orders the scatter
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {                            // digit-major: row d = the counts of digit d over the tiles
+        const uint32_t d = threadIdx.x + k * SORT_THREADS;
+        hist[(size_t)d * nb + blockIdx.x] = h[d];
+    }
 }
 
-// exclusive scan of M = RADIX*nb counters by one 1024-thread workgroup, in chunks of 16384 staged through LDS:
-// coalesced global reads/writes, each thread scans 16 consecutive counters in LDS (row pitch 17 words: conflict-free),
-// the 1024 partial sums are scanned with wave shuffles, a running carry links the chunks.
-#define SCAN_PER 16
-#define SCAN_CHUNK (1024 * SCAN_PER)
-__global__ void __launch_bounds__(1024)
-k_scan_exclusive(uint32_t *__restrict__ data, uint32_t M)
+// Offsets of the scatter, two cheap steps instead of one scan over all RADIX*nb counters (which took a single workgroup 34 us
+// per pass - half of the whole forward warp): the counters are digit-major, so the exclusive offset of (digit d, tile b) is
+//     base[d] + rowprefix[d][b],   base[d] = sum of the totals of the digits below d,   rowprefix[d][b] = sum over tiles < b of hist[d][.]
+// k_radix_rowscan: one wave per digit turns its row into rowprefix in place and writes the digit's total;
+// k_radix_scatter: every workgroup rebuilds base[] from the RADIX totals in LDS (256 .. 2048 numbers).
+__global__ void __launch_bounds__(64)
+k_radix_rowscan(uint32_t *__restrict__ hist, uint32_t nb, uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t buf[1024 * (SCAN_PER + 1)];
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
-    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
-    if (t == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < M; base += SCAN_CHUNK) {
-        const uint32_t n = min((uint32_t)SCAN_CHUNK, M - base);
+    uint32_t *row = hist + (size_t)blockIdx.x * nb;
+    const uint32_t lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+        const uint32_t i = b0 + lane;
+        const uint32_t v = i < nb ? row[i] : 0u;
+        uint32_t inc = v;
 #pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) {
-            const uint32_t i = k * 1024u + t;
-            buf[(i / SCAN_PER) * (SCAN_PER + 1) + (i % SCAN_PER)] = (i < n) ? data[base + i] : 0u;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= (uint32_t)off) inc += o;
         }
-        __syncthreads();
-        uint32_t sum = 0;
+        if (i < nb) row[i] = carry + inc - v;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) totals[blockIdx.x] = carry;
+}
+
+// Stable scatter of one tile.  Keys are visited in index order: iteration `it` covers 256 consecutive keys, wave k of
+// the workgroup the k-th 64 of them, lane l the l-th.  rank-in-wave comes from BITS ballots (one per digit bit), waves
+// are ordered through per-wave digit counts in LDS, iterations through a running per-digit cursor.
+template <int BITS>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+                uint32_t *__restrict__ vals_out, uint32_t N, int shift, uint32_t nb, const uint32_t *__restrict__ offsets,
+                const uint32_t *__restrict__ totals)
+{
+    constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS, NW = SORT_THREADS / 64;
+    __shared__ uint32_t running[RADIX];
+    __shared__ uint32_t cnt[NW][RADIX];
+    __shared__ uint32_t wave_tot[NW];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    {   // base[d] = exclusive scan of the digit totals; thread t owns the DPT consecutive digits t*DPT ..
+        uint32_t v[DPT], sum = 0;
 #pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) {
-            const uint32_t v = buf[t * (SCAN_PER + 1) + k];
-            buf[t * (SCAN_PER + 1) + k] = sum;
-            sum += v;
-        }
-        // exclusive scan of `sum` over the 1024 threads: inclusive scan inside each wave, then across the 16 waves
+        for (int k = 0; k < DPT; ++k) { v[k] = totals[tid * DPT + k]; sum += v[k]; }
         uint32_t inc = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off);
             if (lane >= (uint32_t)off) inc += o;
         }
-        if (lane == 63) wave_tot[wv] = inc;
+        if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
-        uint32_t wave_off = 0, total = 0;
+        uint32_t base = inc - sum;
+        for (uint32_t k = 0; k < wave; ++k) base += wave_tot[k];
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const uint32_t v = wave_tot[w];
-            if ((uint32_t)w < wv) wave_off += v;
-            total += v;
+        for (int k = 0; k < DPT; ++k) {
+            const uint32_t d = tid * DPT + k;
+            running[d] = base + offsets[(size_t)d * nb + blockIdx.x];
+            base += v[k];
         }
-        const uint32_t off = carry_s + wave_off + (inc - sum);
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) buf[t * (SCAN_PER + 1) + k] += off;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) {
-            const uint32_t i = k * 1024u + t;
-            if (i < n) data[base + i] = buf[(i / SCAN_PER) * (SCAN_PER + 1) + (i % SCAN_PER)];
-        }
-        if (t == 0) carry_s += total;
-        __syncthreads();
     }
-}
-
-// Stable scatter of one tile.  Keys are visited in index order: iteration `it` covers 256 consecutive keys, wave k of
-// the workgroup the k-th 64 of them, lane l the l-th.  rank-in-wave comes from 8 ballots (one per digit bit), waves
-// are ordered through per-wave digit counts in LDS, iterations through a running per-digit cursor.
-__global__ void __launch_bounds__(SORT_THREADS)
-k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
-                uint32_t *__restrict__ vals_out, uint32_t N, int shift, uint32_t nb, const uint32_t *__restrict__ offsets)
-{
-    __shared__ uint32_t running[RADIX];
-    __shared__ uint32_t cnt[SORT_THREADS / 64][RADIX];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    running[tid] = offsets[tid * nb + blockIdx.x];
     const uint32_t base = blockIdx.x * SORT_TILE;
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const uint32_t i = base + it * SORT_THREADS + tid;
@@ -267,7 +276,7 @@ k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict
         for (int k = 0; k < RADIX / 64; ++k) cnt[wave][lane + 64 * k] = 0;
         unsigned long long mask = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < RADIX_BITS; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const bool bit = (digit >> b) & 1;
             const unsigned long long bal = __ballot(bit);
             mask &= bit ? bal : ~bal;
@@ -282,12 +291,25 @@ k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict
             vals_out[pos] = val;
         }
         __syncthreads();
-        uint32_t add = 0;
 #pragma unroll
-        for (int k = 0; k < SORT_THREADS / 64; ++k) add += cnt[k][tid];
-        running[tid] += add;
+        for (int k = 0; k < DPT; ++k) {
+            const uint32_t d = tid + k * SORT_THREADS;
+            uint32_t add = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) add += cnt[w][d];
+            running[d] += add;
+        }
         __syncthreads();
     }
+}
+
+template <int BITS>
+static void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, uint32_t N, int shift, uint32_t nb,
+                       uint32_t *hist, uint32_t *totals, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_radix_hist<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, N, shift, nb, hist);
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(1u << BITS), dim3(64), 0, st, hist, nb, totals);
+    hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals);
 }
 
 // ---- resolve ----------------------------------------------------------------------------------------------------
@@ -331,8 +353,8 @@ extern "C" size_t mpf_forward_warp_workspace(int h, int w)
     const int64_t N = (int64_t)h * w;
     if (N <= 0) return 0;
     const size_t a = ((size_t)N * 4 + 255) & ~(size_t)255;
-    const size_t hs = (((size_t)RADIX * fw_blocks(N)) * 4 + 255) & ~(size_t)255;
-    return 5 * a + hs;                // keysA, keysB, valsA, valsB, win, hist
+    const size_t hs = (((size_t)RADIX_MAX * fw_blocks(N)) * 4 + 255) & ~(size_t)255;
+    return 5 * a + hs + 4 * RADIX_MAX;    // keysA, keysB, valsA, valsB, win, hist, digit totals
 }
 
 static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_idy, const float *d_z, uint8_t *d_warped, int h,
@@ -352,24 +374,28 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
     uint32_t *win = (uint32_t *)(ws + 4 * a);
     uint32_t *hist = (uint32_t *)(ws + 5 * a);
     const uint32_t nb = fw_blocks(N);
+    uint32_t *totals = hist + (((size_t)RADIX_MAX * nb + 63) & ~(size_t)63);
     const uint32_t g256 = (N + 255) / 256;
 
-    hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0]);
+    hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], win, zero_fill ? d_warped : (uint8_t *)nullptr);
     int bits = 0;
     while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)N) ++bits;
-    int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
-    if (passes < 1) passes = 1;
+    // the fewest passes of 8..11-bit digits that cover the key: 640 x 960 (20 bits) -> 2 x 10, 1024 x 1536 (21 bits) -> 2 x 11
+    if (bits < 1) bits = 1;
+    const int passes = (bits + RADIX_BITS_MAX - 1) / RADIX_BITS_MAX;
+    int dbits = (bits + passes - 1) / passes;
+    if (dbits < 8) dbits = 8;
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
-        const int shift = p * RADIX_BITS;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SORT_THREADS), 0, st, keys[cur], N, shift, nb, hist);
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, hist, (uint32_t)RADIX * nb);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(SORT_THREADS), 0, st, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
-                           N, shift, nb, hist);
+        const int shift = p * dbits;
+        switch (dbits) {
+        case 8: radix_pass<8>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st); break;
+        case 9: radix_pass<9>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st); break;
+        case 10: radix_pass<10>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st); break;
+        default: radix_pass<11>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st); break;
+        }
         cur ^= 1;
     }
-    MPF_HIP(hipMemsetAsync(win, 0, (size_t)N * 4, st));
-    if (zero_fill) MPF_HIP(hipMemsetAsync(d_warped, 0, (size_t)N * 5, st));   // unvisited targets: 0 (moving_obj.py:123 zero-inits)
     hipLaunchKernelGGL(k_fw_mark, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, N, win);
     hipLaunchKernelGGL(k_fw_write, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, d_src, N, win, d_warped);
     return mpf_launch_status("forward_warp kernels");

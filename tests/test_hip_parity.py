@@ -269,7 +269,8 @@ def test_forward_warp_stress_golden(dev):
     assert bits_equal(N(got), g["warped"]) == 0
 
 
-@pytest.mark.parametrize("h,w,spread", [(1, 1, 1), (3, 7, 1), (33, 65, 1), (64, 64, 8), (100, 300, 64), (640, 960, 4)])
+@pytest.mark.parametrize("h,w,spread", [(1, 1, 1), (3, 7, 1), (33, 65, 1), (64, 64, 8), (100, 300, 64), (640, 960, 4),
+                                        (512, 512, 2), (1100, 1200, 3)])      # radix digits of 8, 10, 9 and 11 bits
 def test_forward_warp_random_vs_oracle(dev, oracle, h, w, spread):
     from mpiflow_amd import ops
     rs = np.random.RandomState(h * 1000 + w)

@@ -178,11 +178,15 @@ def test_every_pixel_c5_more_random_poses(dev, oracle, pose_seed):
 
 
 @pytest.mark.parametrize("S,H,W,V,mask,aux", [(8, 32, 48, 2, True, True), (20, 23, 37, 3, True, False), (5, 17, 19, 1, False, True),
-                                              (64, 40, 72, 5, True, False), (33, 64, 65, 16, False, False), (272, 8, 64, 2, True, True)])
+                                              (64, 40, 72, 5, True, False), (33, 64, 65, 16, False, False), (272, 8, 64, 2, True, True),
+                                              (12, 40, 56, 2, True, True)])
 def test_views_launch_bit_identical_to_single_launches(dev, oracle, S, H, W, V, mask, aux):
-    """mpf_warp_composite_views == V calls of mpf_warp_composite, bit for bit, for every output."""
+    """mpf_warp_composite_views == V calls of mpf_warp_composite, bit for bit, for every output.  (12, 40, 56): skewed intrinsics,
+    i.e. the dense K^-1 path instead of the pinhole shortcut."""
     from mpiflow_amd import host_math, ops, synth
     inp = synth.make_inputs(S, H, W, seed=S + V, kind="white")
+    if (S, H, W) == (12, 40, 56):
+        inp["K"][0, 1], inp["K"][1, 0] = 3.5, 0.25
     k_inv = host_math.k_inverse(inp["K"])
     d = host_math.plane_depths(inp["disparity"])
     a = ops.src_blend_flow(T(inp["mpi"], dev), T(inp["image"], dev), k_inv, d, None, out_rgba=ops.alloc_rgba_stack(S, H, W, dev))
@@ -219,13 +223,16 @@ def test_views_launch_bit_identical_to_single_launches(dev, oracle, S, H, W, V, 
 
 @pytest.mark.parametrize("S,H,W,V,mask,aux,extreme", [(8, 32, 48, 2, True, True, False), (20, 23, 37, 3, True, False, False),
                                                       (64, 72, 200, 2, True, False, False), (33, 64, 65, 4, False, False, False),
-                                                      (16, 96, 160, 2, True, True, True), (256, 16, 64, 1, True, False, False)])
+                                                      (16, 96, 160, 2, True, True, True), (256, 16, 64, 1, True, False, False),
+                                                      (12, 40, 56, 2, True, True, False)])
 def test_lds_staged_variant_bit_identical(dev, S, H, W, V, mask, aux, extreme):
     """mpf_tune("stage_b", 20): the kernel that stages each tile's source footprint in LDS == the gather kernel, bit for bit.
     `extreme`: poses whose footprint does not fit the 48x16 LDS tile, so some workgroups take the in-kernel gather fall-back."""
     from mpiflow_amd import _lib, host_math, ops, synth
     lib = _lib.load()
     inp = synth.make_inputs(S, H, W, seed=S + V + 40, kind="white")
+    if (S, H, W) == (12, 40, 56):                             # skewed intrinsics: the dense K^-1 path
+        inp["K"][0, 1], inp["K"][1, 0] = 3.5, 0.25
     k_inv = host_math.k_inverse(inp["K"])
     d = host_math.plane_depths(inp["disparity"])
     a = ops.src_blend_flow(T(inp["mpi"], dev), T(inp["image"], dev), k_inv, d, None, out_rgba=ops.alloc_rgba_stack(S, H, W, dev))

@@ -14,8 +14,8 @@
 //
 // Round 2: the single-workgroup scan over all RADIX*tiles counters (34 us per pass - half of the 189 us total) is gone (per-digit
 // row scan + digit bases rebuilt in the scatter), the two fill launches are folded into the key kernel, and digits are 8..11 bits
-// wide so that 640 x 960 needs two passes: 88 us, 9 launches (profiles/r2/forward_warp_kernels.txt).  Smaller tiles (512 keys per
-// workgroup) were slower (112 us): the digit-major counter table makes every workgroup touch RADIX separate cache lines.
+// wide so that 640 x 960 needs two passes, and the counter table is tile-major (coalesced everywhere but in the column scan): 87 us, 9 launches (profiles/r2/forward_warp_kernels.txt).  Smaller tiles (512 keys per
+// workgroup) were slower (112 us with the digit-major table of the time).
 // Integer/byte work, bandwidth-trivial (N = h*w <= a few million 4-byte keys, 2-3 radix passes): the design goal is
 // bit-exact equality with the serial C, with bounded cost for pathological pile-ups (thousands of sources clamped onto
 // one border pixel), which is what the global sort buys over per-target lists.
@@ -198,33 +198,35 @@ k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t 
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < DPT; ++k) {                            // digit-major: row d = the counts of digit d over the tiles
+    for (int k = 0; k < DPT; ++k) {                            // tile-major table [tile][digit]: coalesced here and in the scatter
         const uint32_t d = threadIdx.x + k * SORT_THREADS;
-        hist[(size_t)d * nb + blockIdx.x] = h[d];
+        hist[(size_t)blockIdx.x * RADIX + d] = h[d];
     }
 }
 
 // Offsets of the scatter, two cheap steps instead of one scan over all RADIX*nb counters (which took a single workgroup 34 us
-// per pass - half of the whole forward warp): the counters are digit-major, so the exclusive offset of (digit d, tile b) is
-//     base[d] + rowprefix[d][b],   base[d] = sum of the totals of the digits below d,   rowprefix[d][b] = sum over tiles < b of hist[d][.]
-// k_radix_rowscan: one wave per digit turns its row into rowprefix in place and writes the digit's total;
-// k_radix_scatter: every workgroup rebuilds base[] from the RADIX totals in LDS (256 .. 2048 numbers).
+// per pass - half of the whole forward warp): the exclusive offset of (digit d, tile b) is
+//     base[d] + colprefix[b][d],   base[d] = sum of the totals of the digits below d,   colprefix[b][d] = sum over tiles < b of hist[.][d]
+// k_radix_colscan: one wave per digit walks its column of the tile-major table (the only strided access of the sort), turns it into
+//                  colprefix in place and writes the digit's total;
+// k_radix_scatter: every workgroup rebuilds base[] from the RADIX totals in LDS (256 .. 2048 numbers) and reads its own row of
+//                  colprefix with coalesced loads.
 __global__ void __launch_bounds__(64)
-k_radix_rowscan(uint32_t *__restrict__ hist, uint32_t nb, uint32_t *__restrict__ totals)
+k_radix_colscan(uint32_t *__restrict__ hist, uint32_t nb, uint32_t radix, uint32_t *__restrict__ totals)
 {
-    uint32_t *row = hist + (size_t)blockIdx.x * nb;
+    uint32_t *col = hist + blockIdx.x;
     const uint32_t lane = threadIdx.x;
     uint32_t carry = 0;
     for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
         const uint32_t i = b0 + lane;
-        const uint32_t v = i < nb ? row[i] : 0u;
+        const uint32_t v = i < nb ? col[(size_t)i * radix] : 0u;
         uint32_t inc = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off);
             if (lane >= (uint32_t)off) inc += o;
         }
-        if (i < nb) row[i] = carry + inc - v;
+        if (i < nb) col[(size_t)i * radix] = carry + inc - v;
         carry += __shfl(inc, 63);
     }
     if (lane == 0) totals[blockIdx.x] = carry;
@@ -261,7 +263,7 @@ k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict
 #pragma unroll
         for (int k = 0; k < DPT; ++k) {
             const uint32_t d = tid * DPT + k;
-            running[d] = base + offsets[(size_t)d * nb + blockIdx.x];
+            running[d] = base + offsets[(size_t)blockIdx.x * RADIX + d];
             base += v[k];
         }
     }
@@ -308,7 +310,7 @@ static void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
                        uint32_t *hist, uint32_t *totals, hipStream_t st)
 {
     hipLaunchKernelGGL((k_radix_hist<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, N, shift, nb, hist);
-    hipLaunchKernelGGL(k_radix_rowscan, dim3(1u << BITS), dim3(64), 0, st, hist, nb, totals);
+    hipLaunchKernelGGL(k_radix_colscan, dim3(1u << BITS), dim3(64), 0, st, hist, nb, 1u << BITS, totals);
     hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals);
 }
 

@@ -12,10 +12,12 @@
 //      winner(target) = max j with cond(j)                (atomicMax on a per-target word)
 //   4. the last slot of each segment writes the 5 output bytes of its target
 //
-// Round 2: the single-workgroup scan over all RADIX*tiles counters (34 us per pass - half of the 189 us total) is gone (per-digit
-// row scan + digit bases rebuilt in the scatter), the two fill launches are folded into the key kernel, and digits are 8..11 bits
-// wide so that 640 x 960 needs two passes, and the counter table is tile-major (coalesced everywhere but in the column scan): 87 us, 9 launches (profiles/r2/forward_warp_kernels.txt).  Smaller tiles (512 keys per
-// workgroup) were slower (112 us with the digit-major table of the time).
+// Round 2 (189 us in 14 launches -> 53 us in 4 at 640 x 960, profiles/r2/forward_warp_kernels.txt):
+//   * images up to 2^22 pixels: ONE stable pass on the HIGH bits of the target (keys + histogram fused, a per-digit column scan
+//     instead of a single-workgroup scan over all counters - that scan alone was 34 us per pass -, stable scatter), then one
+//     workgroup per bucket of 2^lb consecutive targets finishes the sort in LDS and resolves its targets (k_fw_bucket): no
+//     second histogram / scan / scatter, no global winner array, no separate fill, mark and write launches;
+//   * larger images: the general path - two or three passes with 8..11-bit digits, mark, write.
 // Integer/byte work, bandwidth-trivial (N = h*w <= a few million 4-byte keys, 2-3 radix passes): the design goal is
 // bit-exact equality with the serial C, with bounded cost for pathological pile-ups (thousands of sources clamped onto
 // one border pixel), which is what the global sort buys over per-target lists.
@@ -168,7 +170,7 @@ k_fw_keys(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy, int 
     const int64_t N = (int64_t)h * w;
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    win[n] = 0u;
+    if (win) win[n] = 0u;
     if (warped_to_clear) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) warped_to_clear[5 * n + k] = 0;
@@ -201,6 +203,39 @@ k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t 
     for (int k = 0; k < DPT; ++k) {                            // tile-major table [tile][digit]: coalesced here and in the scatter
         const uint32_t d = threadIdx.x + k * SORT_THREADS;
         hist[(size_t)blockIdx.x * RADIX + d] = h[d];
+    }
+}
+
+// The first pass of the fast path: keys and the histogram of their high digit in one sweep over the sources (tile = SORT_TILE keys)
+template <int BITS>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_fw_keys_hist(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy, int h, int w, uint32_t *__restrict__ keys,
+               uint32_t *__restrict__ vals, uint32_t N, int shift, uint32_t *__restrict__ hist)
+{
+    constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS;
+    __shared__ uint32_t hh[RADIX];
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) hh[threadIdx.x + k * SORT_THREADS] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t n = base + it * SORT_THREADS + threadIdx.x;
+        if (n < N) {
+            int64_t x = idx[n], y = idy[n];
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);              // as k_fw_keys: clamp instead of scribbling
+            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            const uint32_t key = (uint32_t)(y * w + x);
+            keys[n] = key;
+            vals[n] = n;
+            atomicAdd(&hh[(key >> shift) & (RADIX - 1)], 1u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+        const uint32_t d = threadIdx.x + k * SORT_THREADS;
+        hist[(size_t)blockIdx.x * RADIX + d] = hh[d];
     }
 }
 
@@ -314,7 +349,154 @@ static void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
     hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals);
 }
 
-// ---- resolve ----------------------------------------------------------------------------------------------------
+// ---- buckets: finish the sort inside each high-digit bucket and resolve it, in ONE kernel ------------------------------------
+// After ONE stable pass on the HIGH bits of the target (bucket = 2^LB consecutive targets, about an image row), a bucket's visitors
+// are contiguous and in raster order.  One workgroup per bucket then (A) counts them per target, (B) scans the counts, (C) places
+// them stably by target - the same ballot ranking as k_radix_scatter, with cursors in LDS and the bucket's slice of the second
+// key/value arrays as destination - and (D) resolves every target of the bucket: per slot "z < z of the previous visitor of the
+// same target (1000 for the first)", the last such slot per target through an LDS atomicMax, and the segment's last slot writes
+// the 5 output bytes (warping.c:13-29).  Targets of the bucket nobody visited are cleared here when the caller wants a cleared
+// image.  This replaces the second histogram / scan / scatter and the global mark / write passes (5 launches, 44 us at 640 x 960).
+// Pile-ups stay bounded: a bucket of any size is walked in slabs of 256 by its workgroup.
+#define FW_BUCKET_CAP 2048        // visitors of a bucket kept in LDS (sorted key, source index, z); larger buckets go through global memory
+
+template <int LB>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_fw_bucket(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+            uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ totals, uint32_t N, const float *__restrict__ z,
+            const uint8_t *__restrict__ src, uint8_t *__restrict__ warped, int zero_fill)
+{
+    constexpr int NT = 1 << LB, DPT = NT / SORT_THREADS, NW = SORT_THREADS / 64;
+    __shared__ uint32_t hcount[NT];            // visitors per target of the bucket (kept for the clears)
+    __shared__ uint32_t cursor[NT];            // running insertion point per target, then: winner slot + 1 per target
+    __shared__ uint32_t cnt[NW][NT];
+    __shared__ uint32_t red[NW];
+    __shared__ uint32_t skey[FW_BUCKET_CAP];   // the bucket's visitors sorted by (target, raster index): target, source index, z
+    __shared__ uint32_t sval[FW_BUCKET_CAP];
+    __shared__ float sz[FW_BUCKET_CAP];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
+    // this bucket's slice [start, start + n) of the sorted-by-high-digit arrays: start = sum of the totals of the buckets below
+    uint32_t part = 0;
+    for (uint32_t k = tid; k < b; k += SORT_THREADS) part += totals[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) red[wave] = part;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) hcount[tid + k * SORT_THREADS] = 0;
+    __syncthreads();
+    uint32_t start = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) start += red[k];
+    const uint32_t n = totals[b];
+    const bool in_lds = n <= FW_BUCKET_CAP;     // uniform
+    const uint32_t *kin = keys_in + start, *vin = vals_in + start;
+    uint32_t *ko = keys_out + start, *vo = vals_out + start;
+    // (A) visitors per target
+    for (uint32_t j = tid; j < n; j += SORT_THREADS) atomicAdd(&hcount[kin[j] & (NT - 1)], 1u);
+    __syncthreads();
+    // (B) exclusive scan of hcount -> cursor (thread t owns DPT consecutive targets)
+    {
+        uint32_t v[DPT], sum = 0;
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) { v[k] = hcount[tid * DPT + k]; sum += v[k]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= (uint32_t)off) inc += o;
+        }
+        __syncthreads();
+        if (lane == 63) red[wave] = inc;
+        __syncthreads();
+        uint32_t base = inc - sum;
+        for (uint32_t k = 0; k < wave; ++k) base += red[k];
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) { cursor[tid * DPT + k] = base; base += v[k]; }
+    }
+    __syncthreads();
+    // (C) stable placement by target, slab by slab (the visitor's z travels with it)
+    for (uint32_t j0 = 0; j0 < n; j0 += SORT_THREADS) {
+        const uint32_t j = j0 + tid;
+        const bool valid = j < n;
+        const uint32_t key = valid ? kin[j] : 0xFFFFFFFFu;
+        const uint32_t val = valid ? vin[j] : 0u;
+        const float zv = (valid && in_lds) ? z[val] : 0.0f;
+        const uint32_t digit = key & (NT - 1);
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) cnt[wave][lane + 64 * k] = 0;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < LB; ++bit) {
+            const bool on = (digit >> bit) & 1;
+            const unsigned long long bal = __ballot(on);
+            mask &= on ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) cnt[wave][digit] = __popcll(mask);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = cursor[digit] + rank;
+            for (uint32_t k = 0; k < wave; ++k) pos += cnt[k][digit];
+            if (in_lds) { skey[pos] = key; sval[pos] = val; sz[pos] = zv; }
+            else { ko[pos] = key; vo[pos] = val; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) {
+            const uint32_t d = tid + k * SORT_THREADS;
+            uint32_t add = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) add += cnt[w][d];
+            cursor[d] += add;
+        }
+        __syncthreads();
+    }
+    // the slice is complete and sorted by (target, raster index); make the global form visible to the whole workgroup
+    if (!in_lds) __threadfence_block();
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) cursor[tid + k * SORT_THREADS] = 0;          // now: winner slot + 1 per target
+    __syncthreads();
+    auto key_at = [&](uint32_t j) -> uint32_t { return in_lds ? skey[j] : ko[j]; };
+    auto val_at = [&](uint32_t j) -> uint32_t { return in_lds ? sval[j] : vo[j]; };
+    auto z_at = [&](uint32_t j) -> float { return in_lds ? sz[j] : z[vo[j]]; };
+    // (D) resolve
+    for (uint32_t j = tid; j < n; j += SORT_THREADS) {
+        const uint32_t t = key_at(j);
+        const bool has_pred = (j > 0) && (key_at(j - 1) == t);
+        const float zprev = has_pred ? z_at(j - 1) : 1000.0f;                   // dlut, warping.c:11, :29
+        if (z_at(j) < zprev) atomicMax(&cursor[t & (NT - 1)], j + 1);           // warping.c:19
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < n; j += SORT_THREADS) {
+        const uint32_t t = key_at(j);
+        if (j + 1 < n && key_at(j + 1) == t) continue;                          // only the last visitor of a target writes
+        const bool has_pred = (j > 0) && (key_at(j - 1) == t);
+        const float zprev = has_pred ? z_at(j - 1) : 1000.0f;
+        uint8_t *o = warped + (size_t)t * 5;
+        const uint32_t wj = cursor[t & (NT - 1)];
+        if (wj) {                                                               // no visitor passed the z test: the colour bytes keep
+            const uint8_t *sp = src + (size_t)val_at(wj - 1) * 3;               // what they held (warping.c:19-21)
+            o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
+        } else if (zero_fill) {
+            o[0] = o[1] = o[2] = 0;
+        }
+        o[3] = 1;                                                               // warping.c:23
+        o[4] = (zprev == 1000.0f) ? 1 : 0;                                      // warping.c:24-27
+    }
+    if (zero_fill) {                                                            // targets nobody visited (moving_obj.py:123 zero-inits)
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) {
+            const uint32_t tl = tid + k * SORT_THREADS;
+            const uint64_t t = ((uint64_t)b << LB) + tl;
+            if (hcount[tl] == 0 && t < N) {
+                uint8_t *o = warped + (size_t)t * 5;
+                o[0] = o[1] = o[2] = o[3] = o[4] = 0;
+            }
+        }
+    }
+}
+
+// ---- resolve (the general path: images above 2^22 pixels) ------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256)
 k_fw_mark(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const float *__restrict__ z, uint32_t N,
@@ -348,6 +530,10 @@ k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
     o[4] = (zprev == 1000.0f) ? 1 : 0;                                // warping.c:24-27
 }
 
+static int g_fw_path = 0;       // mpf_tune("fwarp_path", 1): force the general multi-pass path (tests; images above 2^22 pixels take it anyway)
+
+void mpf_fwarp_set_path(int v) { g_fw_path = v; }
+
 static inline uint32_t fw_blocks(int64_t N) { return (uint32_t)((N + SORT_TILE - 1) / SORT_TILE); }
 
 extern "C" size_t mpf_forward_warp_workspace(int h, int w)
@@ -379,9 +565,37 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
     uint32_t *totals = hist + (((size_t)RADIX_MAX * nb + 63) & ~(size_t)63);
     const uint32_t g256 = (N + 255) / 256;
 
-    hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], win, zero_fill ? d_warped : (uint8_t *)nullptr);
     int bits = 0;
     while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)N) ++bits;
+    if (bits <= 2 * RADIX_BITS_MAX && g_fw_path == 0) {
+        // the fast path: one stable pass on the high bits, then one workgroup per bucket of 2^lb targets sorts and resolves it
+        const int lb = bits <= 16 ? 8 : (bits <= 18 ? 9 : (bits <= 20 ? 10 : 11));
+        const int hb = bits > lb ? bits - lb : 1;                        // 1 .. 11 high bits (hb < 8: the pass still uses 8-bit digits)
+        const int pb = hb < 8 ? 8 : hb;
+        const uint32_t nbuckets = (uint32_t)(((uint64_t)N + ((uint64_t)1 << lb) - 1) >> lb);
+#define MPF_FW_PASS1(PBv)                                                                                                          \
+        hipLaunchKernelGGL((k_fw_keys_hist<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], N, lb, hist);      \
+        hipLaunchKernelGGL(k_radix_colscan, dim3(1u << PBv), dim3(64), 0, st, hist, nb, 1u << PBv, totals);                                  \
+        hipLaunchKernelGGL((k_radix_scatter<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, keys[0], vals[0], keys[1], vals[1], N, lb, nb, hist, totals)
+        switch (pb) {
+        case 8: MPF_FW_PASS1(8); break;
+        case 9: MPF_FW_PASS1(9); break;
+        case 10: MPF_FW_PASS1(10); break;
+        default: MPF_FW_PASS1(11); break;
+        }
+#undef MPF_FW_PASS1
+#define MPF_FW_BUCKET(LBv) hipLaunchKernelGGL((k_fw_bucket<LBv>), dim3(nbuckets), dim3(SORT_THREADS), 0, st, keys[1], vals[1], keys[0], vals[0], totals, \
+                                              N, d_z, d_src, d_warped, zero_fill ? 1 : 0)
+        switch (lb) {
+        case 8: MPF_FW_BUCKET(8); break;
+        case 9: MPF_FW_BUCKET(9); break;
+        case 10: MPF_FW_BUCKET(10); break;
+        default: MPF_FW_BUCKET(11); break;
+        }
+#undef MPF_FW_BUCKET
+        return mpf_launch_status("forward_warp kernels");
+    }
+    hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], win, zero_fill ? d_warped : (uint8_t *)nullptr);
     // the fewest passes of 8..11-bit digits that cover the key: 640 x 960 (20 bits) -> 2 x 10, 1024 x 1536 (21 bits) -> 2 x 11
     if (bits < 1) bits = 1;
     const int passes = (bits + RADIX_BITS_MAX - 1) / RADIX_BITS_MAX;

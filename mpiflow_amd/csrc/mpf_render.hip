@@ -1138,10 +1138,13 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
 #undef MPF_SBF
 }
 
+void mpf_fwarp_set_path(int v);      // mpf_fwarp.hip
+
 extern "C" int mpf_tune(const char *key, int value)
 {
     if (key && !strcmp(key, "sbf_px")) { g_sbf_px = value; return 0; }
     if (key && !strcmp(key, "stage_b")) { g_stage_b_variant = value; return 0; }
+    if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
     mpf_set_error("mpf_tune: unknown key");
     return MPF_ERR_BAD_ARGUMENT;
 }

@@ -461,6 +461,26 @@ k_warp_composite_dbg(const float *__restrict__ rgba, const float *__restrict__ q
                                                        mpf_xcd_remap(blockIdx.x, gridDim.x));
 }
 
+// Tile order: strips of MPF_STRIP_TILES tiles wide, row by row inside a strip.  With the image-wide row-major order the ~80 tiles an
+// XCD has resident at a time form a band 2-3 tile rows tall and as wide as the image; the two poses of a pair displace a tile's source
+// footprint by up to ~100 px in BOTH directions, so the views of a multi-view launch rarely met in that XCD's L2.  A 4-tile-wide strip
+// makes the resident set a compact 128 x 160 px patch: one launch for two views went 160 -> 146 us per view at 64x640x960 (four views
+// 148 -> 132), widths 2 / 3 / 4 / 6 / 8: 155.5 / 149.8 / 146.1 / 152.5 / 147.3 (profiles/r2/stage_b_strip_order.log).  A pure
+// scheduling choice: results never depend on it.
+#ifndef MPF_STRIP_TILES
+#define MPF_STRIP_TILES 4
+#endif
+MPF_DEV unsigned mpf_strip_order(unsigned t, unsigned tiles_x, unsigned tiles_y)
+{
+    const unsigned SWd = MPF_STRIP_TILES, nfull = tiles_x / SWd, full = nfull * SWd * tiles_y;
+    if (t < full) {
+        const unsigned strip = t / (SWd * tiles_y), r = t - strip * SWd * tiles_y;
+        return (r / SWd) * tiles_x + strip * SWd + (r % SWd);
+    }
+    const unsigned rem = tiles_x - nfull * SWd, r = t - full;              // the last, narrower strip
+    return (r / rem) * tiles_x + nfull * SWd + (r % rem);
+}
+
 template <bool HAS_MASK, int NL, int TW, int TH, bool TP>
 MPF_DEV void mpf_wc2_select(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
                             int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
@@ -484,7 +504,7 @@ k_warp_composite_v2(const float *__restrict__ rgba, const float *__restrict__ qu
                     float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
 {
     mpf_wc2_select<HAS_MASK, NL, TW, TH, TP>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out,
-                                             mpf_xcd_remap(blockIdx.x, gridDim.x));
+                                             mpf_strip_order(mpf_xcd_remap(blockIdx.x, gridDim.x), (W + TW - 1) / TW, (H + TH - 1) / TH));
 }
 
 // Several views of ONE stack in one launch (the reference renders two poses of every stack, utils/utils.py:210-236, and
@@ -499,7 +519,8 @@ __global__ void __launch_bounds__(TW *TH, WPS)
 k_warp_composite_views(const float *__restrict__ rgba, const MpfViewSet vs, const unsigned V, int S, int H, int W)
 {
     const unsigned l = mpf_xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned view = l % V, tile = l / V;
+    const unsigned view = l % V;
+    const unsigned tile = mpf_strip_order(l / V, (W + TW - 1) / TW, (H + TH - 1) / TH);
     const MpfWarpView &w = vs.v[view];
     mpf_wc2_select<HAS_MASK, NL, TW, TH, TP>(rgba, w.d_mask_quads, w.d_params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask,
                                              w.d_rgb_u8_bgr, tile);

@@ -39,10 +39,10 @@ class PairRenderer:
         self.quads = [torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)]    # obj_mask, 1 - obj_mask
         self.src_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         self.n_views = n_views
-        # all Stage B views of a pair in ONE launch (mpf_warp_composite_views) where that wins: measured x1.06-1.09 per pair up to
-        # 64 x 640 x 960 (x1.24 for the 10 views of a `repeat` loop at 64 x 384 x 1280), x0.97 at 128 x 1024 x 1536 (25 MB per plane:
-        # the two views no longer meet in the caches) - profiles/r2/stage_b_views_shapes.log
-        self.multi_view = H * W * 16 <= (16 << 20)
+        # all Stage B views of a pair in ONE launch (mpf_warp_composite_views): with the strip-major tile order it wins at every shape
+        # measured - x1.06 (128 x 1024 x 1536) to x1.17 (64 x 640 x 960) for a pair, x1.20-1.42 for the 10 views of a `repeat` loop
+        # (profiles/r2/stage_b_views_strip_shapes.log).  False = one launch per view (bench.py's comparison record, tests).
+        self.multi_view = True
         self._pair_bufs = []
 
     # -- host side: small matrices ---------------------------------------------------------------------------------

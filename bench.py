@@ -189,6 +189,28 @@ def measured_traffic():
     return None, None
 
 
+def hbm_reference(dev, nbytes=1 << 30, reps=10):
+    """What this box's HBM delivers to two trivial streaming kernels (report an on-box figure beside the 8 TB/s
+    spec): a device-to-device copy (read + write) and a read-only reduction, `nbytes` each, HIP events, outside the timed region."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+
+    def timed(fn, moved):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    rec = {"copy_GBps": timed(lambda: b.copy_(a), 2 * nbytes), "read_GBps": timed(lambda: a.sum(), nbytes), "bytes": nbytes,
+           "note": "torch copy_ / sum on 1 GiB of fp32; the roofline fractions above are against the 8 TB/s specification, not against these"}
+    del a, b
+    return rec
+
+
 def cpu_baseline(S, H, W, pairs):
     """Time the oracle (checker, used here only as the reported CPU baseline) on `pairs` full dynamic pairs."""
     from oracle import mpi_oracle as orc
@@ -312,6 +334,8 @@ def main():
             sub.append(sub_record("c1: BASELINE configs[0] shape, 32x384x512 dynamic pair (on the GPU: the product has no CPU path)", 32, 384, 512, 8, dev, True, 10))
             sub.append(sub_record("c5: BASELINE configs[4] shape, 128x1024x1536 dynamic pair, random poses", 128, 1024, 1536, 2, dev, True, 5))
             out["sub"] = sub
+        if world == 1 and not a.no_sub:
+            out["hbm_reference"] = hbm_reference(dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, H, W, a.cpu_pairs)
             out["cpu_baseline"]["reference_measured_in_build_container"] = \

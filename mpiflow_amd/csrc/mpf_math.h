@@ -85,6 +85,17 @@ MPF_DEV float mpf_div_nr(float n, float d, float r /* = mpf_rcp_nr(d) */)
     e = fmaf(-d, q, n);
     return fmaf(e, r, q);
 }
+// Division by a divisor whose CORRECTLY ROUNDED reciprocal y = RN(1/d) is at hand (a per-launch constant: half the image width /
+// height): Markstein's sequence - q = RN(n*y), exact residual by fma, one correction - returns RN(n/d) for every n whose quotient
+// is a normal number, so the second correction of mpf_div_nr (needed there because v_rcp + one Newton step is only ALMOST always
+// the correctly rounded reciprocal) can go.  tools/div_const_exhaustive.hip: 0 mismatches against the double-precision quotient
+// over every divisor k/2, k = 2..16384, and every numerator of 32 binades (70 binades for the image sizes in use).
+MPF_DEV float mpf_div_by_const(float n, float d, float y /* = RN(1/d) */)
+{
+    float q = n * y;
+    float e = fmaf(-d, q, n);
+    return fmaf(e, y, q);
+}
 // correctly rounded sqrt for x in 2^-102 .. 2^127: v_rsq_f32, one coupled Newton step on (sqrt, 1/(2 sqrt)) and one residual
 // correction - 1 transcendental, 2 multiplies, 5 fmas, all of them full-rate ops.  (Round 1 used v_sqrt_f32 followed by the +-1 ulp
 // residual test hipcc emits for an IEEE sqrt: 2 integer adds, 2 compares and 2 selects, which issue at little more than half the

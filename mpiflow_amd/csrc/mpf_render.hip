@@ -215,8 +215,8 @@ MPF_DEV float mpf_geom_core(const ParamPtr params, int s, const MpfConsts &c, fl
         const bool inside = (u < c.Wf) & (u > -1.0f) & (v < c.Hf) & (v > -1.0f);
         valid = inside ? 1.0f : 0.0f;
     }
-    float gx = mpf_div_nr(u + 0.5f, c.halfW, c.rhalfW) - 1.0f;
-    float gy = mpf_div_nr(v + 0.5f, c.halfH, c.rhalfH) - 1.0f;
+    float gx = mpf_div_by_const(u + 0.5f, c.halfW, c.rhalfW) - 1.0f;
+    float gy = mpf_div_by_const(v + 0.5f, c.halfH, c.rhalfH) - 1.0f;
     float ix = (gx + 1.0f) * c.halfW - 0.5f;
     float iy = (gy + 1.0f) * c.halfH - 0.5f;
     ix = __builtin_amdgcn_fmed3f(ix, 0.0f, c.maxx);       // min(max_val, max(x, 0)) in one op (inputs are never NaN here)
@@ -357,7 +357,7 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
     c.fx = (float)min(x, W - 1); c.fy = (float)min(y, H - 1);
     c.W = W; c.H = H; c.Wf = (float)W; c.Hf = (float)H;
     c.halfW = (float)W * 0.5f; c.halfH = (float)H * 0.5f;
-    c.rhalfW = mpf_rcp_nr(c.halfW); c.rhalfH = mpf_rcp_nr(c.halfH);
+    c.rhalfW = 1.0f / c.halfW; c.rhalfH = 1.0f / c.halfH;      // IEEE division (build flag): RN(1/d), which mpf_div_by_const relies on
     c.maxx = (float)(W - 1); c.maxy = (float)(H - 1);
     c.row_bytes = (unsigned)W * 16u;
     const char *qbase = reinterpret_cast<const char *>(quads);
@@ -598,7 +598,7 @@ MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restric
     c.fx = (float)min(x, W - 1); c.fy = (float)min(y, H - 1);
     c.W = W; c.H = H; c.Wf = (float)W; c.Hf = (float)H;
     c.halfW = (float)W * 0.5f; c.halfH = (float)H * 0.5f;
-    c.rhalfW = mpf_rcp_nr(c.halfW); c.rhalfH = mpf_rcp_nr(c.halfH);
+    c.rhalfW = 1.0f / c.halfW; c.rhalfH = 1.0f / c.halfH;      // IEEE division (build flag): RN(1/d), which mpf_div_by_const relies on
     c.maxx = (float)(W - 1); c.maxy = (float)(H - 1);
     c.row_bytes = (unsigned)W * 16u;
     const char *qbase = reinterpret_cast<const char *>(quads);

@@ -24,6 +24,9 @@ is the PMC-measured HBM traffic of that kernel from profiles/roofline_traffic.js
 still has the digest the measurement was taken at (else null: a stale number is worse than none).
 `sub`: the other configs on rank 0 at N=1, outside the timed region: camera-only pair (configs[1]), c1 and c5 dynamic
 pairs, each with per-kernel roofline entries for Stage B and Stage A+C.
+`overlap`: the same dynamic pairs on two HIP streams (own renderers): throughput when Stage A+C of one pair overlaps Stage B of
+another - information beside `value`, which stays the single-stream figure so that the roofline entries are clean kernel times.
+`hbm_reference`: what a plain device copy / read-only reduction reaches on this box.
 `cpu_baseline`: the CPU oracle (our plain-C restatement of the reference algorithm, OpenMP) timed on this host on a
 bounded sample of the same workload (dynamic pairs), rank 0, N=1 only.
 """
@@ -249,6 +252,35 @@ def sub_record(name, S, H, W, B, dev, dynamic, steps, multi_view=True):
     return rec
 
 
+def overlap_record(S, H, W, dev, n_streams=2, images=4, steps=8):
+    """The same dynamic pairs on `n_streams` HIP streams, each with its own renderer and images: the HBM-bound Stage A+C of one
+    pair runs beside the issue-bound Stage B of another.  Reported beside `value`, not as `value`: under overlap a kernel's own
+    duration includes the other stream's interference, so the per-kernel roofline entries are taken from the single-stream run."""
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    wls = []
+    for k, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            wls.append(Workload(S, H, W, images, dev, True, seed0=700 + 10 * k))
+
+    def run(n):
+        for _ in range(n):
+            for i in range(images):
+                for wl, st in zip(wls, streams):
+                    with torch.cuda.stream(st):
+                        wl.pair(i, False)
+    run(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = steps * images * n_streams
+    del wls
+    torch.cuda.empty_cache()
+    return {"workload": "c3 dynamic pairs on %d streams (separate renderers; Stage A+C of one pair beside Stage B of another)" % n_streams,
+            "streams": n_streams, "pairs_per_s": n / dt, "us_per_pair": dt / n * 1e6, "pairs_timed": n}
+
+
 def main():
     a = parse()
     rank, world, local = init_dist()
@@ -334,6 +366,8 @@ def main():
             sub.append(sub_record("c1: BASELINE configs[0] shape, 32x384x512 dynamic pair (on the GPU: the product has no CPU path)", 32, 384, 512, 8, dev, True, 10))
             sub.append(sub_record("c5: BASELINE configs[4] shape, 128x1024x1536 dynamic pair, random poses", 128, 1024, 1536, 2, dev, True, 5))
             out["sub"] = sub
+            if dynamic:
+                out["overlap"] = overlap_record(S, H, W, dev)
         if world == 1 and not a.no_sub:
             out["hbm_reference"] = hbm_reference(dev)
         if world == 1 and not a.no_cpu_baseline:

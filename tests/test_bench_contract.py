@@ -78,3 +78,7 @@ def test_single_gpu_line_has_sub_records_and_names_the_dynamic_pair():
     assert any(n.startswith("c2") for n in names) and any(n.startswith("c1") for n in names) and any(n.startswith("c5") for n in names)
     for s_ in d["sub"]:
         assert s_["stage_b"]["frac"] > 0 and s_["stage_ac"]["frac"] > 0
+    # the on-box streaming figures next to the 8 TB/s specification: plausible, and the kernels do not beat them
+    assert d["overlap"]["streams"] == 2 and d["overlap"]["pairs_per_s"] > 0.8 * d["value"]
+    hb = d["hbm_reference"]
+    assert 1000.0 < hb["copy_GBps"] < 8000.0 and 1000.0 < hb["read_GBps"] < 8000.0

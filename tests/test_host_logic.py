@@ -252,3 +252,19 @@ def test_batched_host_algebra_is_bit_identical_to_single_evaluations():
     for i, G in enumerate(poses):
         a, b = host_math.homographies(G, k_inv, K, d)
         assert torch.equal(H_ts[i], a) and torch.equal(H_st[i], b)
+
+
+def test_reference_named_entry_points_share_the_generator_cli():
+    """gen_3dphoto_dynamic_v2.py is the generator the reference ships (scripts/gen_train_kitti15_v2.sh); gen_coco.sh calls
+    gen_3dphoto_dynamic_coco.py.  Both names exist here, take the reference's flags, and the COCO one defaults to the COCO poses."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script in ("gen_3dphoto_dynamic_v2.py", "gen_3dphoto_dynamic_coco.py", "gen_3dphoto_dynamic.py"):
+        r = subprocess.run([sys.executable, os.path.join(root, script), "--help"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        for flag in ("--width", "--height", "--seed", "--ext_cz", "--ckpt_path", "--repeat", "--base", "--out"):   # gen_3dphoto_dynamic_v2.py:22-32
+            assert flag in r.stdout
+    sys.path.insert(0, root)
+    import gen_3dphoto_dynamic as g
+    assert g.parse(["--base", "b", "--out", "o"]).poses == "v2"
+    src = open(os.path.join(root, "gen_3dphoto_dynamic_coco.py")).read()
+    assert '"--poses", "coco"' in src

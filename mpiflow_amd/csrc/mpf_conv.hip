@@ -289,36 +289,37 @@ void k_conv3x3(const MpfConvArgs a)
 
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
         if (chunk) __syncthreads();
-        u32x4 staged[NI], wst[WLDS ? NW : 1];
+        u32x4 staged[NI];
         if constexpr (WLDS) {
+            // LDS-DMA (global_load_lds_dwordx4): the fragments are a plain copy (host-packed in fragment order), so they go global ->
+            // LDS without passing through registers or ds_write; destination = wave-uniform base + lane * 16, i.e. one 1 KB fragment
+            // per wave instruction.  The __syncthreads() below drains it (hipcc waits vmcnt(0) before the barrier), and the barrier
+            // at the top of the loop keeps it from overtaking the previous chunk's fragment reads.  Against staging through
+            // registers: -20 % on the full-resolution bilinear layer, -5..-10 % on the decoder's 24-block layers, and it makes
+            // LDS staging the better choice on three more layers (profiles/r2/engine_glds_layers.txt)
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
-                const unsigned v = (unsigned)(tid + j * 256);
-                const unsigned ks = v / (NB * 64), r = v - ks * (NB * 64);
-                if (NW * 256 == WVEC || v < WVEC) wst[j] = wbase[(unsigned)(chunk * KS + ks) * wstride + r];
+                const unsigned vb = (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 64 + j * 256);
+                if (NW * 256 == WVEC || vb < WVEC) {
+                    const unsigned v = vb + (unsigned)lane;
+                    const unsigned ks = v / (NB * 64), r = v - ks * (NB * 64);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wbase + ((unsigned)(chunk * KS + ks) * wstride + r)),
+                                                     (__attribute__((address_space(3))) void *)(wlds + vb * 16), 16, 0, 0);
+                }
             }
         }
         if constexpr (RAW) {
             if ((unsigned)(chunk * VPP) < ((unsigned)a.CA >> 3)) {              // uniform: a chunk of the upsampled source
-                u32x4 rv[NR];
 #pragma unroll
-                for (int k = 0; k < NR; ++k)
-                    if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC) rv[k] = ((const u32x4 *)a.srcA)[rawsrc[k] + (unsigned)(chunk * VPP)];
-#pragma unroll
-                for (int k = 0; k < NR; ++k)
-                    if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC) *reinterpret_cast<u32x4 *>(raw + (tid + k * 256) * 16) = rv[k];
+                for (int k = 0; k < NR; ++k)                                    // also a plain copy: LDS-DMA, lane-linear destination
+                    if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const u32x4 *)a.srcA + (rawsrc[k] + (unsigned)(chunk * VPP))),
+                                                         (__attribute__((address_space(3))) void *)(raw + (__builtin_amdgcn_readfirstlane(wave) * 64 + k * 256) * 16), 16, 0, 0);
                 __syncthreads();
             }
         }
 #pragma unroll
         for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv, raw, VPP * 16, RW * VPP * 16);
-        if constexpr (WLDS) {
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int v = tid + j * 256;
-                if (NW * 256 == WVEC || v < WVEC) *reinterpret_cast<u32x4 *>(wlds + v * 16) = wst[j];
-            }
-        }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int p = sp + k * PPT;

@@ -33,9 +33,10 @@ def _ct(layer, default):
     return default
 
 
-# layers whose weights go through LDS once per workgroup (measured per layer at 64x384x1280, profiles/r1/engine_layers.txt):
-# the many-chunk / many-block layers and the full-resolution single-block ones; the others load fragments per wave
-_WLDS_LAYERS = {"l1", "l2", "l5", "l6", "l8", "l9", "up0_4", "up1_4", "up1_3", "up1_2", "up1_1", "up0_3", "up0_2", "up0_1", "up0_0"}
+# layers whose weights go through LDS once per workgroup (by LDS-DMA) - all but three, measured per layer at 64x384x1280
+# (profiles/r2/engine_glds_layers.txt): the stride-2 encoder layers of the feature-mask network load their fragments per wave
+_PER_WAVE_LAYERS = {"l2", "l3", "l4"}
+_WLDS_LAYERS = {"l1", "l5", "l6", "l7", "l8", "l9", "up0_4", "up1_4", "up0_3", "up1_3", "up0_2", "up1_2", "up0_1", "up1_1", "up0_0", "up1_0", "disp0"}
 
 
 def _wlds(layer, default):
@@ -251,7 +252,7 @@ class DecoderEngine:
                 self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(0, 0), (enc[4] + 8, enc[4] + 2)], loader=LD_NEAREST_PLANE, ct=_ct("up0_4", 32), name="up0_4")
             else:
                 cin = dec[i + 1]
-                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(pad8(cin), cin)], loader=LD_DIRECT, ct=_ct("up0_%d" % i, 16 if i in (1, 2, 3) else 32), name="up0_%d" % i)
+                self.up0[i] = G(device, blk0.gated_conv, blk0.bn, [(pad8(cin), cin)], loader=LD_DIRECT, ct=_ct("up0_%d" % i, 16), name="up0_%d" % i)
             cx = dec[i]
             if i > 0:
                 self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx), (enc[i - 1] + 8, enc[i - 1] + 2)],

@@ -37,12 +37,13 @@ def ev(fn, n=3):
 
 t_eng = ev(lambda: hp(img, dsp))
 E.ConvLayer.__call__ = timed
-for _ in range(3):
+ITERS = int(os.environ.get("BENCH_ENGINE_ITERS", "3"))
+for _ in range(ITERS):
     hp(img, dsp)
 torch.cuda.synchronize()
 E.ConvLayer.__call__ = orig
 tot = 0
-print("%-6s %-4s %-3s %-5s %-14s %9s %9s %9s" % ("loader", "epi", "ct", "nblk", "S,Hin,Win", "ms", "TFLOP/s", "GB/s(out)"))
+print("%-6s %-4s %-3s %-5s %-14s %9s %9s %9s  %s" % ("loader", "epi", "ct", "nblk", "S,Hin,Win", "ms", "TFLOP/s", "GB/s(out)", "layer (blocks per workgroup, weights through LDS)"))
 for lst in times.values():
     t = sum(a.elapsed_time(b) for a, b, _, _ in lst) / len(lst)
     L, (s, hin, win) = lst[0][2], lst[0][3]
@@ -50,7 +51,8 @@ for lst in times.values():
     flops = 2.0 * s * hout * wout * L.nblk * 16 * L.nchunk * E.ksteps(L.ct) * 32
     outb = s * hout * wout * (L.Cst * 2 if L.epi in (0, 2) else 4 * L.Cst)
     tot += t
-    print("%-6d %-4d %-3d %-5d %-14s %9.3f %9.1f %9.1f" % (L.loader, L.epi, L.ct, L.nblk, "%d,%d,%d" % (s, hin, win), t, flops / t / 1e9, outb / t / 1e6))
+    print("%-6d %-4d %-3d %-5d %-14s %9.3f %9.1f %9.1f  %s (%d, %s)" % (L.loader, L.epi, L.ct, L.nblk, "%d,%d,%d" % (s, hin, win), t, flops / t / 1e9, outb / t / 1e6,
+                                                                    L.name, L.nblk // L.ncg, "lds" if E._wlds(L.name, L.wlds_default) else "per wave"))
 print("engine forward %.2f ms (conv launches %.2f ms)" % (t_eng, tot))
 fm = lambda: hp.fmn(img[0], dsp[0, 0], m.plane_disparities(img)[0])
 print("feature-mask network on the engine %.2f ms" % ev(fm))

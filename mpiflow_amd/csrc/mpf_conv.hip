@@ -47,6 +47,15 @@ __host__ __device__ constexpr int pix_stride_bytes(int CT, int ST)
     return CT == 8 ? 16 : CT == 16 ? (ST == 1 ? 32 : 48) : (ST == 1 ? 96 : 80);
 }
 
+// floats of the epilogue rows a workgroup parks in LDS - none where those bytes would cost a resident workgroup (the LDS is handed
+// out in 1280-byte granules on gfx950: the 8-block stride-2 layer went from 3 to 2 workgroups per CU over 1 KB of rows, +16 % time)
+__host__ __device__ constexpr int lds_workgroups(int bytes) { return 163840 / ((bytes + 1279) / 1280 * 1280); }
+__host__ __device__ constexpr int ep_lds_floats(int EPI, int NB, int other_lds_bytes)
+{
+    const int n = EPI == EP_GATED_PLANAR_F32 ? 0 : (EPI == EP_GATED_ELU ? 2 * (NB / 2) * 16 : 2 * NB * 16);
+    return lds_workgroups(other_lds_bytes + n * 4) == lds_workgroups(other_lds_bytes) ? n : 0;
+}
+
 __device__ __forceinline__ u32x4 zero4() { return u32x4{0u, 0u, 0u, 0u}; }
 
 __device__ __forceinline__ unsigned pack2(float a, float b)
@@ -140,14 +149,8 @@ __device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs 
         const int ya = a.HA == a.Hin ? y : (y >> 1), xa = a.HA == a.Hin ? x : (x >> 1);
         st.ia = (unsigned)((s * a.HA + ya) * a.WA + xa);
         st.ib = (unsigned)(y * a.Win + x);
-        st.cm2 = __float2half2_rn(0.f);
+        st.cm2 = __float2half2_rn(0.f);                      // the plane's mask values are filled in by the kernel (batched loads)
         st.masks = 0u;
-        if (a.CB) {
-            const size_t o = (size_t)s * a.Hin * a.Win + st.ib;
-            const float cm = a.cm[o];
-            st.cm2 = __float2half2_rn(cm);
-            st.masks = pack2(cm, a.fm[o]);
-        }
     }
 }
 
@@ -230,9 +233,26 @@ void k_conv3x3(const MpfConvArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *tile = lds, *wlds = lds + TILE_BYTES;      // input tile | this chunk's A fragments (shared by the 4 waves)
     unsigned char *raw = lds + TILE_BYTES + WL_BYTES;         // | raw low-resolution tile of the bilinear loader
+    // | this workgroup's slice of the epilogue rows, parked at kernel entry: read from global memory in the
+    // epilogue, hipcc sinks each block's loads into that block's store branch, i.e. 2 dependent L2 round trips per block with
+    // nothing left to overlap them (profiles/r2/engine_epilogue_rows_in_lds.txt)
+    constexpr int RAW_BYTES_ = RAW ? RH * RW * VPP * 16 : 0;
+    float *eplds = reinterpret_cast<float *>(lds + TILE_BYTES + WL_BYTES + RAW_BYTES_);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.z / a.ncg, cg = blockIdx.z - s * a.ncg;
+    // affine epilogues use rows 0, 1 of all NB blocks; the gated one rows 1, 2 of its NB/2 feature blocks; the planar one none.
+    // One value per thread, loaded here (the round trip overlaps the staging set-up) and parked in LDS: in its own region where
+    // that costs no resident workgroup (EPW > 0), else in the input tile's space once the last MFMA phase is over.
+    constexpr bool EP_GATED = EPI == EP_GATED_ELU || EPI == EP_GATED_PLANAR_F32;
+    constexpr int EPN = EPI == EP_GATED_PLANAR_F32 ? 0 : (EPI == EP_GATED_ELU ? (NB / 2) * 16 : NB * 16);
+    constexpr int EPW = ep_lds_floats(EPI, NB, TILE_BYTES + WL_BYTES + RAW_BYTES_) / 2;
+    static_assert(2 * EPN <= 256 && 2 * EPN * 4 <= TILE_BYTES, "one epilogue value per thread");
+    float epv = 0.f;
+    if (tid < 2 * EPN) {
+        const int row = tid / (EPN ? EPN : 1), c = tid - row * EPN;
+        epv = a.ep[(row + (EP_GATED ? 1 : 0)) * (a.nblk * 16) + cg * (NB * 16) + c];
+    }
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
     const int ix0 = ox0 * ST - 1, iy0 = oy0 * ST - 1;
 
@@ -257,6 +277,25 @@ void k_conv3x3(const MpfConvArgs a)
         const int ly = p / LW, lx = p - ly * LW;
         stage_init<LOADER>(stage[k], a, s, iy0 + ly, ix0 + lx, p < LH * LW, ry0, rx0, RW, VPP, sv);
     }
+    if constexpr (LOADER == LD_NEAREST_PLANE) {
+        // the plane's mask values of the staged pixels: all 2 * NI loads first, conversions after (written per pixel, hipcc waited
+        // for each load before issuing the next: 6 dependent round trips at the head of every workgroup)
+        if (a.CB) {
+            float cmv[NI], fmv[NI];
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const size_t o = (size_t)s * a.Hin * a.Win + stage[k].ib;
+                cmv[k] = a.cm[o];
+                fmv[k] = a.fm[o];
+            }
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                stage[k].cm2 = __float2half2_rn(cmv[k]);
+                stage[k].masks = pack2(cmv[k], fmv[k]);
+            }
+        }
+    }
+    if (EPW && tid < 2 * EPN) eplds[tid] = epv;
 
     const int q = lane >> 4, pi = lane & 15;
     // gated layers start their accumulators at the convolution biases (row 4q+i of block b), the others at zero
@@ -318,8 +357,24 @@ void k_conv3x3(const MpfConvArgs a)
                 __syncthreads();
             }
         }
+        if constexpr (RAW) {
+            // the source of a chunk (upsampled A from the raw tile / skip tensor B) is uniform: branch ONCE around the NI passes, so that
+            // the B loads of all passes are in flight together (inside stage_load each pass had its own branch and its own wait)
+            if ((unsigned)(chunk * VPP) < ((unsigned)a.CA >> 3)) {
 #pragma unroll
-        for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv, raw, VPP * 16, RW * VPP * 16);
+                for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv, raw, VPP * 16, RW * VPP * 16);
+            } else {
+                const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3, vq = (unsigned)(chunk * VPP + sv) - va, vc = vq < vb ? vq : vb - 1;
+                u32x4 ld[NI];
+#pragma unroll
+                for (int k = 0; k < NI; ++k) ld[k] = ((const u32x4 *)a.srcB)[(size_t)stage[k].ib * vb + vc];
+#pragma unroll
+                for (int k = 0; k < NI; ++k) staged[k] = select4(stage[k].ok && vq < vb, ld[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv, raw, VPP * 16, RW * VPP * 16);
+        }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int p = sp + k * PPT;
@@ -347,6 +402,13 @@ void k_conv3x3(const MpfConvArgs a)
         }
     }
 
+    const float *eprows = eplds;
+    if constexpr (EPW == 0 && EPN > 0) {
+        __syncthreads();                                      // every wave is done reading the tile
+        if (tid < 2 * EPN) reinterpret_cast<float *>(tile)[tid] = epv;
+        __syncthreads();
+        eprows = reinterpret_cast<const float *>(tile);
+    }
 #include "mpf_conv_epilogue.inc"
 }
 
@@ -355,7 +417,8 @@ int launch_w(const MpfConvArgs &a, hipStream_t st)
 {
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, KS = (9 * CT + 31) / 32;
     constexpr int RAW_BYTES = LOADER == LD_BILINEAR_CAT ? raw_rows(LH) * raw_cols(LW) * (CT / 8) * 16 : 0;
-    constexpr int LDS_BYTES = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + (WLDS ? KS * NB * 1024 : 0) + RAW_BYTES;
+    constexpr int LDS_OTHER = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + (WLDS ? KS * NB * 1024 : 0) + RAW_BYTES;
+    constexpr int LDS_BYTES = LDS_OTHER + ep_lds_floats(EPI, NB, LDS_OTHER) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "tile + weights exceed the LDS of a CU");
     static bool attr_set = false;
     if (!attr_set && LDS_BYTES > 64 * 1024) {

@@ -1182,15 +1182,24 @@ k_merge(const float *__restrict__ frame, const float *__restrict__ frame_dyn, co
 {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const bool obj = obj_mask[n] >= th;                 // source-frame mask   utils/utils.py:270-271, :277-278
-    flow_mix[2 * n] = obj ? flow[n] : flow_dyn[n];
-    flow_mix[2 * n + 1] = obj ? flow[N + n] : flow_dyn[N + n];
-    const float m = mask[n], md = mask_dyn[n];
+    // every input first, unconditionally (all addresses are valid): written as `cond ? a[n] : b[n]` hipcc branches around the loads and
+    // the wave sits out six dependent round trips in a kernel that is nothing but latency
+    const float om = obj_mask[n], m = mask[n], md = mask_dyn[n];
+    const float fx = flow[n], fy = flow[N + n], gx = flow_dyn[n], gy = flow_dyn[N + n];
+    float fr[3], fd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        fr[c] = frame[c * N + n];
+        fd[c] = frame_dyn[c * N + n];
+    }
+    const bool obj = om >= th;                          // source-frame mask   utils/utils.py:270-271, :277-278
+    flow_mix[2 * n] = obj ? fx : gx;
+    flow_mix[2 * n + 1] = obj ? fy : gy;
     const bool sel = m >= th;                           // target-frame masks  :273-276
 #pragma unroll
     for (int c = 0; c < 3; ++c) {                       // BGR order           :240-242
-        uint8_t a = (m < th) ? (uint8_t)255 : mpf_to_u8(frame[(2 - c) * N + n]);
-        uint8_t b = (md < th) ? (uint8_t)255 : mpf_to_u8(frame_dyn[(2 - c) * N + n]);
+        const uint8_t a = (m < th) ? (uint8_t)255 : mpf_to_u8(fr[2 - c]);
+        const uint8_t b = (md < th) ? (uint8_t)255 : mpf_to_u8(fd[2 - c]);
         frame_mix[3 * n + c] = sel ? a : b;
     }
     const float f = sel ? 1.0f : md;                    // :280-283

@@ -457,6 +457,12 @@ int dispatch_nb(const MpfConvArgs &a, int nb, hipStream_t st)
 // the 2x2, 4x4 and 8x8 block sums are lane reductions (xor 1|2, 4|8, 16|32); the 16x16 and 32x32 sums are combined from the
 // per-wave sums parked in LDS.  Pass 1 is an online softmax (running max and sum), pass 2 normalises, accumulates the
 // cumulative mask and emits everything - the logits are read twice and nothing else is read.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
 __global__ __launch_bounds__(1024) void k_plane_masks(const float *__restrict__ logits, int S, int H, int W, float *__restrict__ fmask,
                                                        float *__restrict__ cum, float *__restrict__ cm2, float *__restrict__ fm2,
                                                        float *__restrict__ cm4, float *__restrict__ fm4, float *__restrict__ cm8,
@@ -471,18 +477,35 @@ __global__ __launch_bounds__(1024) void k_plane_masks(const float *__restrict__ 
     const int x = blockIdx.x * 32 + wx * 8 + lx, y = blockIdx.y * 32 + wy * 8 + ly;
     const bool in = x < W && y < H;
     const size_t n = (size_t)H * W, o = (size_t)(in ? y : 0) * W + (in ? x : 0);
+    // the logits are read CH planes at a time, all CH loads in flight together: plane by plane (load, wait, use) the kernel was 2 * S
+    // dependent memory round trips long and nothing else (0.28 ms at 64 x 384 x 1280); same operations in the same order
+    constexpr int CH = 16;
     float mx = -INFINITY, sum = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float v = logits[s * n + o];
-        const float m2 = fmaxf(mx, v);
-        sum = sum * __expf(mx - m2) + __expf(v - m2);
-        mx = m2;
+    for (int s0 = 0; s0 < S; s0 += CH) {
+        float v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = logits[(size_t)min(s0 + j, S - 1) * n + o];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (s0 + j < S) {
+                const float m2 = fmaxf(mx, v[j]);
+                sum = sum * __expf(mx - m2) + __expf(v[j] - m2);
+                mx = m2;
+            }
+        }
     }
     const float inv = 1.f / sum;
     const int H2 = H >> 1, W2 = W >> 1, H4 = H >> 2, W4 = W >> 2, H8 = H >> 3, W8 = W >> 3;
     float run = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float p = __expf(logits[s * n + o] - mx) * inv;
+    for (int s0 = 0; s0 < S; s0 += CH) {
+      float lg[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) lg[j] = logits[(size_t)min(s0 + j, S - 1) * n + o];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int s = s0 + j;
+        if (s >= S) break;
+        const float p = __expf(lg[j] - mx) * inv;
         const float ctx = 1.f - run;                         // context mask: 1 - cumulative mask of the planes in front
         run += p;
         if (in) {
@@ -490,14 +513,15 @@ __global__ __launch_bounds__(1024) void k_plane_masks(const float *__restrict__ 
             if (fmask) fmask[s * n + o] = p;
         }
         float c = in ? ctx : 0.f, f = in ? p : 0.f;
-        c += __shfl_xor(c, 1); f += __shfl_xor(f, 1);
-        c += __shfl_xor(c, 2); f += __shfl_xor(f, 2);
+        // 2x2 / 4x4 sums by DPP (VALU operand permutes) instead of ds_bpermute: the 12 shuffles per plane were LDS-pipe time
+        c += dpp_f<0xB1>(c); f += dpp_f<0xB1>(f);            // quad_perm [1,0,3,2]: lane ^ 1
+        c += dpp_f<0x4E>(c); f += dpp_f<0x4E>(f);            // quad_perm [2,3,0,1]: lane ^ 2
         if ((lane & 3) == 0 && in) {
             const size_t q = (size_t)s * H2 * W2 + (size_t)(y >> 1) * W2 + (x >> 1);
             cm2[q] = c * 0.25f; fm2[q] = f * 0.25f;
         }
-        c += __shfl_xor(c, 4); f += __shfl_xor(f, 4);
-        c += __shfl_xor(c, 8); f += __shfl_xor(f, 8);
+        c += dpp_f<0x141>(c); f += dpp_f<0x141>(f);          // row_half_mirror: the other quad of the 8 lanes (all its lanes hold its sum)
+        c += dpp_f<0x140>(c); f += dpp_f<0x140>(f);          // row_mirror: the other half of the 16 lanes
         if ((lane & 15) == 0 && in) {
             const size_t q = (size_t)s * H4 * W4 + (size_t)(y >> 2) * W4 + (x >> 2);
             cm4[q] = c * 0.0625f; fm4[q] = f * 0.0625f;
@@ -512,6 +536,7 @@ __global__ __launch_bounds__(1024) void k_plane_masks(const float *__restrict__ 
             wsum[(s * 16 + wave) * 2] = c;
             wsum[(s * 16 + wave) * 2 + 1] = f;
         }
+      }
     }
     __syncthreads();
     // 16x16 (4 per block) and 32x32 (1 per block) sums for every plane

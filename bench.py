@@ -31,6 +31,7 @@ another - information beside `value`, which stays the single-stream figure so th
 bounded sample of the same workload (dynamic pairs), rank 0, N=1 only.
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import os
@@ -193,23 +194,25 @@ def measured_traffic():
 
 
 def hbm_reference(dev, nbytes=1 << 30, reps=10):
-    """What this box's HBM delivers to two trivial streaming kernels (report an on-box figure beside the 8 TB/s
-    spec): a device-to-device copy (read + write) and a read-only reduction, `nbytes` each, HIP events, outside the timed region."""
+    """What this box's HBM delivers to the plainest streaming kernels (report an on-box figure beside the 8 TB/s
+    spec): mpf_stream_probe's 16-byte-per-lane read-only and copy kernels over 1 GiB, HIP events, outside the timed region."""
+    lib = _lib.load()
     a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
     b = torch.empty_like(a)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def timed(fn, moved):
-        fn()
+    def timed(mode, moved):
+        _lib.check(lib.mpf_stream_probe(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), nbytes, mode, st), "mpf_stream_probe")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            fn()
+            lib.mpf_stream_probe(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), nbytes, mode, st)
         e1.record()
         torch.cuda.synchronize()
         return moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    rec = {"copy_GBps": timed(lambda: b.copy_(a), 2 * nbytes), "read_GBps": timed(lambda: a.sum(), nbytes), "bytes": nbytes,
-           "note": "torch copy_ / sum on 1 GiB of fp32; the roofline fractions above are against the 8 TB/s specification, not against these"}
+    rec = {"read_GBps": timed(0, nbytes), "copy_GBps": timed(1, 2 * nbytes), "bytes": nbytes,
+           "note": "mpf_stream_probe (16 B per lane, non-temporal) on 1 GiB; the roofline fractions above are against the 8 TB/s specification, not against these"}
     del a, b
     return rec
 

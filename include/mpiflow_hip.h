@@ -144,6 +144,11 @@ int mpf_inpaint_host(const uint8_t *img, const uint8_t *mask, int H, int W, int 
 #define MPF_PAIR_STATS_SLICES 64
 int mpf_pair_stats(const float *d_flow_mix, const uint8_t *d_fill_mask, int H, int W, double *d_out, void *stream);
 
+/* Measurement aid (bench.py `hbm_reference`; SURVEY.md 8(d) asks for an on-box streaming figure beside the 8 TB/s specification):
+ * mode 0 reads `bytes` from d_src with 16-byte loads (d_dst: one float, never written for ordinary data), mode 1 copies d_src to
+ * d_dst.  16-byte aligned device buffers, bytes a multiple of 16.  No counterpart in the reference. */
+int mpf_stream_probe(const void *d_src, void *d_dst, size_t bytes, int mode, void *stream);
+
 /* Frame -> PNG scanlines on the device (what cv2.imwrite does first, utils/utils.py:240-242 / gen_3dphoto_dynamic_v2.py:121-122):
  * d_bgr u8 [H,W,3] -> d_scanlines u8 [H, 1 + 3W]: filter byte 2 ("Up") followed by the RGB row minus the previous row
  * (mod 256).  The host only deflates these bytes and wraps them in chunks (mpiflow_amd/io_formats.py). */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mpf_inpaint_host": (c_i, [c_p, c_p, c_i, c_i, c_i, ctypes.c_double, c_i, c_p]),
     "mpf_png_filter_up": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "mpf_pair_stats": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+    "mpf_stream_probe": (c_i, [c_p, c_p, ctypes.c_size_t, c_i, c_p]),
     "mpf_to_u8_bgr": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "mpf_src_xyz": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "mpf_transform_xyz": (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p]),

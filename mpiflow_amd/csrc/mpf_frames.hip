@@ -143,6 +143,35 @@ extern "C" int mpf_pair_stats(const float *d_flow_mix, const uint8_t *d_fill_mas
     return mpf_launch_status("k_pair_stats");
 }
 
+// ---- streaming probe: what HBM delivers to the plainest possible kernels on this box (bench.py reports it beside the 8 TB/s peak) ----
+typedef float mpf_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_stream_copy(const mpf_f4 *__restrict__ src, mpf_f4 *__restrict__ dst, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
+__global__ void __launch_bounds__(256) k_stream_read(const mpf_f4 *__restrict__ src, float *__restrict__ sink, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const mpf_f4 v = __builtin_nontemporal_load(&src[i]);
+        acc += (v.x + v.y) + (v.z + v.w);
+    }
+    if (acc == 12345.678f) *sink = acc;                      // keeps the loads alive; never true for the probe's data
+}
+
+extern "C" int mpf_stream_probe(const void *d_src, void *d_dst, size_t bytes, int mode, void *stream)
+{
+    MPF_REQUIRE(d_src && d_dst && bytes >= 16 && (bytes & 15) == 0 && (mode == 0 || mode == 1), "mpf_stream_probe: bad argument");
+    MPF_REQUIRE((((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0, "mpf_stream_probe: buffers must be 16-byte aligned");
+    const size_t n4 = bytes / 16;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 256u * 32u ? (n4 + 255) / 256 : 256u * 32u);   // 32 workgroups per CU, grid-stride
+    if (mode == 0) hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const mpf_f4 *)d_src, (float *)d_dst, n4);
+    else hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const mpf_f4 *)d_src, (mpf_f4 *)d_dst, n4);
+    return mpf_launch_status("k_stream_probe");
+}
+
 extern "C" size_t mpf_fill_holes_workspace(int H, int W)
 {
     const size_t N = (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0);

@@ -118,6 +118,9 @@ void zero_border(std::vector<uint8_t> &a, int er, int ec)
 
 inline uint8_t sat8(long v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
 struct Offset { int dk, dl; float w_ns, w_telea; };     // neighbourhood offsets within the radius, raster order, with their distance weights
 
 template <int C>
@@ -192,6 +195,12 @@ void fill(const uint8_t *img, const uint8_t *mask_in, int rows, int cols, int ra
         }
         return out[((size_t)r * cols + c) * C + ch];
     };
+    // NS on 3 channels works on a float copy of the image, one 16-byte vector per pixel, kept in step with `out`
+    std::vector<v4f> fimg;
+    if (C == 3 && method == MPF_INPAINT_NS) {
+        fimg.resize((size_t)rows * cols);
+        for (size_t n = 0; n < (size_t)rows * cols; ++n) fimg[n] = v4f{(float)out[3 * n], (float)out[3 * n + 1], (float)out[3 * n + 2], 0.0f};
+    }
     int ii, jj;
     while (front.pop(ii, jj)) {
         f[(size_t)ii * ec + jj] = KNOWN;
@@ -236,6 +245,58 @@ void fill(const uint8_t *img, const uint8_t *mask_in, int rows, int cols, int ra
                     const float sat = Ia[c] / s[c] + (Jx[c] + Jy[c]) / (sqrtf(Jx[c] * Jx[c] + Jy[c] * Jy[c]) + 1.0e-20f) + 0.5f;
                     out[((size_t)(i - 1) * cols + (j - 1)) * C + c] = sat8(lrintf(sat));
                 }
+            } else if constexpr (C == 3) {
+                // Navier-Stokes rule, the three channels of a neighbour in one 4-lane vector: the neighbour tests are shared, and the
+                // division and the square root each channel needs per neighbour (what this loop spends its time on) become one divps
+                // and one sqrtps.  Lane-wise IEEE operations in the scalar code's order, so the bytes are the same (tests/test_inpaint.py
+                // holds it to the plain-C restatement): 18.0 -> 10.4 ms per 384 x 1280 frame with 33 500 hole pixels on the GPU box's host (tools/bench_inpaint_threads.py).
+                v4f Ia = {0.0f, 0.0f, 0.0f, 0.0f}, sw = {1.0e-20f, 1.0e-20f, 1.0e-20f, 1.0e-20f};
+                auto px3 = [&](int r, int c) -> v4f {                       // the pixel as floats (0..255: exact, differences and |.| too)
+                    if (__builtin_expect(tiny, 0)) {
+                        r = r < 0 ? 0 : (r > rows - 1 ? rows - 1 : r);
+                        c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+                    }
+                    return fimg[(size_t)r * cols + c];
+                };
+                auto vabs = [](v4f a) -> v4f { return __builtin_elementwise_abs(a); };
+                for (const Offset &o : offs) {
+                    const int k = i + o.dk, l = j + o.dl;
+                    if (!(k > 0 && l > 0 && k < er - 1 && l < ec - 1) || inside(k, l)) continue;
+                    const int km = k - 1 + (k == 1), kp = k - 1 - (k == er - 2), lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
+                    const float ry = (float)(k - i), rx = (float)(l - j);
+                    const float r2 = rx * rx + ry * ry;
+                    const bool e_in = inside(k, l + 1), w_in = inside(k, l - 1), s_in = inside(k + 1, l), n_in = inside(k - 1, l);
+                    const v4f ctr = px3(km, lm);
+                    v4f gIx, gIy;
+                    if (!s_in) {
+                        const v4f a = px3(kp + 1, lm), b = px3(kp, lm);
+                        gIx = !n_in ? vabs(a - b) + vabs(b - px3(km - 1, lm)) : vabs(a - b) * 2.0f;
+                    } else {
+                        gIx = !n_in ? vabs(px3(kp, lm) - px3(km - 1, lm)) * 2.0f : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                    if (!e_in) {
+                        const v4f a = px3(km, lp + 1);
+                        gIy = !w_in ? vabs(a - ctr) + vabs(ctr - px3(km, lm - 1)) : vabs(a - ctr) * 2.0f;
+                    } else {
+                        gIy = !w_in ? vabs(ctr - px3(km, lm - 1)) * 2.0f : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                    gIx = -gIx;
+                    const v4f num = rx * gIx + ry * gIy;
+                    // fabsf(dir) <= 0.01 compares in double; 0.01f is the largest float below 0.01, so the float comparison decides the same
+                    const v4i small = vabs(num) <= 0.01f;
+                    const v4f q = vabs(num / __builtin_elementwise_sqrt(r2 * (gIx * gIx + gIy * gIy)));
+                    const v4f dir = small ? v4f{0.000001f, 0.000001f, 0.000001f, 0.000001f} : q;
+                    const v4f w = o.w_ns * dir;
+                    Ia += w * ctr;
+                    sw += w;
+                }
+                v4f filled = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int c = 0; c < 3; ++c) {
+                    const uint8_t v = sat8(lrint((double)Ia[c] / sw[c]));
+                    out[((size_t)(i - 1) * cols + (j - 1)) * 3 + c] = v;
+                    filled[c] = (float)v;
+                }
+                fimg[(size_t)(i - 1) * cols + (j - 1)] = filled;
             } else {
                 float Ia[C], s[C];
                 for (int c = 0; c < C; ++c) { Ia[c] = 0.0f; s[c] = 1.0e-20f; }

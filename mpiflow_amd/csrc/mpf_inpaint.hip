@@ -195,12 +195,21 @@ void fill(const uint8_t *img, const uint8_t *mask_in, int rows, int cols, int ra
         }
         return out[((size_t)r * cols + c) * C + ch];
     };
-    // NS on 3 channels works on a float copy of the image, one 16-byte vector per pixel, kept in step with `out`
+    // 3 channels: the fill rules work on a float copy of the image, one 16-byte vector per pixel, kept in step with `out`
     std::vector<v4f> fimg;
-    if (C == 3 && method == MPF_INPAINT_NS) {
+    if (C == 3) {
         fimg.resize((size_t)rows * cols);
         for (size_t n = 0; n < (size_t)rows * cols; ++n) fimg[n] = v4f{(float)out[3 * n], (float)out[3 * n + 1], (float)out[3 * n + 2], 0.0f};
     }
+    auto px3 = [&](int r, int c) -> v4f {                                   // the pixel as floats (0..255: exact, differences and |.| too)
+        if (__builtin_expect(tiny, 0)) {
+            r = r < 0 ? 0 : (r > rows - 1 ? rows - 1 : r);
+            c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+        }
+        return fimg[(size_t)r * cols + c];
+    };
+    auto vabs = [](v4f a) -> v4f { return __builtin_elementwise_abs(a); };
+    const v4f vzero = {0.0f, 0.0f, 0.0f, 0.0f};
     int ii, jj;
     while (front.pop(ii, jj)) {
         f[(size_t)ii * ec + jj] = KNOWN;
@@ -217,6 +226,39 @@ void fill(const uint8_t *img, const uint8_t *mask_in, int rows, int cols, int ra
                 else gTx = !inside(i, j - 1) ? (float)(g.T(i, j) - g.T(i, j - 1)) : 0.0f;
                 if (!inside(i + 1, j)) gTy = !inside(i - 1, j) ? (float)(g.T(i + 1, j) - g.T(i - 1, j)) * 0.5f : (float)(g.T(i + 1, j) - g.T(i, j));
                 else gTy = !inside(i - 1, j) ? (float)(g.T(i, j) - g.T(i - 1, j)) : 0.0f;
+                if constexpr (C == 3) {
+                    // Telea's rule with the three channels of a neighbour in one vector (the weight is shared by the channels)
+                    v4f Ia = vzero, Jx = vzero, Jy = vzero;
+                    float sw = 1.0e-20f;
+                    for (const Offset &o : offs) {
+                        const int k = i + o.dk, l = j + o.dl;
+                        if (!(k > 0 && l > 0 && k < er - 1 && l < ec - 1) || inside(k, l)) continue;
+                        const int km = k - 1 + (k == 1), kp = k - 1 - (k == er - 2), lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
+                        const float ry = (float)(i - k), rx = (float)(j - l);
+                        const float lev = (float)(1. / (1 + fabsf(g.T(k, l) - g.T(i, j))));
+                        float dir = rx * gTx + ry * gTy;
+                        if (fabsf(dir) <= 0.01) dir = 0.000001f;
+                        const float w = fabsf(o.w_telea * lev * dir);
+                        const bool e_in = inside(k, l + 1), w_in = inside(k, l - 1), s_in = inside(k + 1, l), n_in = inside(k - 1, l);
+                        v4f gIx, gIy;
+                        if (!e_in) gIx = !w_in ? (px3(km, lp + 1) - px3(km, lm - 1)) * 2.0f : px3(km, lp + 1) - px3(km, lm);
+                        else gIx = !w_in ? px3(km, lp) - px3(km, lm - 1) : vzero;
+                        if (!s_in) gIy = !n_in ? (px3(kp + 1, lm) - px3(km - 1, lm)) * 2.0f : px3(kp + 1, lm) - px3(km, lm);
+                        else gIy = !n_in ? px3(kp, lm) - px3(km - 1, lm) : vzero;
+                        Ia += w * px3(km, lm);
+                        Jx -= w * (gIx * rx);
+                        Jy -= w * (gIy * ry);
+                        sw += w;
+                    }
+                    const v4f sat = Ia / sw + (Jx + Jy) / (__builtin_elementwise_sqrt(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f;
+                    v4f filled = vzero;
+                    for (int c = 0; c < 3; ++c) {
+                        const uint8_t v = sat8(lrintf(sat[c]));
+                        out[((size_t)(i - 1) * cols + (j - 1)) * 3 + c] = v;
+                        filled[c] = (float)v;
+                    }
+                    fimg[(size_t)(i - 1) * cols + (j - 1)] = filled;
+                } else {
                 float Ia[C], Jx[C], Jy[C], s[C];
                 for (int c = 0; c < C; ++c) { Ia[c] = Jx[c] = Jy[c] = 0.0f; s[c] = 1.0e-20f; }
                 for (const Offset &o : offs) {
@@ -245,20 +287,13 @@ void fill(const uint8_t *img, const uint8_t *mask_in, int rows, int cols, int ra
                     const float sat = Ia[c] / s[c] + (Jx[c] + Jy[c]) / (sqrtf(Jx[c] * Jx[c] + Jy[c] * Jy[c]) + 1.0e-20f) + 0.5f;
                     out[((size_t)(i - 1) * cols + (j - 1)) * C + c] = sat8(lrintf(sat));
                 }
+                }
             } else if constexpr (C == 3) {
                 // Navier-Stokes rule, the three channels of a neighbour in one 4-lane vector: the neighbour tests are shared, and the
                 // division and the square root each channel needs per neighbour (what this loop spends its time on) become one divps
                 // and one sqrtps.  Lane-wise IEEE operations in the scalar code's order, so the bytes are the same (tests/test_inpaint.py
                 // holds it to the plain-C restatement): 18.0 -> 10.4 ms per 384 x 1280 frame with 33 500 hole pixels on the GPU box's host (tools/bench_inpaint_threads.py).
                 v4f Ia = {0.0f, 0.0f, 0.0f, 0.0f}, sw = {1.0e-20f, 1.0e-20f, 1.0e-20f, 1.0e-20f};
-                auto px3 = [&](int r, int c) -> v4f {                       // the pixel as floats (0..255: exact, differences and |.| too)
-                    if (__builtin_expect(tiny, 0)) {
-                        r = r < 0 ? 0 : (r > rows - 1 ? rows - 1 : r);
-                        c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
-                    }
-                    return fimg[(size_t)r * cols + c];
-                };
-                auto vabs = [](v4f a) -> v4f { return __builtin_elementwise_abs(a); };
                 for (const Offset &o : offs) {
                     const int k = i + o.dk, l = j + o.dl;
                     if (!(k > 0 && l > 0 && k < er - 1 && l < ec - 1) || inside(k, l)) continue;
@@ -272,13 +307,13 @@ void fill(const uint8_t *img, const uint8_t *mask_in, int rows, int cols, int ra
                         const v4f a = px3(kp + 1, lm), b = px3(kp, lm);
                         gIx = !n_in ? vabs(a - b) + vabs(b - px3(km - 1, lm)) : vabs(a - b) * 2.0f;
                     } else {
-                        gIx = !n_in ? vabs(px3(kp, lm) - px3(km - 1, lm)) * 2.0f : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                        gIx = !n_in ? vabs(px3(kp, lm) - px3(km - 1, lm)) * 2.0f : vzero;
                     }
                     if (!e_in) {
                         const v4f a = px3(km, lp + 1);
                         gIy = !w_in ? vabs(a - ctr) + vabs(ctr - px3(km, lm - 1)) : vabs(a - ctr) * 2.0f;
                     } else {
-                        gIy = !w_in ? vabs(ctr - px3(km, lm - 1)) * 2.0f : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                        gIy = !w_in ? vabs(ctr - px3(km, lm - 1)) * 2.0f : vzero;
                     }
                     gIx = -gIx;
                     const v4f num = rx * gIx + ry * gIy;

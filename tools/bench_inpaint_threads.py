@@ -14,6 +14,10 @@ for x0 in range(60, W, 160):
 mask |= (rs.rand(H, W) < 0.01).astype(np.uint8)
 print("hole pixels", int(mask.sum()), "host threads available", os.cpu_count())
 ops.inpaint_host(img, mask, 3, ops.INPAINT_NS)
+t0 = time.perf_counter()
+for _ in range(5):
+    ops.inpaint_host(img, mask, 3, ops.INPAINT_TELEA)
+print("Telea, one thread: %.1f ms per frame" % ((time.perf_counter() - t0) / 5 * 1e3))
 for T in (1, 4, 8, 16, 32, 64):
     n_each = 6
     def work():

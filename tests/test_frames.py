@@ -234,3 +234,28 @@ def test_pair_stats_kernel(tmp_path):
     assert r["pairs"] == 3 and r["hole_px"] == tot["hole"]
     assert abs(r["sum_flow_mag"] - tot["sum"]) < 1e-3 * tot["sum"] * 1e-3
     assert abs(r["max_flow_mag"] - tot["mx"]) < 1e-4 and r["neg_min_flow"] == float(tot["neg"])
+
+
+@pytest.mark.gpu
+def test_stream_probe_copies_and_validates():
+    """mpf_stream_probe (bench.py's on-box HBM reference): mode 1 is an exact copy, mode 0 leaves its sink alone, bad arguments
+    are refused with an error code."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes
+    from mpiflow_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    a = torch.randn(1 << 20, device=dev)
+    b = torch.zeros_like(a)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    assert lib.mpf_stream_probe(p(a), p(b), a.numel() * 4, 1, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    sink = torch.full((4,), 7.0, device=dev)
+    assert lib.mpf_stream_probe(p(a), p(sink), a.numel() * 4, 0, st) == 0
+    torch.cuda.synchronize()
+    assert (sink == 7.0).all()
+    assert lib.mpf_stream_probe(p(a), p(b), 24, 1, st) != 0          # not a multiple of 16
+    assert lib.mpf_stream_probe(p(a), p(b), 64, 2, st) != 0          # unknown mode

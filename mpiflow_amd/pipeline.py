@@ -65,6 +65,28 @@ class PairRenderer:
         bf, P = ops.blend_flow_params(k_inv, d, H_ts)
         return dict(P=P, blend=ops.upload_params(bf, self.device), warp=wp, k_inv=k_inv, depths=d)
 
+    def prepare_many(self, K, disparity, pose_pairs):
+        """prepare() for the R pairs of one image at once: ONE batched homography evaluation over the 2R poses (bit-identical to the
+        per-pair ones: every matrix goes through the same per-matrix code) and ONE pinned buffer / H2D copy for the 3R parameter
+        blocks (each block starts on a 256-byte boundary).  -> R dicts like prepare()'s."""
+        k_inv, d = self._constants(K, disparity)
+        flat = [G for pair in pose_pairs for G in pair]
+        H_ts, H_st = host_math.homographies_multi(flat, k_inv, K, d)
+        blocks = []
+        for r, pair in enumerate(pose_pairs):
+            blocks.append(ops.blend_flow_params(k_inv, d, H_ts[2 * r:2 * r + 2])[0])
+            blocks += [ops.warp_params(H_st[2 * r + v], k_inv, pair[v], d) for v in range(2)]
+        offs, n = [], 0
+        for b in blocks:
+            offs.append(n)
+            n += (b.numel() + 63) // 64 * 64
+        host = torch.zeros(n, dtype=torch.float32).pin_memory()
+        for o, b in zip(offs, blocks):
+            host[o:o + b.numel()] = b
+        dev = host.to(device=self.device, non_blocking=True)
+        view = lambda i: dev[offs[i]:offs[i] + blocks[i].numel()]  # noqa: E731
+        return [dict(P=2, blend=view(3 * r), warp=[view(3 * r + 1), view(3 * r + 2)], k_inv=k_inv, depths=d) for r in range(len(pose_pairs))]
+
     # -- device side: launches only ------------------------------------------------------------------------------------
     def blend(self, mpi, image, K, disparity, cum_mask=None):
         """Blend the source image into the stack once per IMAGE (the blended stack does not depend on the pose): the
@@ -115,8 +137,8 @@ class PairRenderer:
         R = len(obj_masks)
         bufs = self._pair_buffers(R)
         views = []
-        for om, (G_cam, G_dyn), b in zip(obj_masks, poses, bufs):
-            prep = self.prepare(K, disparity, [G_cam, G_dyn])
+        preps = self.prepare_many(K, disparity, [[G_cam, G_dyn] for (G_cam, G_dyn) in poses])
+        for om, prep, b in zip(obj_masks, preps, bufs):
             ops.src_blend_flow(mpi, image, out_rgba=None, want_rgba=False, out_flows=b["flows"], dparams=prep["blend"], P=2, obj_mask=om,
                                quads=b["quads"][0], quads_complement=b["quads"][1], cum_mask=cum_mask)
             views += [dict(dparams=prep["warp"][v], quads=b["quads"][v], out=b["views"][v]) for v in range(2)]

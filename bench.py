@@ -76,10 +76,34 @@ def parse():
     return p.parse_args()
 
 
-def init_dist():
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here - one process per GPU under
+    torch.distributed.run (the form the driver uses itself), LOCAL_RANK = device index, rendezvous on 127.0.0.1 - and pass their
+    output and exit status through.  The reference's model is the same: one process per GPU (scripts/gen_train_kitti15_v2.sh:1-4,
+    gen_3dphoto_dynamic_v2.py:78).  Fails loudly when the box has fewer devices than ranks asked for."""
+    import socket
+    import subprocess
+    forced = "MPIFLOW_FORCE_DEVICE" in os.environ            # test hook: all ranks on one device over gloo
+    have = torch.cuda.device_count()
+    if have < a.gpus and not forced:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible on this box" % (a.gpus, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MPIFLOW_SELF_LAUNCHED="1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def init_dist(a):
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (a.gpus, world))
     # test hooks (the multi-process path on a 1-GPU box / in CPU CI): MPIFLOW_DIST_BACKEND=gloo, MPIFLOW_FORCE_DEVICE=0
     backend = os.environ.get("MPIFLOW_DIST_BACKEND", "nccl")
     forced = "MPIFLOW_FORCE_DEVICE" in os.environ
@@ -88,6 +112,7 @@ def init_dist():
     if local >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d wants cuda:%d but only %d device(s) are visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
+    ranks = [pipeline.device_description(local)]
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -95,9 +120,13 @@ def init_dist():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend=backend)
-        if backend == "nccl" and not forced:
-            pipeline.assert_distinct_devices(local)        # one process per GPU: fail fast, before RCCL hangs on a shared device
-    return rank, world, local
+        assert dist.get_world_size() == world and dist.get_rank() == rank
+        # one process per GPU: checked over a gloo side group BEFORE the first RCCL collective (which would hang on a shared device)
+        ids, ranks = pipeline.exchange_device_records(local)
+        dup = sorted({i for i in ids if ids.count(i) > 1})
+        if dup and backend == "nccl" and not forced:
+            raise SystemExit("bench.py: ranks share a GPU: %s" % dict(enumerate(ids)))
+    return rank, world, local, backend if world > 1 else None, ranks
 
 
 def make_image(S, H, W, dev, seed):
@@ -286,7 +315,7 @@ def overlap_record(S, H, W, dev, n_streams=2, images=4, steps=8):
 
 def main():
     a = parse()
-    rank, world, local = init_dist()
+    rank, world, local, backend, rank_devices = init_dist(a)
     dev = torch.device("cuda", local)
     _lib.load()
     if a.sbf_px:
@@ -350,7 +379,11 @@ def main():
             "config": {"workload": cfg_name, "mode": a.mode,
                        "pairs_per_step_per_gpu": (len(order) if order is not None else B), "resident_stacks_per_gpu": B,
                        "sharding": "independent images per rank (i % world == rank), stats all-reduce only",
-                       "device": _lib.device_info(local)},
+                       "device": _lib.device_info(local),
+                       "world_size": world, "backend": ("%s (RCCL over xGMI)" % backend if backend == "nccl" else backend) if world > 1 else "none (single rank)",
+                       "launcher": "self (bench.py --gpus N spawned torch.distributed.run)" if os.environ.get("MPIFLOW_SELF_LAUNCHED") else
+                                   ("external (torchrun)" if world > 1 else "none"),
+                       "ranks": rank_devices},
             "roofline": roof,
             "roofline_stage_ac": roofs["stage_ac"],
         }

@@ -9,7 +9,8 @@ reference's instance ids and poses.
 
 What is different:
   * the render/flow path runs in the HIP kernels of mpiflow_amd (fp32);
-  * images are sharded over ranks when launched under torchrun (rank r takes images i = r mod world); every rank
+  * images are sharded over ranks - `--gpus N` starts one process per GPU itself, or launch under torchrun - (rank r takes images
+    i = r mod world); every rank
     replays the whole RNG schedule, so an N-GPU run produces exactly the files of a 1-GPU run; one all-reduce of a
     7-float statistics vector (RCCL over xGMI) closes the batch;
   * the MPI producer: `--mpi-from model` runs the AdaMPI network (mpiflow_amd.model, state-dict compatible with the
@@ -72,7 +73,14 @@ def parse(argv=None):
                         "builtin = the same algorithm restated in libmpiflow_hip.so, run on the writer threads; peel (alias hip) = the onion-peel "
                         "GPU kernel, NOT OpenCV's algorithm; none = leave holes white")
     p.add_argument("--resume", action="store_true", help="skip images whose outputs (all --repeat pairs) already exist; the RNG schedule is unaffected")
-    p.add_argument("--writers", type=int, default=max(8, min(32, (os.cpu_count() or 8) // 4)), help="writer threads (hole fill, PNG encode and file I/O overlap the GPU)")
+    p.add_argument("--gpus", type=int, default=0,
+                   help="GPUs of this node to shard the images over, one process per GPU (the reference's model: scripts/gen_train_kitti15_v2.sh "
+                        "starts one process per CUDA_VISIBLE_DEVICES).  0 = whatever the launcher says (WORLD_SIZE; 1 when run bare).  N > 1 from "
+                        "a bare `python gen_3dphoto_dynamic.py` starts the N ranks itself (torch.distributed.run, RCCL over xGMI); under torchrun it "
+                        "must equal the launcher's rank count")
+    p.add_argument("--writers", type=int, default=0,
+                   help="writer threads PER RANK (hole fill, PNG encode and file I/O overlap the GPU); 0 = cores / (4 x ranks on this node), "
+                        "between 2 and 32 - the ranks of a node share its host cores")
     p.add_argument("--lanes", type=int, default=1,
                    help="images in flight on this GPU, each with its own streams, plane-stack buffer and network graph (same files for any "
                         "value).  Measured on MI355X: 1 lane 359 pairs/s, 2 lanes 267, 3 lanes 298 - the kernels are sized to fill the GPU on "
@@ -102,12 +110,39 @@ def outputs_exist(out, name, repeat):
     return True
 
 
+def default_writers(local_world):
+    """cores / (4 x ranks on this node), clamped to 2..32: every rank of a node draws on the same host cores"""
+    return max(2, min(32, (os.cpu_count() or 8) // (4 * max(1, local_world))))
+
+
+def self_launch(opt, argv):
+    """--gpus N > 1 without a launcher: start one process per GPU under torch.distributed.run and pass the exit status through."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < opt.gpus and "MPIFLOW_FORCE_DEVICE" not in os.environ:
+        raise SystemExit("gen_3dphoto_dynamic: --gpus %d but only %d GPU(s) are visible on this box" % (opt.gpus, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(opt.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    raise SystemExit(subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode)
+
+
 def main(argv=None):
     opt = parse(argv)
-    print(opt)
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(opt, argv)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if opt.gpus and opt.gpus != world:
+        raise SystemExit("gen_3dphoto_dynamic: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (opt.gpus, world))
+    if opt.writers <= 0:
+        opt.writers = default_writers(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    if rank == 0:
+        print(opt)
     # test hooks (multi-process path on a 1-GPU box): MPIFLOW_DIST_BACKEND=gloo, MPIFLOW_FORCE_DEVICE=0
     backend = os.environ.get("MPIFLOW_DIST_BACKEND", "nccl")
     forced = "MPIFLOW_FORCE_DEVICE" in os.environ
@@ -306,7 +341,11 @@ def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, m
             rgb8 = item["rgb_u8"].to(dev, non_blocking=True)
             dsp8 = item["disp_u8"].to(dev, non_blocking=True)
             ids = item["ids_u8"].to(dev, non_blocking=True)
-            pre = ops.prepare_inputs(rgb_u8=rgb8, disp_u8=dsp8, size=(H, W), out=lane.inputs)         # :82-89 in one launch
+            if rgb8.shape[:2] == dsp8.shape[:2]:
+                pre = ops.prepare_inputs(rgb_u8=rgb8, disp_u8=dsp8, size=(H, W), out=lane.inputs)     # :82-89 in one launch
+            else:                                                          # files of different sizes: each resized on its own, as :86-89 does
+                pre = dict(image=ops.prepare_inputs(rgb_u8=rgb8, size=(H, W), out=lane.inputs)["image"],
+                           disp=ops.prepare_inputs(disp_u8=dsp8, size=(H, W), out=lane.inputs)["disp"])
             image, disp = pre["image"][None], pre["disp"][None, None]
         cum_mask = None
         with lap("MPI producer + blend"):

@@ -102,9 +102,13 @@ MPF_DEV float mpf_div_by_const(float n, float d, float y /* = RN(1/d) */)
 // rate of an fma on gfx950.)  tools/sqrt_exhaustive.hip compares both with the double-precision square root rounded to float on
 // EVERY float: identical and correctly rounded on all 2^23 values of every binade from 2^-102 up; below that the residual
 // underflows in both (the guarded library sqrt pre-scales there) - the kernels take square roots of squared plane distances, 1e-4 .. 1e7.
+// x == 0 (two adjacent planes with EQUAL disparity - a user-supplied stack, or fp16-quantised plane disparities): v_rsq(0) is +inf
+// and 0 * inf would turn the pixel into NaN where the reference gets dist = 0, T = exp(-0) = 1.  Clamping r to FLT_MAX (one
+// v_min_f32; the identity for every x > 0, so the exhaustive check above is unaffected) makes every later product an exact 0:
+// g = 0, e = 0.5, h finite, d = 0 -> returns +0, the correctly rounded root.
 MPF_DEV float mpf_sqrt_nr(float x)
 {
-    const float r = __builtin_amdgcn_rsqf(x);
+    const float r = fminf(__builtin_amdgcn_rsqf(x), 3.402823466e+38f);
     float g = x * r;
     float h = 0.5f * r;
     const float e = fmaf(-h, g, 0.5f);

@@ -249,7 +249,7 @@ class InputPrefetcher:
     - the uint8 arrays exactly as the reference's loaders see them before their `/255` (image: PIL RGB, utils/utils.py:35-39;
     disparity: cv2.imread(path, 0), :42-43; mask: PIL "L", gen_3dphoto_dynamic_v2.py:83) - as torch tensors in page-locked
     memory (pin=True) ready for an asynchronous upload; the float conversion and the resize happen on the GPU
-    (mpf_prepare_inputs).  A file that cannot be decoded does not raise here: its item carries `error`, and the driver skips
+    (mpf_prepare_inputs).  The three arrays of an image need NOT share one (h, w): each is resized on its own.  A file that cannot be decoded does not raise here: its item carries `error`, and the driver skips
     that image and carries on."""
 
     def __init__(self, names, img_dir, disp_dir, mask_dir, indices, depth=8, threads=4, pin=True):
@@ -275,8 +275,8 @@ class InputPrefetcher:
             ids = np.array(Image.open(os.path.join(mask_dir, n)).convert("L"))
             rgb = np.array(Image.open(os.path.join(img_dir, n)).convert("RGB"))
             disp = read_disparity_u8(os.path.join(disp_dir, n))
-            if not (rgb.shape[:2] == disp.shape == ids.shape):
-                raise ValueError("image %s, disparity %s and mask %s differ in size" % (rgb.shape[:2], disp.shape, ids.shape))
+            # the three files may differ in size (e.g. a MiDaS/DPT disparity saved at network resolution): the reference resizes each
+            # of them on its own to (height, width) (gen_3dphoto_dynamic_v2.py:82-89, :104-105), and so does mpf_prepare_inputs
             out = dict(i=i, name=n, error=None, rgb_u8=rgb, disp_u8=disp, ids_u8=ids)
             if self._pin:
                 import torch

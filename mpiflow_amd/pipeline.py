@@ -255,21 +255,47 @@ def device_identity(local_index):
     return "%s|%s|%d" % (socket.gethostname(), env, int(local_index))
 
 
-_identity_round = 0
+def device_description(local_index):
+    """Human-readable record of the GPU a rank drives (bench.py / the CLI put one per rank into their reports): name, PCI address,
+    CU count.  Information only - the one-process-per-GPU check keys on device_identity()."""
+    try:
+        p = torch.cuda.get_device_properties(int(local_index))
+        pci = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+        return "cuda:%d %s pci %s %d CUs" % (int(local_index), p.name, pci, p.multi_processor_count)
+    except Exception as e:                                   # no GPU (CPU CI): still a record
+        return "cuda:%d (%s)" % (int(local_index), type(e).__name__)
+
+
+_side_group = None
+
+
+def host_side_group(group=None):
+    """A gloo (CPU, TCP) process group over the same ranks, for the small host-side exchanges that must not touch RCCL: under the
+    "nccl" backend a collective between two ranks that share one GPU stalls or aborts deep inside RCCL, which is exactly the
+    misconfiguration assert_distinct_devices() exists to report.  Public API only (dist.new_group); created once, collectively."""
+    import torch.distributed as dist
+    global _side_group
+    if dist.get_backend(group) == "gloo":
+        return group
+    if _side_group is None:
+        _side_group = dist.new_group(backend="gloo")
+    return _side_group
+
+
+def exchange_device_records(local_index, group=None):
+    """-> ([identity of rank 0..world-1], [description of rank 0..world-1]) on every rank; one all_gather_object over gloo."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    box = [None] * world
+    dist.all_gather_object(box, (device_identity(local_index), device_description(local_index)), group=host_side_group(group))
+    return [b[0] for b in box], [b[1] for b in box]
 
 
 def assert_distinct_devices(local_index, group=None):
-    """One process per GPU: every rank publishes the identity of its device through the process group's
-    key-value store (no collective, so it also works before the first RCCL communicator exists) and fails fast when two
-    ranks share one - RCCL would otherwise stall or abort deep inside its first all-reduce."""
-    import torch.distributed as dist
-    global _identity_round
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    store = dist.distributed_c10d._get_default_store()
-    _identity_round += 1                                                         # fresh keys per call: never read a previous call's entry
-    key = "mpiflow_dev_%d_%%d" % _identity_round
-    store.set(key % rank, device_identity(local_index))
-    ids = [store.get(key % r).decode() for r in range(world)]                   # get() blocks until the key exists
+    """One process per GPU: every rank publishes the identity of its device over the gloo side group (no RCCL
+    communicator is needed, so it also works before - and instead of - the first RCCL collective) and fails fast when two ranks
+    share one; RCCL would otherwise stall or abort deep inside its first all-reduce.  Returns the identities."""
+    ids, _ = exchange_device_records(local_index, group)
     dup = sorted({i for i in ids if ids.count(i) > 1})
     if dup:
         raise RuntimeError("ranks share a GPU: %s (rank -> device: %s); launch one process per GPU" % (dup, dict(enumerate(ids))))

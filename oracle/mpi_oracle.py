@@ -398,8 +398,18 @@ def moving_object(disp_HW, rgb_HW3_u8, K33, inv_K33, inst_HW, T_obj_44):
 INPAINT_NS, INPAINT_TELEA = 0, 1
 
 
-def inpaint(img_u8, mask_u8, radius, method):
-    """cv2.inpaint(img, mask, radius, method) for u8 [H,W,3] / [H,W,1] / [H,W] images (utils/utils.py:284-286, moving_obj.py:162)"""
+def inpaint(img_u8, mask_u8, radius, method, reading=0):
+    """cv2.inpaint(img, mask, radius, method) for u8 [H,W,3] / [H,W,1] / [H,W] images (utils/utils.py:284-286, moving_obj.py:162).
+    reading: 0 = OpenCV's unqualified sqrt / fabs on floats as the float overloads (default), 1 = as the double functions - the one
+    open question of this restatement, see oracle_inpaint.c and tests/golden/inpaint_reading_exhibit.npz"""
+    lib().orc_inpaint_set_reading(int(reading))
+    try:
+        return _inpaint(img_u8, mask_u8, radius, method)
+    finally:
+        lib().orc_inpaint_set_reading(0)
+
+
+def _inpaint(img_u8, mask_u8, radius, method):
     img = _c(img_u8, np.uint8)
     H, W = img.shape[:2]
     C = 1 if img.ndim == 2 else img.shape[2]

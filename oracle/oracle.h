@@ -111,6 +111,9 @@ void orc_resize_bilinear_ac(const float *src, int C, int h, int w, int H, int W,
 /* img u8 [rows,cols,C] (C = 1 or 3), mask u8 [rows,cols] (non-zero = fill), method 0 = INPAINT_NS, 1 = INPAINT_TELEA
  * (reference: utils/utils.py:284-286, moving_obj.py:162).  Returns 0, -1 on allocation failure. */
 int orc_inpaint(const uint8_t *img, const uint8_t *mask, int rows, int cols, int C, double radius, int method, uint8_t *out);
+/* 0 (default) = OpenCV's unqualified sqrt / fabs on float arguments taken as the float overloads, 1 = as the double functions
+ * (see oracle_inpaint.c); an open question until the real cv2 has been run on tests/golden/inpaint_reading_exhibit.npz */
+void orc_inpaint_set_reading(int reading);
 /* cv2.dilate(img, ones(3,3)) on one u8 channel (moving_obj.py:144-145) */
 void orc_dilate3x3(const uint8_t *img, int rows, int cols, uint8_t *out);
 

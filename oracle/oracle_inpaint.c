@@ -37,6 +37,16 @@
 #include <string.h>
 #include "oracle.h"
 
+/* Which overloads OpenCV's unqualified sqrt() / fabs() calls on FLOAT arguments resolved to when the wheel was compiled decides
+ * bytes at three sites (marked READING below), and cannot be settled without OpenCV at hand:
+ *   reading 0 (default, the precision note above): the float overloads  -> sqrtf / fabsf, the surrounding sums stay float;
+ *   reading 1: ::sqrt(double) / ::fabs(double) (what a translation unit sees that only has <cmath>, not <math.h>) -> the argument
+ *              is promoted, and so is every operation the result feeds until the explicit (float) cast.
+ * tests/golden/inpaint_reading_exhibit.npz holds inputs on which the two readings give different bytes; one run of the real
+ * cv2.inpaint on them (tests/golden/make_cv2_golden.py, tests/test_inpaint.py) decides. */
+static int g_reading = 0;
+void orc_inpaint_set_reading(int r) { g_reading = r ? 1 : 0; }
+
 #define KNOWN 0
 #define BAND 1
 #define INSIDE 2
@@ -221,7 +231,8 @@ static void telea_pixel(int i, int j, const uint8_t *f, const float *t, uint8_t 
                 if (F(k, l) == INSIDE || (l - j) * (l - j) + (k - i) * (k - i) > range * range) continue;
                 const float ry = (float)(i - k), rx = (float)(j - l);
                 const float dst = (float)(1. / (vlen2(rx, ry) * sqrt((double)vlen2(rx, ry))));
-                const float lev = (float)(1. / (1 + fabsf(TT(k, l) - TT(i, j))));     /* 1 + |dt| is a FLOAT sum (see the precision note) */
+                const float lev = g_reading ? (float)(1. / (1 + fabs((double)(TT(k, l) - TT(i, j)))))      /* READING: 1 + |dt| summed in double */
+                                            : (float)(1. / (1 + fabsf(TT(k, l) - TT(i, j))));              /*          ... or as a FLOAT sum */
                 float dir = vdot(rx, ry, gTx, gTy);
                 if (fabsf(dir) <= 0.01) dir = 0.000001f;
                 const float w = fabsf(dst * lev * dir);
@@ -246,7 +257,8 @@ static void telea_pixel(int i, int j, const uint8_t *f, const float *t, uint8_t 
                 s += w;
             }
         }
-        const float sat = (float)((Ia / s + (Jx + Jy) / (sqrtf(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f));
+        const float sat = g_reading ? (float)((Ia / s + (Jx + Jy) / (sqrt((double)(Jx * Jx + Jy * Jy)) + 1.0e-20f) + 0.5f))   /* READING */
+                                    : (float)((Ia / s + (Jx + Jy) / (sqrtf(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f));
         PIX(i - 1, j - 1, color) = sat_u8_f(sat);
     }
 }
@@ -285,6 +297,7 @@ static void ns_pixel(int i, int j, const uint8_t *f, uint8_t *out, int rows, int
                 gIx = -gIx;
                 float dir = vdot(rx, ry, gIx, gIy);
                 if (fabsf(dir) <= 0.01) dir = 0.000001f;
+                else if (g_reading) dir = (float)fabs(vdot(rx, ry, gIx, gIy) / sqrt((double)(vlen2(rx, ry) * vlen2(gIx, gIy))));   /* READING */
                 else dir = fabsf(vdot(rx, ry, gIx, gIy) / sqrtf(vlen2(rx, ry) * vlen2(gIx, gIy)));
                 const float w = dst * dir;
                 Ia += (float)w * (float)(PIX(km, lm, color));

@@ -49,6 +49,36 @@ def test_two_rank_path_over_gloo():
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6     # all ranks' pairs / max time
 
 
+def test_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's command form): bench.py starts the two ranks itself, and the
+    line reports what the process group saw - world size, backend, one device record per rank.  (gloo + one shared device here; on an
+    N-GPU node the same path runs RCCL with LOCAL_RANK = device.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo"
+    assert len(d["config"]["ranks"]) == 2 and all(x.startswith("cuda:0") for x in d["config"]["ranks"])
+    assert d["config"]["launcher"].startswith("self")
+    assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
+
+
+def test_gpus_flag_fails_loudly_without_enough_devices():
+    """No test hook: --gpus beyond the visible device count must exit non-zero with a message, not measure fewer GPUs silently."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MPIFLOW_FORCE_DEVICE", "MPIFLOW_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)] + SMALL, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "only %d GPU(s) are visible" % n in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_batch_mode_two_ranks_over_gloo():
     """--mode batch (BASELINE configs[3], strong scaling): a fixed batch sharded i % world == rank; value = batch pairs / max time."""
     if not torch.cuda.is_available():

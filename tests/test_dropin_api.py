@@ -309,6 +309,37 @@ def test_cli_skips_bad_images_without_disturbing_the_others(dev, tmp_path):
             assert open(tmp_path / "o_full" / sub / f, "rb").read() == open(tmp_path / "o_two" / sub / f, "rb").read(), f
 
 
+def test_cli_gpus_flag_starts_the_ranks_and_inputs_of_mixed_sizes_render(dev, tmp_path):
+    """(1) `gen_3dphoto_dynamic.py --gpus 2` without a launcher starts its two ranks itself (gloo + one device here) and writes the files
+    of a one-rank run.  (2) A disparity map saved at another resolution than its image is resized on its own, as the reference does
+    (gen_3dphoto_dynamic_v2.py:86-89): the image renders instead of landing in skipped.txt, and the result is that of handing
+    mpf_prepare_inputs the arrays one by one."""
+    import os
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--width", "64", "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "none", "--mpi-from", "disparity"]
+    base = tmp_path / "d"
+    _toy_dataset(base, ["a", "b", "c"])
+    yy, xx = np.mgrid[0:24, 0:32]
+    Image.fromarray((255 * (0.2 + 0.6 * xx / 32)).astype(np.uint8)).save(base / "disps" / "b.png")        # b: disparity at 24 x 32, image 40 x 56
+    r = _run_cli(root, ["--base", str(base), "--out", str(tmp_path / "one")] + common)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(tmp_path / "one" / "skipped.txt").read() == "" and "pairs 6 " in r.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0")
+    r = _run_cli(root, ["--base", str(base), "--out", str(tmp_path / "two"), "--gpus", "2"] + common, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "pairs 6 " in r.stdout and "(2 ranks)" in r.stdout
+    for sub in ("flows", "dst_images", "src_images"):
+        files = sorted(os.listdir(tmp_path / "one" / sub))
+        assert len(files) == 6 and files == sorted(os.listdir(tmp_path / "two" / sub))
+        for f in files:
+            assert open(tmp_path / "one" / sub / f, "rb").read() == open(tmp_path / "two" / sub / f, "rb").read(), f
+    # a launcher whose rank count disagrees with --gpus is an error
+    r = _run_cli(root, ["--base", str(base), "--out", str(tmp_path / "x"), "--gpus", "3"] + common, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "must agree" in r.stderr
+
+
 def test_cli_resume_and_defaults(dev, tmp_path):
     """--resume re-renders only what is missing and reproduces the same bytes; the default producer is the network, and a missing
     checkpoint is an error, not a silent switch to another data generator."""

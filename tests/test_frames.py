@@ -59,6 +59,21 @@ def test_input_prefetcher_yields_what_the_reference_loaders_decode(tmp_path):
         assert np.array_equal(U.disparity_to_tensor(str(dirs["disps"] / n))[0, 0].numpy(), (g["disp_u8"] / 255).astype(np.float32))
 
 
+def test_input_prefetcher_accepts_files_of_different_sizes(tmp_path):
+    """The reference resizes image, disparity and mask INDEPENDENTLY to (height, width) (gen_3dphoto_dynamic_v2.py:82-89, :104-105), so
+    a disparity saved at another resolution (MiDaS / DPT network size) is valid input - not an error, not a skipped image."""
+    from PIL import Image
+    from mpiflow_amd import io_formats
+    for d in ("images", "disps", "masks"):
+        (tmp_path / d).mkdir()
+    Image.fromarray(_rgb(20, 30, 1)).save(tmp_path / "images" / "x.png")
+    Image.fromarray(_rgb(12, 16, 2)[..., 0]).save(tmp_path / "disps" / "x.png")
+    Image.fromarray((_rgb(24, 36, 3)[..., 0] // 100).astype(np.uint8)).save(tmp_path / "masks" / "x.png")
+    (g,) = list(io_formats.InputPrefetcher(["x.png"], str(tmp_path / "images"), str(tmp_path / "disps"), str(tmp_path / "masks"), [0], pin=False))
+    assert g["error"] is None
+    assert g["rgb_u8"].shape == (20, 30, 3) and g["disp_u8"].shape == (12, 16) and g["ids_u8"].shape == (24, 36)
+
+
 def test_input_prefetcher_reports_errors_per_image(tmp_path):
     from PIL import Image
     from mpiflow_amd import io_formats
@@ -73,9 +88,11 @@ def test_input_prefetcher_reports_errors_per_image(tmp_path):
     assert io_formats.mask_max_of_file(str(tmp_path / "masks" / "bad.png")) == -1
 
 
-def test_disparity_decode_follows_cv2_imread_grayscale(tmp_path):
+@pytest.mark.parametrize("job", ["cpu_job", pytest.param("gpu_box_job", marks=pytest.mark.gpu)])
+def test_disparity_decode_follows_cv2_imread_grayscale(tmp_path, job):
     """cv2.imread(path, 0) (utils/utils.py:43): 16-bit grey -> high byte (PIL's convert("L") would saturate), colour PNG -> libpng's
-    fixed-point grey, 8-bit grey -> stored bytes.  Compared with the real cv2 when it is installed."""
+    fixed-point grey, 8-bit grey -> stored bytes.  Compared with the real cv2 when it is installed - in the CPU job and again on the GPU
+    box, a second machine that may carry OpenCV (needs no GPU)."""
     from PIL import Image
     from mpiflow_amd import io_formats
     ramp = (np.arange(300 * 200, dtype=np.uint32).reshape(200, 300) * 65535 // (300 * 200 - 1)).astype(np.uint16)

@@ -425,6 +425,43 @@ def test_short_stacks_and_degenerate_shapes(dev, kernel_exp, S, H, W):
     assert bits_equal(N(out["view_dyn"]["objmask"]), ref["view_dyn"]["objmask"]) == 0
 
 
+@pytest.mark.parametrize("S,H,W,dups", [(8, 24, 40, (2,)), (9, 17, 33, (0, 5, 7)), (2, 8, 64, (0,))])
+def test_equal_adjacent_plane_disparities_give_dist_zero_not_nan(dev, kernel_exp, S, H, W, dups):
+    """Two adjacent planes with the SAME disparity (a user-supplied --mpi-from stack, fp16-quantised disparities): the plane distance is
+    exactly 0, the reference gets T = exp(-0) = 1 and a finite frame (mpi_rendering.py:68-79).  The rsq-based square root must return
+    0 there, not 0 * inf = NaN - in Stage A+C, in both Stage B kernels and in the LDS-staged variant."""
+    from mpiflow_amd import _lib, ops, pipeline
+    o = kernel_exp
+    inp = _inputs(S, H, W, seed=S * 13 + W)
+    disp = inp["disparity"].copy()
+    for s in dups:
+        disp[s + 1] = disp[s]
+    G_cam, G_dyn = _poses(o, S + 3 * H)
+    ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], disp, inp["K"], G_cam, G_dyn)
+    assert np.isfinite(ref["flow_mix"]).all() and np.isfinite(ref["view_cam"]["rgb"]).all()
+    for variant in (1, 20):
+        _lib.check(_lib.load().mpf_tune(b"stage_b", variant))
+        try:
+            out = pipeline.render_pair(T(inp["image"], dev), T(inp["obj_mask"], dev), T(inp["mpi"], dev), disp, inp["K"], G_cam, G_dyn)
+            for k in ("flow_mix", "frame_mix", "fill_mask"):
+                assert bits_equal(N(out[k]), ref[k]) == 0, (k, variant)
+            for v in ("view_cam", "view_dyn"):
+                assert bits_equal(N(out[v]["rgb"]), ref[v]["rgb"]) == 0 and bits_equal(N(out[v]["objmask"]), ref[v]["objmask"]) == 0, (v, variant)
+        finally:
+            _lib.check(_lib.load().mpf_tune(b"stage_b", 1))
+    # the reference-signature (planar, v1 kernel) path and the generic volume renderer use the library sqrt: same answer
+    d = o.plane_depths(disp)
+    k_inv = o.k_inverse(inp["K"])
+    Hts, Hst = o.homographies(G_cam, k_inv, inp["K"], d)
+    rb = o.src_blend_flow(inp["mpi"], inp["image"], k_inv, d, Hts[None])
+    gb = ops.src_blend_flow(T(inp["mpi"], dev), T(inp["image"], dev), k_inv, d, Hts[None], want_planar=True)
+    assert bits_equal(N(gb["rgba"]), rb["rgba"]) == 0 and bits_equal(N(gb["flows"]), rb["flows"]) == 0
+    want = o.warp_composite(rb["rgba"], None, Hst, k_inv, G_cam, d)
+    planar = torch.cat([gb["rgb_planar"], T(inp["mpi"][:, 3:], dev)], dim=1).contiguous()
+    have = ops.warp_composite(planar, None, Hst, k_inv, G_cam, d, interleaved=False)
+    assert bits_equal(N(have["rgb"]), want["rgb"]) == 0 and bits_equal(N(have["depth"]), want["depth"]) == 0
+
+
 def test_general_intrinsics_take_the_dense_k_inverse_path(dev, kernel_exp):
     """A skewed K (K[0,1] != 0) disables the pinhole shortcut in Stage B: the dense 3x3 chain must still match the oracle."""
     from mpiflow_amd import ops

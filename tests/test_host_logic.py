@@ -268,3 +268,17 @@ def test_reference_named_entry_points_share_the_generator_cli():
     assert g.parse(["--base", "b", "--out", "o"]).poses == "v2"
     src = open(os.path.join(root, "gen_3dphoto_dynamic_coco.py")).read()
     assert '"--poses", "coco"' in src
+
+
+def test_bench_gpus_flag_is_never_silently_ignored():
+    """bench.py --gpus N: N > 1 without a launcher spawns the ranks itself and refuses when the box has fewer devices (here: none);
+    under a launcher, a WORLD_SIZE that disagrees with --gpus is an error, not a smaller measurement with n_gpus quietly adjusted."""
+    bench = os.path.join(ROOT, "bench.py")
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MPIFLOW_FORCE_DEVICE", "MPIFLOW_DIST_BACKEND")}
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=clean)
+        assert r.returncode != 0 and "only 0 GPU(s) are visible" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300,
+                       env=dict(clean, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "they must agree" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -135,6 +135,11 @@ def test_dilate3x3_vs_scipy(oracle):
 
 
 # ---- the pin: real OpenCV, whenever it is there ---------------------------------------------------------------------------
+# These comparisons need no GPU, but the driver's GPU box is a second machine that may carry OpenCV: every one of them runs in BOTH
+# jobs (`-m "not gpu"` here, `-m gpu` there), and skips with the reason wherever cv2 is absent.
+
+BOTH_JOBS = pytest.mark.parametrize("job", ["cpu_job", pytest.param("gpu_box_job", marks=pytest.mark.gpu)])
+
 
 def _cv2():
     try:
@@ -144,8 +149,16 @@ def _cv2():
         pytest.skip("OpenCV (cv2) is not installed here: parity of rows A13 / N2 with cv2 itself stays unpinned")
 
 
+def _golden(name):
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+@BOTH_JOBS
 @pytest.mark.parametrize("method", [0, 1])
-def test_against_real_cv2_inpaint(prod, oracle, method):
+def test_against_real_cv2_inpaint(prod, oracle, method, job):
     cv2 = _cv2()
     flag = cv2.INPAINT_TELEA if method == 1 else cv2.INPAINT_NS
     for img, mask in _cases():
@@ -156,8 +169,74 @@ def test_against_real_cv2_inpaint(prod, oracle, method):
         assert bits_equal(prod.inpaint_host(img, mask, 3, method), want) == 0
 
 
-def test_against_real_cv2_dilate(oracle):
+@BOTH_JOBS
+def test_against_real_cv2_dilate(oracle, job):
     cv2 = _cv2()
     rs = np.random.RandomState(1)
     m = (rs.rand(37, 53) < 0.1).astype(np.uint8)
     assert bits_equal(oracle.dilate3x3(m), cv2.dilate(m, np.ones((3, 3)))) == 0
+
+
+def test_reading_exhibit_discriminates(oracle):
+    """oracle_inpaint.c leaves ONE question open: whether OpenCV's unqualified sqrt() / fabs() on float arguments compiled to the float
+    overloads (reading 0, what both restatements implement) or to the double functions (reading 1).  The committed exhibit holds one NS
+    and one Telea input on which the two readings give different bytes, so a single cv2 run on them decides; here: the exhibit is
+    reproducible from its recipe, and still discriminates."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_cv2_golden as mk
+    ex = _golden("inpaint_reading_exhibit")
+    for name, img, mask, method in mk.exhibit_inputs():
+        assert bits_equal(img, ex[name + "_img"]) == 0 and bits_equal(mask, ex[name + "_mask"]) == 0
+        a, b = oracle.inpaint(img, mask, 3, method, reading=0), oracle.inpaint(img, mask, 3, method, reading=1)
+        assert bits_equal(a, ex[name + "_float_reading"]) == 0 and bits_equal(b, ex[name + "_double_reading"]) == 0
+        assert int((a != b).sum()) == int(ex[name + "_bytes_that_differ"]) > 0
+
+
+@BOTH_JOBS
+def test_reading_exhibit_decided_by_real_cv2(prod, oracle, job):
+    """The one cv2 run that settles the float-vs-double reading: on the exhibit inputs cv2 must equal reading 0 - the one the product
+    implements - and differ from reading 1.  If this fails with "cv2 follows the DOUBLE reading", flip the three READING sites."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    cv2 = _cv2()
+    sys.path.insert(0, GOLDEN)
+    import make_cv2_golden as mk
+    for name, img, mask, method in mk.exhibit_inputs():
+        want = cv2.inpaint(img, mask, 3, cv2.INPAINT_TELEA if method == 1 else cv2.INPAINT_NS)
+        f, d = oracle.inpaint(img, mask, 3, method, reading=0), oracle.inpaint(img, mask, 3, method, reading=1)
+        assert not (bits_equal(d, want) == 0 and bits_equal(f, want) != 0), "cv2 %s follows the DOUBLE reading on exhibit %s" % (cv2.__version__, name)
+        assert bits_equal(f, want) == 0, "cv2 %s matches neither reading on exhibit %s (%d / %d bytes off)" % (cv2.__version__, name, bits_equal(f, want), bits_equal(d, want))
+        assert bits_equal(prod.inpaint_host(img, mask, 3, method), want) == 0
+
+
+@BOTH_JOBS
+def test_against_recorded_cv2_golden(prod, oracle, job):
+    """tests/golden/cv2_golden.npz = the real cv2's outputs on the committed fixtures (the exact frame_mix / fill_mask / warped / 1 - H /
+    M arrays the reference handed to OpenCV), written by tests/golden/make_cv2_golden.py on any machine that has OpenCV.  Present:
+    both restatements must reproduce it byte for byte - the pin of rows A13 / N2.  Absent: skipped, rows stay unpinned."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "cv2_golden.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/cv2_golden.npz has not been recorded yet (needs OpenCV once: tests/golden/make_cv2_golden.py)")
+    sys.path.insert(0, GOLDEN)
+    import make_cv2_golden as mk
+    g = _golden("cv2_golden")
+    for name in mk.PAIR_FIXTURES:
+        fx = _golden(name)
+        for tag, method in (("_ns", 0), ("_telea", 1)):
+            assert bits_equal(oracle.inpaint(fx["frame_mix"], fx["fill_mask"], 3, method), g[name + tag]) == 0, (name, tag)
+            assert bits_equal(prod.inpaint_host(fx["frame_mix"], fx["fill_mask"], 3, method), g[name + tag]) == 0, (name, tag)
+    fw = _golden("fwarp_small")
+    frame = np.ascontiguousarray(fw["warped"][..., :3])
+    for tag, method in (("_ns", 0), ("_telea", 1)):
+        assert bits_equal(oracle.inpaint(frame, fw["inpaint_mask"], 3, method), g["fwarp_small" + tag]) == 0
+        assert bits_equal(prod.inpaint_host(frame, fw["inpaint_mask"], 3, method), g["fwarp_small" + tag]) == 0
+    assert bits_equal(oracle.dilate3x3(np.ascontiguousarray(fw["warped"][..., 4])), g["fwarp_small_dilate"]) == 0
+    for name, img, mask, method in mk.exhibit_inputs():
+        assert bits_equal(oracle.inpaint(img, mask, 3, method), g["exhibit_" + name]) == 0, "the recorded cv2 does not follow reading 0 on exhibit " + name

@@ -1,32 +1,43 @@
 #!/usr/bin/env python3
 """bench.py - image-pairs/sec of the MPI render + flow hot path on MI355X, with roofline and CPU baseline.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: bench.py starts the N ranks itself, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Workload of `value` (BASELINE.json configs[2], the reference's real unit of work - its only entry point always renders
 the DYNAMIC pair, utils/utils.py:159-288): 64 planes, 640 x 960, object pose + background pose.  One *step* = every rank
-renders `--images` distinct image pairs whose plane stacks are already resident in HBM (synthetic data of the shape
-AdaMPI emits; the reference sampler's random poses, fixed per image).  Per pair, three launches:
-    mpf_src_blend_flow         Stage A+C: blend the source image into the stack, volume-rendered flow for BOTH poses (P = 2)
-                               (+ fused: source frame as uint8 BGR, bilinear tap quads of obj_mask and 1 - obj_mask)
-    mpf_warp_composite_views   Stage B, both views in one launch: 64-plane homography warp + front-to-back composite
-                               <- dominant / roofline kernel (2 units of 16*S*N algorithmic bytes per launch)
-    mpf_merge                  Stage D: thresholds, layer select, uint8 BGR frame, fill mask, merged flow
+renders `--pairs-per-step` image pairs, cycling through `--images` distinct plane stacks that are already resident in HBM
+(synthetic data of the shape AdaMPI emits; the reference sampler's random poses, fixed per image).  The pairs of a rank form a
+two-stage software pipeline (pipeline.OverlappedPairRenderer) - per pair ONE heterogeneous-grid launch and one merge:
+    mpf_warp_views_and_blend_next   Stage B of pair i (64-plane homography warp + front-to-back composite of BOTH views) and
+                                    Stage A+C of pair i+1 (blend the source image into the stack, volume-rendered flow for both
+                                    poses, source frame as uint8 BGR, bilinear tap quads of obj_mask and 1 - obj_mask), their
+                                    workgroups interleaved on every CU   <- dominant / roofline kernel: the whole pair's
+                                    60*S*N algorithmic bytes per launch
+    mpf_merge                       Stage D: thresholds, layer select, uint8 BGR frame, fill mask, merged flow
+The very first pair of the timed region pays a stand-alone Stage A+C launch and the very last one a stand-alone Stage B launch
+(the pipeline's prologue / epilogue), both inside the timed region: every timed pair is rendered completely.
+`--pipeline serial` is the round-2 structure (A+C, Stage B, merge one after the other); it is what the `sub` records use to time
+the two kernels on their own.
 `--mode batch` (strong scaling, BASELINE configs[3]): a FIXED batch of `--batch` images (default 512) is sharded over the ranks
 (i % world == rank, as the generator does) and rendered once per step; `value` = batch pairs / max-over-ranks time.
 Images are independent, so ranks share nothing; the only collective is the end-of-batch statistics all-reduce
-(RCCL over xGMI under torchrun), issued once after the K timed steps, inside the timed region.
+(RCCL over xGMI), issued once after the K timed steps, inside the timed region.
 
-`roofline`: Stage B's algorithmic bytes (16*S*N per view) over its mean launch duration, measured with HIP
-events recorded on the launch stream around every Stage B launch inside the timed region; peak 8.0 TB/s.  `roofline.traffic`
-is the PMC-measured HBM traffic of that kernel from profiles/roofline_traffic.json - reported only while the kernel source
-still has the digest the measurement was taken at (else null: a stale number is worse than none).
-`sub`: the other configs on rank 0 at N=1, outside the timed region: camera-only pair (configs[1]), c1 and c5 dynamic
-pairs, each with per-kernel roofline entries for Stage B and Stage A+C.
-`overlap`: the same dynamic pairs on two HIP streams (own renderers): throughput when Stage A+C of one pair overlaps Stage B of
-another - information beside `value`, which stays the single-stream figure so that the roofline entries are clean kernel times.
-`hbm_reference`: what a plain device copy / read-only reduction reaches on this box (SURVEY.md §8(d)).
+`roofline`: the dominant kernel's algorithmic bytes per launch (Stage B 16*S*N per view x 2 + Stage A+C
+16*S*N + 12*N read and 12*S*N + 8*N per pose written = the pair's 60*S*N) over its mean launch duration, measured with HIP events
+recorded on the launch stream around every such launch inside the timed region; peak 8.0 TB/s.  `roofline.traffic` is the
+PMC-measured HBM traffic of that kernel from profiles/roofline_traffic.json - reported only while the kernel source still has the
+digest the measurement was taken at (else null: a stale number is worse than none).
+`roofline_stage_b`, `roofline_stage_ac`: the two stages as kernels of their own (non-overlapped, from the serial c3 sub-record);
+Stage A+C on SURVEY 8(d)'s bytes, with the interleaved layout's real byte count beside it.
+`sub` (rank 0, N=1, outside the timed region): the serial c3 pair; c3 + the moving-object chain (depth->flow projection, forward warp,
+masks on disp = rand: SURVEY 8(d)'s full c3); the camera-only pair (configs[1]); c1 and c5 dynamic pairs.
+`overlap`: the same pipelined pairs as two pipelines on two HIP streams (each launch's ramp-down filled by the other stream) -
+information beside `value`, which stays the single-stream figure so that the kernel times are clean.
+`generator`: the whole data generator (gen_3dphoto_dynamic.py: PNG decode, AdaMPI network on the HIP engine, render, hole filling,
+PNG / .flo files) on a small synthetic KITTI-shaped set at 64 x 384 x 1280 - a subprocess, outside the timed region.
+`hbm_reference`: what a plain device copy / read-only reduction reaches on this box (SURVEY.md 8(d)).
 `cpu_baseline`: the CPU oracle (our plain-C restatement of the reference algorithm, OpenMP) timed on this host on a
 bounded sample of the same workload (dynamic pairs), rank 0, N=1 only.
 """
@@ -63,7 +74,12 @@ def parse():
     p.add_argument("--workload", choices=["c3", "c2"], default="c3", help="c3 = dynamic pair (value), c2 = camera-only pair")
     p.add_argument("--mode", choices=["resident", "batch"], default="resident",
                    help="resident: every rank renders --images pairs per step (weak scaling); batch: a fixed --batch images sharded over ranks (strong)")
-    p.add_argument("--images", type=int, default=8, help="resident image stacks (pairs per step) per GPU")
+    p.add_argument("--images", type=int, default=8, help="distinct resident image stacks per GPU")
+    p.add_argument("--pairs-per-step", type=int, default=104,
+                   help="pairs every rank renders per step, cycling through its resident stacks (104 x 20 steps > 1 s of timed work); 0 = --images")
+    p.add_argument("--pipeline", choices=["overlapped", "serial"], default="overlapped",
+                   help="overlapped: Stage B of pair i and Stage A+C of pair i+1 in one heterogeneous-grid launch; serial: one kernel after the other")
+    p.add_argument("--no-generator", action="store_true", help="skip the end-to-end generator record")
     p.add_argument("--batch", type=int, default=512, help="--mode batch: images of the whole job per step (BASELINE configs[3]: 512)")
     p.add_argument("--planes", type=int, default=64)
     p.add_argument("--height", type=int, default=640)
@@ -139,10 +155,20 @@ def make_image(S, H, W, dev, seed):
     return mpi, img
 
 
-class Workload:
-    """`B` resident images of one shape with fixed random poses; step() renders one pair per image."""
+def alg_bytes(S, N, views):
+    """SURVEY.md 8(d) algorithmic bytes (fp32 planar API layout): Stage B 16*S*N per view; Stage A+C reads 16*S*N + 12*N and writes
+    12*S*N + 8*N per pose.  The interleaved layout really moves 16*S*N on the write side (sigma is re-written): reported beside it."""
+    b = 16.0 * S * N * views
+    ac = 16.0 * S * N + 12.0 * N + 12.0 * S * N + 8.0 * N * views
+    ac_layout = 32.0 * S * N + 12.0 * N + 8.0 * N * views
+    return b, ac, ac_layout
 
-    def __init__(self, S, H, W, B, dev, dynamic, seed0=0, multi_view=True, pose_seed=114514):
+
+class Workload:
+    """`B` resident images of one shape with fixed random poses, rendered ONE KERNEL AFTER THE OTHER (the round-2 structure): per pair
+    Stage A+C, Stage B (both views in one launch), merge.  Used for the per-kernel roofline entries and the comparison records."""
+
+    def __init__(self, S, H, W, B, dev, dynamic, seed0=0, multi_view=True, pose_seed=114514, moving_object=False):
         self.S, self.H, self.W, self.B, self.dynamic = S, H, W, B, dynamic
         self.N = H * W
         K, disp = synth.intrinsics(H, W), synth.plane_disparities(S)
@@ -159,6 +185,7 @@ class Workload:
         self.mix = (torch.empty((H, W, 2), dtype=torch.float32, device=dev), torch.empty((H, W, 3), dtype=torch.uint8, device=dev),
                     torch.empty((H, W), dtype=torch.uint8, device=dev))
         self.ev_b, self.ev_ac = [], []
+        self.mo = MovingObjectChain(H, W, K, dev, seed0) if moving_object else None
 
     def pair(self, i, timed):
         r, (mpi, img), prep = self.r, self.images[i], self.preps[i]
@@ -183,21 +210,24 @@ class Workload:
         if self.dynamic:
             v = r.views
             ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], r.flows[0], r.flows[1], self.om, out=self.mix)
+        if self.mo is not None:
+            self.mo.run(r.src_u8, self.om)
 
     def step(self, timed, which=None):
         idx = range(self.B) if which is None else which
         for i in idx:
-            self.pair(i, timed)
+            self.pair(i % self.B, timed)
         return len(idx)
+
+    def finish(self):
+        return None
 
     def rooflines(self):
         """Per-kernel roofline entries from the HIP-event brackets collected by timed steps."""
         views = 2 if self.dynamic else 1
         t_b = float(np.mean([a.elapsed_time(b) for a, b in self.ev_b])) * 1e-3
         t_ac = float(np.mean([a.elapsed_time(b) for a, b in self.ev_ac])) * 1e-3
-        alg_b = 16.0 * self.S * self.N * views
-        # Stage A+C: read 16*S*N + 12*N, write 16*S*N (interleaved stack incl. sigma) + 8*N per pose (SURVEY §8(d), DESIGN §4)
-        alg_ac = 32.0 * self.S * self.N + 12.0 * self.N + 8.0 * self.N * views
+        alg_b, alg_ac, lay_ac = alg_bytes(self.S, self.N, views)
         launches_b = 1 if (views == 1 or self.r.multi_view) else views
         kb = "k_warp_composite_views (Stage B, %d views per launch)" % views if (views > 1 and self.r.multi_view) else "k_warp_composite_v2 (Stage B)"
         return dict(
@@ -206,17 +236,99 @@ class Workload:
                      "avg_launch_ms": t_b * 1e3 / launches_b, "launches_timed": len(self.ev_b) * launches_b, "views_per_pair": views},
             stage_ac={"bound": "hbm", "kernel": "k_src_blend_flow (Stage A+C, P=%d)" % views, "achieved": alg_ac / t_ac / 1e9,
                       "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_ac / t_ac / HBM_PEAK,
-                      "algorithmic_bytes_per_launch": alg_ac, "avg_launch_ms": t_ac * 1e3, "launches_timed": len(self.ev_ac)})
+                      "algorithmic_bytes_per_launch": alg_ac, "avg_launch_ms": t_ac * 1e3, "launches_timed": len(self.ev_ac),
+                      "layout_bytes_per_launch": lay_ac, "frac_on_layout_bytes": lay_ac / t_ac / HBM_PEAK,
+                      "note": "algorithmic bytes per SURVEY 8(d) (read 16SN + 12N, write 12SN + 8N per pose); the interleaved RGBA stack Stage B "
+                              "gathers from re-writes sigma, so the kernel really moves layout_bytes_per_launch"})
 
 
-def measured_traffic():
-    """PMC traffic of the Stage B kernel, valid only for the kernel source it was measured on."""
+class MovingObjectChain:
+    """SURVEY 8(d)'s c3 adds "forward-warp on disp = rs.rand(H, W)": the moving-object chain of moving_obj.py:29-150 on device-resident
+    inputs - fused depth->flow projection (two poses, instance select, truncate + clamp), order-preserving forward splat, masks."""
+
+    def __init__(self, H, W, K, dev, seed):
+        g = torch.Generator(device=dev).manual_seed(4242 + seed)
+        self.H, self.W = H, W
+        self.disp = torch.rand((H, W), generator=g, device=dev)
+        K3 = torch.from_numpy(np.asarray(K, dtype=np.float32)).reshape(3, 3)
+        self.inv_K = torch.inverse(K3.double()).float()
+        K4 = torch.zeros((1, 4, 4))
+        K4[0, -1, -1] = 1.0
+        K4[:, :3, :3] = K3
+        T1 = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.zeros(1, 3))                 # moving_obj.py:43-47
+        Ti = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.tensor([[0.07, -0.06, 0.08]]))  # :81-98 (angles are zeroed there)
+        self.P1, self.Pi = torch.matmul(K4, T1)[:, :3, :][0], torch.matmul(K4, Ti)[:, :3, :][0]
+
+    def run(self, src_u8_HW3, obj_mask):
+        from mpiflow_amd import ops as _ops
+        p1, z1, sx, sy, fl = _ops.moving_object_project(self.disp, self.inv_K, self.P1, self.Pi, obj_mask)
+        warped = _ops.forward_warp(src_u8_HW3.reshape(-1), sx, sy, z1, self.H, self.W)
+        return _ops.warp_masks(warped)
+
+
+class PipelinedWorkload:
+    """The same pairs as Workload(dynamic=True), rendered by pipeline.OverlappedPairRenderer: Stage B of pair i and Stage A+C of pair
+    i+1 in one heterogeneous-grid launch.  finish() flushes the pipeline (the last pair's stand-alone Stage B)."""
+    dynamic = True
+
+    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514):
+        self.S, self.H, self.W, self.B, self.N = S, H, W, B, H * W
+        K, disp = synth.intrinsics(H, W), synth.plane_disparities(S)
+        rng = random.Random(pose_seed)
+        self.r = pipeline.OverlappedPairRenderer(S, H, W, dev)
+        self.images, self.preps = [], []
+        for i in range(B):
+            self.images.append(make_image(S, H, W, dev, seed=seed0 + i))
+            G_dyn = host_math.generate_random_pose(0.15, rng=rng)                          # utils/utils.py:207
+            G_cam = host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng)  # :208
+            self.preps.append(self.r.prepare(K, disp, [G_cam, G_dyn]))
+        self.om = torch.from_numpy(synth.soft_box_mask(H, W)).to(dev)
+        self.mix = (torch.empty((H, W, 2), dtype=torch.float32, device=dev), torch.empty((H, W, 3), dtype=torch.uint8, device=dev),
+                    torch.empty((H, W), dtype=torch.uint8, device=dev))
+        self.ev = []
+        self.timed = False
+
+        def hook(launch):
+            if not self.timed:
+                return launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch()
+            e1.record()
+            self.ev.append((e0, e1))
+        self.r.on_fused = hook
+
+    def step(self, timed, which=None):
+        idx = range(self.B) if which is None else which
+        self.timed = timed
+        for i in idx:
+            mpi, img = self.images[i % self.B]
+            self.r.push(mpi, img, self.preps[i % self.B], self.om, out=self.mix)
+        return len(idx)
+
+    def finish(self):
+        self.r.flush()
+
+    def rooflines(self):
+        t = float(np.mean([a.elapsed_time(b) for a, b in self.ev])) * 1e-3
+        alg_b, alg_ac, lay_ac = alg_bytes(self.S, self.N, 2)
+        return dict(pair={"bound": "hbm", "kernel": "k_pair_overlap (Stage B of pair i, 2 views + Stage A+C of pair i+1, one heterogeneous grid)",
+                          "achieved": (alg_b + alg_ac) / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (alg_b + alg_ac) / t / HBM_PEAK,
+                          "algorithmic_bytes_per_launch": alg_b + alg_ac, "avg_launch_ms": t * 1e3, "launches_timed": len(self.ev), "views_per_pair": 2,
+                          "layout_bytes_per_launch": alg_b + lay_ac,
+                          "note": "algorithmic bytes = the whole dynamic pair per SURVEY 8(d): 2 x 16SN (Stage B) + 16SN + 12N read + 12SN + 16N written (Stage A+C)"})
+
+
+def measured_traffic(kind="pair"):
+    """PMC traffic of the dominant kernel ("pair": k_pair_overlap, "stage_b": k_warp_composite_views), valid only for the kernel
+    source it was measured on."""
     tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     try:
         rec = json.load(open(tp))
         src = b"".join(open(os.path.join(ROOT, "mpiflow_amd", "csrc", f), "rb").read() for f in ("mpf_render.hip", "mpf_math.h"))
         if rec.get("kernel_source_sha256") == hashlib.sha256(src).hexdigest():
-            return rec.get("stage_b_hbm_bytes_per_launch"), rec.get("source")
+            key = "pair_hbm_bytes_per_launch" if kind == "pair" else "stage_b_hbm_bytes_per_launch"
+            return rec.get(key), rec.get("source")
     except Exception:
         pass
     return None, None
@@ -267,14 +379,20 @@ def cpu_baseline(S, H, W, pairs):
                        (pairs, S, H, W, os.cpu_count(), dt))
 
 
-def sub_record(name, S, H, W, B, dev, dynamic, steps, multi_view=True):
-    w = Workload(S, H, W, B, dev, dynamic, seed0=500, multi_view=multi_view)
+def sub_record(name, S, H, W, B, dev, dynamic, steps, multi_view=True, pipelined=False, moving_object=False):
+    """One workload outside the timed region (rank 0, N=1): pairs/s plus per-kernel roofline entries from HIP-event brackets."""
+    if pipelined:
+        w = PipelinedWorkload(S, H, W, B, dev, seed0=500)
+    else:
+        w = Workload(S, H, W, B, dev, dynamic, seed0=500, multi_view=multi_view, moving_object=moving_object)
     w.step(False)
+    w.finish()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 0
     for _ in range(steps):
         n += w.step(True)
+    w.finish()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rec = dict(workload=name, pairs_per_s=n / dt, us_per_pair=dt / n * 1e6, pairs_timed=n)
@@ -285,21 +403,25 @@ def sub_record(name, S, H, W, B, dev, dynamic, steps, multi_view=True):
 
 
 def overlap_record(S, H, W, dev, n_streams=2, images=4, steps=8):
-    """The same dynamic pairs on `n_streams` HIP streams, each with its own renderer and images: the HBM-bound Stage A+C of one
-    pair runs beside the issue-bound Stage B of another.  Reported beside `value`, not as `value`: under overlap a kernel's own
-    duration includes the other stream's interference, so the per-kernel roofline entries are taken from the single-stream run."""
+    """The pipelined dynamic pairs as `n_streams` pipelines on as many HIP streams, each with its own renderer and images: while one
+    stream's heterogeneous-grid launch drains, the other's fills the freed slots.  Reported beside `value`, not as `value`: under
+    stream-level overlap a kernel's own duration includes the other stream's interference, so the roofline entries come from the
+    single-stream runs."""
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     wls = []
     for k, st in enumerate(streams):
         with torch.cuda.stream(st):
-            wls.append(Workload(S, H, W, images, dev, True, seed0=700 + 10 * k))
+            wls.append(PipelinedWorkload(S, H, W, images, dev, seed0=700 + 10 * k))
 
     def run(n):
         for _ in range(n):
             for i in range(images):
                 for wl, st in zip(wls, streams):
                     with torch.cuda.stream(st):
-                        wl.pair(i, False)
+                        wl.step(False, [i])
+        for wl, st in zip(wls, streams):
+            with torch.cuda.stream(st):
+                wl.finish()
     run(1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -309,8 +431,55 @@ def overlap_record(S, H, W, dev, n_streams=2, images=4, steps=8):
     n = steps * images * n_streams
     del wls
     torch.cuda.empty_cache()
-    return {"workload": "c3 dynamic pairs on %d streams (separate renderers; Stage A+C of one pair beside Stage B of another)" % n_streams,
+    return {"workload": "c3 dynamic pairs, pipelined (Stage B of pair i + Stage A+C of pair i+1 per launch), %d pipelines on %d HIP streams" % (n_streams, n_streams),
             "streams": n_streams, "pairs_per_s": n / dt, "us_per_pair": dt / n * 1e6, "pairs_timed": n}
+
+
+def generator_record(n_images=24, repeat=5, timeout=600):
+    """The data generator end to end (gen_3dphoto_dynamic.py, the reference's entry point gen_3dphoto_dynamic_v2.py:20-122): PNG decode,
+    input stage, AdaMPI network (random weights of the reference's architecture: no checkpoint offline) on the HIP engine, blend once per
+    image, `repeat` pairs per image, hole filling (cv2.inpaint's NS restated, on the writer threads), PNG + .flo files - on a synthetic
+    KITTI-shaped set (375 x 1242 PNGs -> 64 planes x 384 x 1280, the reference's defaults).  A subprocess, outside the timed region."""
+    import shutil
+    import subprocess
+    import tempfile
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix="mpf_gen_")
+    try:
+        base = os.path.join(tmp, "data")
+        for d in ("images", "disps", "masks"):
+            os.makedirs(os.path.join(base, d))
+        rs = np.random.RandomState(0)
+        yy, xx = np.mgrid[0:375, 0:1242]
+        for i in range(n_images):
+            img = (np.clip(0.5 + 0.25 * np.sin(xx / (17.0 + i)) + 0.25 * np.cos(yy / 23.0) + 0.05 * rs.randn(375, 1242), 0, 1) * 255).astype(np.uint8)
+            Image.fromarray(np.stack([img, np.roll(img, 7, 1), np.roll(img, 13, 0)], -1)).save(os.path.join(base, "images", "%04d.png" % i))
+            Image.fromarray((255 * (0.1 + 0.8 * yy / 375)).astype(np.uint8)).save(os.path.join(base, "disps", "%04d.png" % i))
+            m = np.zeros((375, 1242), np.uint8)
+            m[150:300, 300:600] = 1
+            m[200:330, 800:1000] = 2
+            Image.fromarray(m).save(os.path.join(base, "masks", "%04d.png" % i))
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        cmd = [sys.executable, os.path.join(ROOT, "gen_3dphoto_dynamic.py"), "--base", base, "--out", os.path.join(tmp, "out"), "--repeat", str(repeat),
+               "--mpi-from", "model", "--ckpt_path", "random:0", "--model-engine", "hip", "--inpaint", "builtin"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        steady = [l for l in r.stdout.splitlines() if l.startswith("steady state")]
+        summary = [l for l in r.stdout.splitlines() if l.startswith("pairs ")]
+        n_files = len(os.listdir(os.path.join(tmp, "out", "flows")))
+        rec = {"workload": "gen_3dphoto_dynamic.py end to end: %d synthetic 375x1242 images -> 64 planes x 384 x 1280, repeat %d, AdaMPI (random weights) on the HIP "
+                           "engine, NS hole filling on the writer threads, PNG + .flo written" % (n_images, repeat),
+               "pairs": n_images * repeat, "flo_files_written": n_files, "process_seconds": dt,
+               "pairs_per_s_whole_process": n_images * repeat / dt, "summary_line": summary[-1] if summary else None}
+        if steady:
+            rec["pairs_per_s_steady_state"] = float(steady[-1].split(":")[1].split("pairs/s")[0])
+            rec["steady_state_note"] = "the CLI's own figure: pairs after the first image / time after the first image (start-up = graph capture, first MIOpen calls, excluded)"
+        return rec
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -322,15 +491,19 @@ def main():
         _lib.check(_lib.load().mpf_tune(b"sbf_px", a.sbf_px))
     S, H, W = a.planes, a.height, a.width
     dynamic = a.workload == "c3"
+    pipelined = dynamic and a.pipeline == "overlapped" and not a.single_view_launches
     if a.mode == "batch":
         mine = pipeline.shard_indices(a.batch, rank, world)          # the generator's sharding: image i belongs to rank i % world
         # each rank keeps min(#mine, --images) distinct stacks resident and cycles through them for its share of the batch
         B = max(1, min(len(mine), a.images))
-        order = [j % B for j in range(len(mine))]
+        order = list(range(len(mine)))
     else:
         B = a.images
-        order = None
-    wl = Workload(S, H, W, B, dev, dynamic, seed0=rank * 1000, multi_view=not a.single_view_launches, pose_seed=114514 + rank)
+        order = list(range(a.pairs_per_step if a.pairs_per_step > 0 else B))
+    if pipelined:
+        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank)
+    else:
+        wl = Workload(S, H, W, B, dev, dynamic, seed0=rank * 1000, multi_view=not a.single_view_launches, pose_seed=114514 + rank)
     torch.cuda.synchronize()
 
     def barrier():
@@ -340,6 +513,7 @@ def main():
 
     for _ in range(a.warmup):
         wl.step(False, order)
+    wl.finish()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -347,6 +521,7 @@ def main():
     st = pipeline.empty_stats()
     for _ in range(a.steps):
         st["pairs"] += wl.step(True, order)
+    wl.finish()                                                      # pipeline epilogue: the last pair's Stage B + merge
     # end-of-batch statistics: the ONE collective of the path (SUM / MAX all-reduce of a 7-float vector, RCCL over xGMI)
     total_pairs = int(pipeline.reduce_stats(st)["pairs"])
     torch.cuda.synchronize()
@@ -364,20 +539,22 @@ def main():
 
     if rank == 0:
         roofs = wl.rooflines()
-        traffic, traffic_src = measured_traffic()
-        roof = dict(roofs["stage_b"])
+        traffic, traffic_src = measured_traffic("pair" if pipelined else "stage_b")
+        roof = dict(roofs["pair"] if pipelined else roofs["stage_b"])
         roof["traffic"] = traffic
         if traffic_src:
             roof["traffic_source"] = traffic_src
-        cfg_name = ("BASELINE configs[2]: %d planes, %dx%d, full dynamic pair (blend + 2 flows, 2 warped views in one launch, merge)" if dynamic
+        how = ("pipelined: per pair one heterogeneous-grid launch (Stage B of this pair, 2 views + Stage A+C of the next pair) + merge" if pipelined
+               else "one kernel after the other: blend + 2 flows, 2 warped views in one launch, merge")
+        cfg_name = ("BASELINE configs[2]: %d planes, %dx%d, full dynamic pair (" + how + ")" if dynamic
                     else "BASELINE configs[1]: %d planes, %dx%d, camera-only novel view (blend+flow, warp+composite, u8 frames)") % (S, H, W)
         out = {
             "metric": "image-pairs/sec (+flow) at 640x960x64 planes",
             "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.mode == "batch" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "mode": a.mode,
-                       "pairs_per_step_per_gpu": (len(order) if order is not None else B), "resident_stacks_per_gpu": B,
+            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial",
+                       "pairs_per_step_per_gpu": len(order), "resident_stacks_per_gpu": B, "timed_seconds": dt,
                        "sharding": "independent images per rank (i % world == rank), stats all-reduce only",
                        "device": _lib.device_info(local),
                        "world_size": world, "backend": ("%s (RCCL over xGMI)" % backend if backend == "nccl" else backend) if world > 1 else "none (single rank)",
@@ -385,8 +562,9 @@ def main():
                                    ("external (torchrun)" if world > 1 else "none"),
                        "ranks": rank_devices},
             "roofline": roof,
-            "roofline_stage_ac": roofs["stage_ac"],
         }
+        if not pipelined:
+            out["roofline_stage_ac"] = roofs["stage_ac"]
         if a.mode == "batch":
             out["config"]["batch_images"] = a.batch
             out["config"]["pairs_rank0_per_step"] = len(order)
@@ -394,18 +572,29 @@ def main():
         torch.cuda.empty_cache()
         if world == 1 and not a.no_sub and a.mode == "resident":
             sub = []
-            if dynamic:
-                sub.append(sub_record("c2: BASELINE configs[1], 64x640x960 camera-only pair", 64, 640, 960, 4, dev, False, 5))
-                sub.append(sub_record("c3 with one Stage B launch per view (comparison)", 64, 640, 960, 4, dev, True, 5, multi_view=False))
+            c3 = sub_record("c3 serial: BASELINE configs[2], 64x640x960 dynamic pair, one kernel after the other (per-kernel roofline entries)", 64, 640, 960, 4, dev, True, 5)
+            sub.append(c3)
+            if pipelined:
+                out["roofline_stage_b"], out["roofline_stage_ac"] = c3["stage_b"], c3["stage_ac"]
             else:
-                sub.append(sub_record("c3: BASELINE configs[2], 64x640x960 dynamic pair", 64, 640, 960, 4, dev, True, 5))
-            sub.append(sub_record("c1: BASELINE configs[0] shape, 32x384x512 dynamic pair (on the GPU: the product has no CPU path)", 32, 384, 512, 8, dev, True, 10))
-            sub.append(sub_record("c5: BASELINE configs[4] shape, 128x1024x1536 dynamic pair, random poses", 128, 1024, 1536, 2, dev, True, 5))
+                sub.append(sub_record("c3 pipelined: Stage B of pair i + Stage A+C of pair i+1 per launch", 64, 640, 960, 4, dev, True, 5, pipelined=True))
+            sub.append(sub_record("c3 + moving-object chain (SURVEY 8(d)'s full c3): serial pair + depth->flow projection, forward warp, masks on disp = rand",
+                                  64, 640, 960, 4, dev, True, 5, moving_object=True))
+            sub.append(sub_record("c2: BASELINE configs[1], 64x640x960 camera-only pair", 64, 640, 960, 4, dev, False, 5))
+            sub.append(sub_record("c1: BASELINE configs[0] shape, 32x384x512 dynamic pair, pipelined (on the GPU: the product has no CPU path)", 32, 384, 512, 8, dev, True, 10, pipelined=True))
+            sub.append(sub_record("c1 serial", 32, 384, 512, 8, dev, True, 10))
+            sub.append(sub_record("c5: BASELINE configs[4] shape, 128x1024x1536 dynamic pair, random poses, pipelined", 128, 1024, 1536, 2, dev, True, 5, pipelined=True))
+            sub.append(sub_record("c5 serial", 128, 1024, 1536, 2, dev, True, 5))
             out["sub"] = sub
             if dynamic:
                 out["overlap"] = overlap_record(S, H, W, dev)
         if world == 1 and not a.no_sub:
             out["hbm_reference"] = hbm_reference(dev)
+        if world == 1 and not a.no_sub and not a.no_generator and a.mode == "resident":
+            try:
+                out["generator"] = generator_record()
+            except Exception as e:                                   # noqa: BLE001 - a side record must never cost the headline line
+                out["generator"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, H, W, a.cpu_pairs)
             out["cpu_baseline"]["reference_measured_in_build_container"] = \

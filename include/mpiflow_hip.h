@@ -51,7 +51,8 @@ const char *mpf_last_error(void);
 /* fills CU count, HBM bytes, gfx arch name (e.g. "gfx950"); any pointer may be NULL */
 int mpf_device_info(int device, int *cu_count, size_t *hbm_bytes, char *arch, size_t arch_len);
 
-/* bench/tuning knobs (never change results): "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2); "stage_b" = Stage B kernel variant */
+/* bench/tuning knobs (never change results): "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2); "stage_b" = Stage B kernel
+ * variant; "ovl_depth" = planes of loads a Stage A+C wave keeps in flight inside mpf_warp_views_and_blend_next (4 or 8) */
 int mpf_tune(const char *key, int value);
 
 /* ================= fused hot path =============================================================================== */
@@ -111,6 +112,22 @@ typedef struct MpfWarpView {
 } MpfWarpView;
 int mpf_warp_composite_views(const float *d_rgba, int interleaved, const MpfWarpView *views, int n_views, int S, int H,
                              int W, void *stream);
+
+/* Stage B of one image AND Stage A+C of the NEXT image in one launch - the throughput form of the reference's unit of work
+ * (utils/utils.py:190-236: one source-frame pass, :190-204 + render :7-39, then two target-frame passes, :210-236).  Run back to back
+ * the two stages are an HBM-bound kernel followed by a VALU-issue-bound one; here a heterogeneous grid interleaves their workgroups
+ * so that every CU holds both kinds at once.  Exactly the arithmetic of
+ *     mpf_warp_composite_views(d_rgba, 2, views, n_views, S, H, W)                                              and
+ *     mpf_src_blend_flow(d_mpi_next, d_img_next, d_params_next, P, S, H, W, flow_clip, d_out_rgba_next, NULL, NULL, d_flows_next,
+ *                        d_src_u8_bgr_next, d_obj_mask_next, d_quads_next, d_quads_complement_next, d_cum_mask_next)
+ * - results are bit-identical to those two calls; arguments have the meaning of their same-named counterparts there.
+ * d_rgba (read) is a tail-padded interleaved stack (interleaved == 2); d_out_rgba_next (written) must be a DIFFERENT buffer, and so
+ * must every *_next output be from anything the views read or write: the two halves of the launch are unordered. */
+int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpView *views, int n_views,
+                                  const float *d_mpi_next, const float *d_img_next, const float *d_params_next, int P,
+                                  float flow_clip, float *d_out_rgba_next, float *d_flows_next, uint8_t *d_src_u8_bgr_next,
+                                  const float *d_obj_mask_next, float *d_quads_next, float *d_quads_complement_next,
+                                  const float *d_cum_mask_next, int S, int H, int W, void *stream);
 
 /* Stage D.  Replaces utils/utils.py:237-283 (uint8 BGR conversion, threshold, layer select, fill mask).
  * frames [3,H,W] RGB float, masks [H,W], flows [2,H,W], obj_mask [H,W] ->

@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpiflow_hip.so")
+# MPIFLOW_HIP_LIB: development hook for same-box A/B timing of two builds of the library (tools/); symbols an older build lacks are skipped
+LIB_PATH = os.environ.get("MPIFLOW_HIP_LIB") or os.path.join(_HERE, "libmpiflow_hip.so")
 
 _lib = None
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "mpf_build_mask_quads": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "mpf_warp_composite": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpf_warp_composite_views": (c_i, [c_p, c_i, ctypes.POINTER(MpfWarpView), c_i, c_i, c_i, c_i, c_p]),
+    "mpf_warp_views_and_blend_next": (c_i, [c_p, ctypes.POINTER(MpfWarpView), c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "mpf_merge": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),
     "mpf_fill_holes_workspace": (c_sz, [c_i, c_i]),
     "mpf_fill_holes": (c_i, [c_p, c_p, c_i, c_i, c_p, c_sz, c_p]),
@@ -100,6 +102,8 @@ def load():
             "`make -C mpiflow_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("MPIFLOW_HIP_LIB") and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
         fn.restype = res
         fn.argtypes = args

@@ -177,6 +177,13 @@ k_warp_composite(const float *__restrict__ rgba, const float *__restrict__ quads
 //   * plane base pointers stay scalar (SGPR base + 32-bit VGPR byte offset), validity is counted where it is computed
 // ---------------------------------------------------------------------------------------------------------------
 
+// d_params is read-only for the whole launch.  hipcc proves that for a plain global pointer only while nothing in the kernel could
+// alias it: behind a workgroup barrier (the fence of __syncthreads() counts as a clobber), or inside a kernel that also carries another
+// role with stores through unrelated pointers (k_pair_overlap), the per-plane records turn into VECTOR loads issued right before their
+// use - measured: 3-6 extra VMEM instructions and a full memory latency per wave and plane, plus the registers to hold them (spills at
+// 5 waves per SIMD).  Reading them through the constant address space keeps them on the scalar unit, whatever surrounds the body.
+typedef const __attribute__((address_space(4))) float *MpfConstParams;
+
 struct MpfGeom {
     float nw, ne, sw, se;
     float X, Y, Z;
@@ -244,7 +251,7 @@ MPF_DEV float mpf_geom_core(const ParamPtr params, int s, const MpfConsts &c, fl
 }
 
 template <bool KS, bool TP, bool WANT_VALID = true>
-MPF_DEV float mpf_geom(const float *__restrict__ params, int s, const MpfConsts &c, MpfGeom &g)
+MPF_DEV float mpf_geom(const MpfConstParams params, int s, const MpfConsts &c, MpfGeom &g)
 {
     int x0, y0;
     float qz;
@@ -343,11 +350,12 @@ struct MpfAcc {
 // DBG (bench-only ablations, results are NOT valid): 1 = no gathers (taps synthesised from the geometry), 2 = gathers and
 // bilinear sums only (geometry of plane 0 reused for every plane, no distance / exp / composite)
 template <bool HAS_MASK, int NL, int TW, int TH, bool KS, bool TP, int DBG = 0, bool AUX = true>
-MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
+MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params_global,
                           int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
                           float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out,
                           const unsigned tile)
 {
+    const MpfConstParams params = (MpfConstParams)params_global;
     const int64_t N = (int64_t)H * W;
     const unsigned tiles_x = (W + TW - 1) / TW;
     const int x = (tile % tiles_x) * TW + (threadIdx.x % TW);
@@ -563,11 +571,6 @@ struct MpfBox {          // wave-uniform (SGPRs)
 };
 
 
-// d_params is read-only for the whole launch.  Behind a workgroup barrier hipcc no longer proves that for a plain global
-// pointer (the fence of __syncthreads() counts as a clobber), and the per-plane records turn into VECTOR loads issued right
-// before their use - measured: 3 extra VMEM instructions and a full memory latency per wave and plane.  Reading them
-// through the constant address space keeps them on the scalar unit.
-typedef const __attribute__((address_space(4))) float *MpfConstParams;
 
 template <bool KS, bool AUX>
 MPF_DEV float mpf_geom_l(MpfConstParams params, int s, const MpfConsts &c, MpfGeomL &g)
@@ -944,16 +947,40 @@ extern "C" int mpf_build_mask_quads(const float *d_obj_mask, int complement, int
 // BLEND = false: flow-only pass (no rgba / planar / tacc output requested): only the sigma channel is read - 4*S*N bytes
 // instead of 16*S*N.  The blended stack depends on the image alone, so a caller rendering several pairs of one image
 // (the reference's `repeat` loop) blends once and runs this variant per pair.
-template <int PX, int P, int NL, bool ACT = false, bool BLEND = true, bool NT_STORE = (MPF_NT_STORE != 0)>
-__global__ void __launch_bounds__(256)
-k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, const float *__restrict__ params, int S,
-                 int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
-                 float *__restrict__ out_tacc, float *__restrict__ flows, int64_t T, uint8_t *__restrict__ src_u8,
-                 const float *__restrict__ obj_mask, float4 *__restrict__ quads, float4 *__restrict__ quads_c,
-                 const float *__restrict__ cum_mask)
+// DEPTH: register sets of plane loads in flight (the plane loop is unrolled DEPTH times so that every set is addressed statically).
+//        2 for the stand-alone kernel, whose 12 waves per CU keep enough bytes in flight between them; the overlapped pair kernel
+//        (k_pair_overlap) gives Stage A+C only about one workgroup per CU and makes each wave carry 4-8 planes instead.
+struct MpfSbfArgs {
+    const float *mpi, *img, *params;
+    float flow_clip;
+    float *out_rgba, *out_planar, *out_tacc, *flows;
+    int64_t T;                      // number of threads that own pixels (thread t owns pixels t, t + T, ...)
+    uint8_t *src_u8;
+    const float *obj_mask;
+    float4 *quads, *quads_c;
+    const float *cum_mask;
+};
+
+template <int PX, int P, int NL, bool ACT, bool BLEND, bool NT_STORE, int DEPTH>
+MPF_DEV void mpf_sbf_body(const MpfSbfArgs &a, const int S, const int H, const int W, const int64_t t)
 {
+    const float *__restrict__ mpi = a.mpi;
+    const float *__restrict__ img = a.img;
+    // d_params is read-only for the whole launch; read through the constant address space so that the per-plane records stay SCALAR
+    // loads whatever the compiler can prove about the stores in between (see MpfConstParams)
+    const MpfConstParams params = (MpfConstParams)a.params;
+    const float *__restrict__ cum_mask = a.cum_mask;
+    const float *__restrict__ obj_mask = a.obj_mask;
+    float *__restrict__ out_rgba = a.out_rgba;
+    float *__restrict__ out_planar = a.out_planar;
+    float *__restrict__ out_tacc = a.out_tacc;
+    float *__restrict__ flows = a.flows;
+    uint8_t *__restrict__ src_u8 = a.src_u8;
+    float4 *__restrict__ quads = a.quads;
+    float4 *__restrict__ quads_c = a.quads_c;
+    const float flow_clip = a.flow_clip;
+    const int64_t T = a.T;
     const int64_t N = (int64_t)H * W;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     constexpr int NP = (P > 0) ? P : 1;
     constexpr int RS = MPF_PLANE_RECORD * NP;            // floats between two planes' records
@@ -991,36 +1018,42 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
         if (live[i] && obj_mask) {
             const int x = (int)(n[i] % W), y = (int)(n[i] / W);
             const bool e = (x + 1) < W, so = (y + 1) < H;
-            const float a = obj_mask[n[i]];
+            const float a0 = obj_mask[n[i]];
             const float b = e ? obj_mask[n[i] + 1] : 0.0f;
             const float c2 = so ? obj_mask[n[i] + W] : 0.0f;
             const float d2 = (e && so) ? obj_mask[n[i] + W + 1] : 0.0f;
-            if (quads) quads[n[i]] = make_float4(a, b, c2, d2);
-            if (quads_c) quads_c[n[i]] = make_float4(1.0f - a, e ? 1.0f - b : 0.0f, so ? 1.0f - c2 : 0.0f, (e && so) ? 1.0f - d2 : 0.0f);
+            if (quads) quads[n[i]] = make_float4(a0, b, c2, d2);
+            if (quads_c) quads_c[n[i]] = make_float4(1.0f - a0, e ? 1.0f - b : 0.0f, so ? 1.0f - c2 : 0.0f, (e && so) ? 1.0f - d2 : 0.0f);
         }
     }
 
-    // Software pipeline: the 4 channel loads of plane s+1 are issued before plane s is processed (two register sets, x2
-    // unrolled), doubling the bytes each wave keeps in flight - the kernel is pure streaming and latency x bandwidth decides.
-    float chA[PX][4], chB[PX][4];
-    auto load_plane = [&](int s, float (&ch)[PX][4]) {
+    // Software pipeline: the 4 channel loads of planes s+1 .. s+DEPTH-1 are issued before plane s is processed (DEPTH register
+    // sets, the loop unrolled DEPTH times) - the kernel is pure streaming and latency x bandwidth decides.
+    float ch[DEPTH][PX][4];
+    auto load_plane = [&](int s, float (&chs)[PX][4]) {
         const float *pl = mpi + (int64_t)s * 4 * N;
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
 #pragma unroll
-            for (int c = BLEND ? 0 : 3; c < 4; ++c) ch[i][c] = pl[c * N + n[i]];
+            for (int c = BLEND ? 0 : 3; c < 4; ++c) {
+#if defined(MPF_OVL_NT_LOAD)
+                if (DEPTH != 2) chs[i][c] = __builtin_nontemporal_load(pl + c * N + n[i]);
+                else
+#endif
+                chs[i][c] = pl[c * N + n[i]];
+            }
             if (ACT) {
                 const float cm = cum_mask[(int64_t)s * N + n[i]];
                 if (BLEND) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) ch[i][c] = 1.0f / (1.0f + mpf_expf_fast(-ch[i][c]));
+                    for (int c = 0; c < 3; ++c) chs[i][c] = 1.0f / (1.0f + mpf_expf_fast(-chs[i][c]));
                 }
-                ch[i][3] = fmaxf(ch[i][3] * cm, 0.0f) + 1e-4f;
+                chs[i][3] = fmaxf(chs[i][3] * cm, 0.0f) + 1e-4f;
             }
         }
     };
-    auto do_plane = [&](int s, const float (&ch)[PX][4]) {
-        const float *rec = params + MPF_PARAMS_HEADER + RS * s;
+    auto do_plane = [&](int s, const float (&chs)[PX][4]) {
+        const MpfConstParams rec = params + MPF_PARAMS_HEADER + RS * s;
         const bool last = (s + 1 == S);
         const float dn = last ? 0.0f : rec[RS + 9];
 #pragma unroll
@@ -1028,7 +1061,7 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
             float nx = ray[i][0] * dn, ny = ray[i][1] * dn, nz = ray[i][2] * dn;
             float dist = last ? 1e3f : mpf_norm3_nr(nx - cur[i][0], ny - cur[i][1], nz - cur[i][2]);
             cur[i][0] = nx; cur[i][1] = ny; cur[i][2] = nz;
-            const float sg = ch[i][3];
+            const float sg = chs[i][3];
             float Tr = mpf_expf_fast(-sg * dist);
             float alpha = 1.0f - Tr;
             float tacc = (float)acc[i];
@@ -1039,9 +1072,9 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
             if (BLEND) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    float a = tacc * im[i][c];                 // blend_weights * src_imgs          utils/utils.py:202-204
-                    float bb = one_m * ch[i][c];               // (1 - blend_weights) * mpi_rgb
-                    o[c] = a + bb;
+                    float av = tacc * im[i][c];                // blend_weights * src_imgs          utils/utils.py:202-204
+                    float bb = one_m * chs[i][c];              // (1 - blend_weights) * mpi_rgb
+                    o[c] = av + bb;
                 }
             }
             if (BLEND && live[i]) {
@@ -1049,6 +1082,15 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
                     typedef float mpf_v4f __attribute__((ext_vector_type(4)));
                     mpf_v4f *dst = reinterpret_cast<mpf_v4f *>(out_rgba) + ((int64_t)s * N + n[i]);
                     const mpf_v4f val = { o[0], o[1], o[2], sg };
+#if defined(MPF_OVL_STORE_POLICY)
+                    if (DEPTH != 2) {                      // experiment build: cache policy of the overlapped role's stack stores
+                        if (MPF_OVL_STORE_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
+                        else if (MPF_OVL_STORE_POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(val) : "memory");
+                        else if (MPF_OVL_STORE_POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst), "v"(val) : "memory");
+                        else if (MPF_OVL_STORE_POLICY == 0) *dst = val;
+                        else __builtin_nontemporal_store(val, dst);
+                    } else
+#endif
                     if (NT_STORE) __builtin_nontemporal_store(val, dst);
                     else *dst = val;
                 }
@@ -1061,7 +1103,7 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
             if (P > 0) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const float *h = rec + MPF_PLANE_RECORD * p;
+                    const MpfConstParams h = rec + MPF_PLANE_RECORD * p;
                     float qx = mpf_row3_xy1(h[0], h[1], h[2], fx[i], fy[i]);
                     float qy = mpf_row3_xy1(h[3], h[4], h[5], fx[i], fy[i]);
                     float qz = mpf_row3_xy1(h[6], h[7], h[8], fx[i], fy[i]);
@@ -1078,20 +1120,23 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
                 for (int p = 0; p < NP; ++p) { cf[i][p][0].fold(s + 1); cf[i][p][1].fold(s + 1); }
         }
     };
-    load_plane(0, chA);
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1; ++k)
+        if (k < S) load_plane(k, ch[k]);
     int s = 0;
-    for (; s + 2 <= S - 1; s += 2) {
-        load_plane(s + 1, chB);
-        do_plane(s, chA);
-        load_plane(s + 2, chA);
-        do_plane(s + 1, chB);
+    for (; s + 2 * DEPTH - 2 < S; s += DEPTH) {                         // steady state: branch-free, every register set addressed statically
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            load_plane(s + k + DEPTH - 1, ch[(k + DEPTH - 1) % DEPTH]);
+            do_plane(s + k, ch[k]);
+        }
     }
-    if (s + 1 < S) {
-        load_plane(s + 1, chB);
-        do_plane(s, chA);
-        do_plane(s + 1, chB);
-    } else {
-        do_plane(s, chA);
+#pragma unroll
+    for (int k = 0; k < 2 * DEPTH - 2; ++k) {                           // the last < 2 DEPTH - 2 planes (uniform branches)
+        if (s + k < S) {
+            if (s + k + DEPTH - 1 < S) load_plane(s + k + DEPTH - 1, ch[(k + DEPTH - 1) % DEPTH]);
+            do_plane(s + k, ch[k % DEPTH]);
+        }
     }
     if (P > 0) {
 #pragma unroll
@@ -1105,6 +1150,18 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
                     if (live[i]) flows[((int64_t)p * 2 + k) * N + n[i]] = f;
                 }
     }
+}
+
+template <int PX, int P, int NL, bool ACT = false, bool BLEND = true, bool NT_STORE = (MPF_NT_STORE != 0)>
+__global__ void __launch_bounds__(256)
+k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, const float *__restrict__ params, int S,
+                 int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
+                 float *__restrict__ out_tacc, float *__restrict__ flows, int64_t T, uint8_t *__restrict__ src_u8,
+                 const float *__restrict__ obj_mask, float4 *__restrict__ quads, float4 *__restrict__ quads_c,
+                 const float *__restrict__ cum_mask)
+{
+    const MpfSbfArgs a = { mpi, img, params, flow_clip, out_rgba, out_planar, out_tacc, flows, T, src_u8, obj_mask, quads, quads_c, cum_mask };
+    mpf_sbf_body<PX, P, NL, ACT, BLEND, NT_STORE, 2>(a, S, H, W, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 template <int PX, int P>
@@ -1159,12 +1216,119 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
 #undef MPF_SBF
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stage B of image i  ||  Stage A+C of image i+1, in ONE launch (the reference's unit of work, utils/utils.py:190-236, is one
+// source-frame pass plus two target-frame passes; back to back they are an HBM-bound kernel followed by a VALU-issue-bound one).
+//
+// Run as two kernels on two streams they barely overlap: each is sized to fill the chip on its own (Stage B takes 480 of the 512
+// VGPRs of every SIMD), so the second only gets the first one's tail.  Here the GRID is heterogeneous instead: the k-th workgroup
+// dispatched to an XCD is a Stage A+C workgroup for KA out of every KA + KB positions (a Bresenham pattern) and a Stage B workgroup
+// otherwise, both compiled into one kernel with Stage B's register budget (5 waves per SIMD).  Workgroups are dispatched in
+// index order as slots free up, so both kinds advance through their lists at the same pace and finish together, and every CU
+// holds a mix of them at any time: while the A+C waves wait on HBM (they stream 1.27 GB) the Stage B waves issue arithmetic.
+// Both roles run exactly the bodies of the stand-alone kernels (mpf_wc2_select, mpf_sbf_body), so results are bit-identical.
+//   * Stage B keeps its XCD-aware strip order: its logical index is recovered from (xcd, rank among the B blocks of that XCD).
+//   * Stage A+C gets only ~1 workgroup per CU, so each wave carries DEPTH (4-8) planes of loads in flight instead of 2, one pixel
+//     per thread (46-62 VGPRs, inside Stage B's 96).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool HAS_MASK, int NL, int P, bool ACT, int DEPTH>
+__global__ void __launch_bounds__(256, 5)
+k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsigned V, const MpfSbfArgs ac, const int S, const int H, const int W,
+               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate)
+{
+    constexpr int TW = 32, TH = 8;
+    const unsigned xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;          // the k-th workgroup of this XCD
+    const unsigned per = KB + KA;
+    const unsigned a0 = (k * KA) / per, a1 = ((k + 1u) * KA) / per;     // A+C workgroups among the first k / k + 1 of this XCD
+    if (a1 > a0) {
+        const unsigned ja = a0 * 8u + xcd;
+        if (ja >= nA || (ablate & 3) == 1) return;                       // ablate (bench only): 1 = Stage B workgroups only, 2 = Stage A+C only
+        if (((ablate >> 2) & 3) == 1) __builtin_amdgcn_s_setprio(1);      // bits 2-3: wave priority of the A+C role (tuning experiment)
+        else if (((ablate >> 2) & 3) == 2) __builtin_amdgcn_s_setprio(2);
+        else if (((ablate >> 2) & 3) == 3) __builtin_amdgcn_s_setprio(3);
+        mpf_sbf_body<1, P, NL, ACT, true, true, DEPTH>(ac, S, H, W, (int64_t)ja * 256 + threadIdx.x);
+    } else {
+        const unsigned jb = (k - a0) * 8u + xcd;
+        if (jb >= nB || (ablate & 3) == 2) return;
+        if (((ablate >> 4) & 3) == 1) __builtin_amdgcn_s_setprio(1);      // bits 4-5: wave priority of the Stage B role
+        else if (((ablate >> 4) & 3) == 3) __builtin_amdgcn_s_setprio(3);
+        const unsigned l = mpf_xcd_remap(jb, nB);
+        const unsigned view = l % V;
+        const unsigned tile = mpf_strip_order(l / V, (W + TW - 1) / TW, (H + TH - 1) / TH);
+        const MpfWarpView &w = vs.v[view];
+        mpf_wc2_select<HAS_MASK, NL, TW, TH, true>(rgba_b, w.d_mask_quads, w.d_params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask,
+                                                   w.d_rgb_u8_bgr, tile);
+    }
+}
+
+static int g_ovl_depth = 8;     // mpf_tune("ovl_depth", 4 | 8)
+static int g_ovl_ablate = 0;    // mpf_tune("ovl_ablate", 0 | 1 | 2): bench-only, results invalid when non-zero
+
+template <bool HAS_MASK, int NL, int P, bool ACT>
+static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V, const MpfSbfArgs &ac, int S, int H, int W, hipStream_t st)
+{
+    const unsigned tiles = ((W + 31) / 32) * ((H + 7) / 8);
+    const unsigned nB = tiles * V;
+    const unsigned nA = (unsigned)((ac.T + 255) / 256);
+    const unsigned KB = (nB + 7) / 8, KA = (nA + 7) / 8;
+    dim3 grid(8u * (KB + KA)), block(256);
+    if (g_ovl_depth == 4)
+        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate);
+    else
+        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 8>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate);
+    return mpf_launch_status("k_pair_overlap");
+}
+
+extern "C" int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpView *views, int n_views,
+                                             const float *d_mpi_next, const float *d_img_next, const float *d_params_next, int P,
+                                             float flow_clip, float *d_out_rgba_next, float *d_flows_next, uint8_t *d_src_u8_bgr_next,
+                                             const float *d_obj_mask_next, float *d_quads_next, float *d_quads_complement_next,
+                                             const float *d_cum_mask_next, int S, int H, int W, void *stream)
+{
+    MPF_REQUIRE(d_rgba && views && d_mpi_next && d_img_next && d_params_next && d_out_rgba_next, "mpf_warp_views_and_blend_next: null pointer");
+    MPF_REQUIRE(d_out_rgba_next != d_rgba, "mpf_warp_views_and_blend_next: the stack being rendered and the stack being written must be different buffers");
+    MPF_REQUIRE(n_views >= 1 && n_views <= MPF_MAX_VIEWS, "mpf_warp_views_and_blend_next: n_views must be 1..%d (got %d)", MPF_MAX_VIEWS, n_views);
+    MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_warp_views_and_blend_next: bad shape S=%d H=%d W=%d", S, H, W);
+    MPF_REQUIRE((int64_t)H * W < ((int64_t)1 << 27), "mpf_warp_views_and_blend_next: H*W too large for 32-bit byte offsets");
+    MPF_REQUIRE(mpf_aligned16(d_rgba) && mpf_aligned16(d_out_rgba_next), "mpf_warp_views_and_blend_next: the stacks must be 16-byte aligned");
+    MPF_REQUIRE(P >= 0 && P <= 2 && (P == 0) == (d_flows_next == nullptr), "mpf_warp_views_and_blend_next: P must be 0..2, flows output iff P > 0");
+    MPF_REQUIRE((d_quads_next == nullptr && d_quads_complement_next == nullptr) || d_obj_mask_next, "mpf_warp_views_and_blend_next: quads need d_obj_mask_next");
+    MPF_REQUIRE(mpf_aligned16(d_quads_next) && mpf_aligned16(d_quads_complement_next), "mpf_warp_views_and_blend_next: quads must be 16-byte aligned");
+    MpfViewSet vs;
+    memset(&vs, 0, sizeof(vs));
+    const bool has_mask = views[0].d_mask_quads != nullptr;
+    for (int v = 0; v < n_views; ++v) {
+        const MpfWarpView &w = views[v];
+        MPF_REQUIRE(w.d_params && w.d_rgb, "mpf_warp_views_and_blend_next: view %d: null params / rgb", v);
+        MPF_REQUIRE((w.d_mask_quads != nullptr) == has_mask, "mpf_warp_views_and_blend_next: all views of a call take a mask, or none does");
+        MPF_REQUIRE((w.d_mask_quads == nullptr) == (w.d_objmask == nullptr), "mpf_warp_views_and_blend_next: view %d: mask quads and objmask output go together", v);
+        MPF_REQUIRE(mpf_aligned16(w.d_mask_quads), "mpf_warp_views_and_blend_next: view %d: mask quads must be 16-byte aligned", v);
+        vs.v[v] = w;
+    }
+    const int64_t N = (int64_t)H * W;
+    const MpfSbfArgs ac = { d_mpi_next, d_img_next, d_params_next, flow_clip, d_out_rgba_next, nullptr, nullptr, d_flows_next, N, d_src_u8_bgr_next,
+                            (d_quads_next || d_quads_complement_next) ? d_obj_mask_next : nullptr, reinterpret_cast<float4 *>(d_quads_next),
+                            reinterpret_cast<float4 *>(d_quads_complement_next), d_cum_mask_next };
+    hipStream_t st = (hipStream_t)stream;
+#define MPF_OVL(HM, NLv)                                                                                                        \
+    switch (P) {                                                                                                                \
+    case 0: return d_cum_mask_next ? launch_overlap<HM, NLv, 0, true>(d_rgba, vs, n_views, ac, S, H, W, st) : launch_overlap<HM, NLv, 0, false>(d_rgba, vs, n_views, ac, S, H, W, st); \
+    case 1: return d_cum_mask_next ? launch_overlap<HM, NLv, 1, true>(d_rgba, vs, n_views, ac, S, H, W, st) : launch_overlap<HM, NLv, 1, false>(d_rgba, vs, n_views, ac, S, H, W, st); \
+    default: return d_cum_mask_next ? launch_overlap<HM, NLv, 2, true>(d_rgba, vs, n_views, ac, S, H, W, st) : launch_overlap<HM, NLv, 2, false>(d_rgba, vs, n_views, ac, S, H, W, st); \
+    }
+    if (S < 256) { if (has_mask) { MPF_OVL(true, 2) } else { MPF_OVL(false, 2) } }
+    else         { if (has_mask) { MPF_OVL(true, 3) } else { MPF_OVL(false, 3) } }
+#undef MPF_OVL
+}
+
 void mpf_fwarp_set_path(int v);      // mpf_fwarp.hip
 
 extern "C" int mpf_tune(const char *key, int value)
 {
     if (key && !strcmp(key, "sbf_px")) { g_sbf_px = value; return 0; }
     if (key && !strcmp(key, "stage_b")) { g_stage_b_variant = value; return 0; }
+    if (key && !strcmp(key, "ovl_depth")) { g_ovl_depth = (value == 4) ? 4 : 8; return 0; }
+    if (key && !strcmp(key, "ovl_ablate")) { g_ovl_ablate = value; return 0; }
     if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
     mpf_set_error("mpf_tune: unknown key");
     return MPF_ERR_BAD_ARGUMENT;

@@ -180,6 +180,43 @@ def warp_composite_views(rgba, views, interleaved=2):
     return [v["out"] for v in views]
 
 
+def _view_array(views, device):
+    arr = (_lib.MpfWarpView * len(views))()
+    for i, v in enumerate(views):
+        o = v["out"]
+        q = v.get("quads")
+        for t in [v["dparams"], q] + [o.get(k) for k in ("rgb", "depth", "objmask", "tgt_mask", "rgb_u8")]:
+            assert t is None or (t.is_cuda and t.is_contiguous() and t.device == device)
+        arr[i] = _lib.MpfWarpView(v["dparams"].data_ptr(), q.data_ptr() if q is not None else None, o["rgb"].data_ptr(),
+                                  *[(o[k].data_ptr() if o.get(k) is not None else None) for k in ("depth", "objmask", "tgt_mask", "rgb_u8")])
+    return arr
+
+
+@_on_device
+def warp_views_and_blend_next(rgba, views, mpi_next, img_next, dparams_next, P, out_rgba_next, out_flows_next=None, flow_clip=200.0,
+                              src_u8_next=None, obj_mask_next=None, quads_next=None, quads_complement_next=None, cum_mask_next=None):
+    """Stage B of one image (all `views` of the tail-padded stack `rgba`, as warp_composite_views) and Stage A+C of the NEXT image
+    (as src_blend_flow with preallocated outputs) in ONE launch whose grid interleaves the two kinds of workgroups
+    (mpf_warp_views_and_blend_next).  Bit-identical to the two separate calls; every *_next buffer must be distinct from what the
+    views read or write."""
+    lib = _lib.load()
+    a = _dev(rgba, "rgba")
+    S, H, W, C = a.shape
+    assert C == 4 and 1 <= len(views) <= _lib.MAX_VIEWS
+    assert a.untyped_storage().nbytes() - a.storage_offset() * 4 >= a.numel() * 4 + (W + 1) * 16
+    mpi = _dev(mpi_next, "mpi_next")
+    assert tuple(mpi.shape) == (S, 4, H, W) and out_rgba_next.is_contiguous() and tuple(out_rgba_next.shape) == (S, H, W, 4)
+    assert out_rgba_next.data_ptr() != a.data_ptr()
+    img = _dev(img_next, "img_next").reshape(3, H, W)
+    arr = _view_array(views, a.device)
+    om = _dev(obj_mask_next, "obj_mask_next").reshape(H, W) if obj_mask_next is not None else None
+    cm = _dev(cum_mask_next, "cum_mask_next") if cum_mask_next is not None else None
+    _lib.check(lib.mpf_warp_views_and_blend_next(_ptr(a), arr, len(views), _ptr(mpi), _ptr(img), _ptr(dparams_next), int(P), float(flow_clip),
+                                                 _ptr(out_rgba_next), _ptr(out_flows_next), _ptr(src_u8_next), _ptr(om), _ptr(quads_next),
+                                                 _ptr(quads_complement_next), _ptr(cm), S, H, W, _stream()), "mpf_warp_views_and_blend_next")
+    return [v["out"] for v in views]
+
+
 @_on_device
 def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.99, out=None):
     """Stage D.  out: optional preallocated (flow_mix [H,W,2] f32, frame_mix [H,W,3] u8, fill_mask [H,W] u8)."""

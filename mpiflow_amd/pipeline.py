@@ -23,27 +23,9 @@ from . import host_math, ops
 MASK_THRESH = 0.99
 
 
-class PairRenderer:
-    """Preallocated fused renderer for one (S, H, W) on one device."""
-
-    def __init__(self, S, H, W, device, n_views=2):
-        self.S, self.H, self.W, self.device = S, H, W, torch.device(device)
-        f32 = torch.float32
-        dev = self.device
-        self.rgba = ops.alloc_rgba_stack(S, H, W, dev)                            # blended interleaved stack (+ tail padding)
-        self.flows = torch.empty((n_views, 2, H, W), dtype=f32, device=dev)
-        # the fused pipeline never reads depth / tgt_mask (the reference discards them too, utils/utils.py:210, :330):
-        # leaving them out selects the leaner Stage B body
-        self.views = [dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), objmask=torch.empty((H, W), dtype=f32, device=dev),
-                           rgb_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev)) for _ in range(n_views)]
-        self.quads = [torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)]    # obj_mask, 1 - obj_mask
-        self.src_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-        self.n_views = n_views
-        # all Stage B views of a pair in ONE launch (mpf_warp_composite_views): with the strip-major tile order it wins at every shape
-        # measured - x1.06 (128 x 1024 x 1536) to x1.17 (64 x 640 x 960) for a pair, x1.20-1.42 for the 10 views of a `repeat` loop
-        # (profiles/r2/stage_b_views_strip_shapes.log).  False = one launch per view (bench.py's comparison record, tests).
-        self.multi_view = True
-        self._pair_bufs = []
+class _PairHostSide:
+    """Host side of a renderer: the small matrices of a pair (K^-1, plane depths, per-plane homographies of every pose) computed with
+    the reference's batched torch-CPU expressions and uploaded as d_params blocks.  Needs self.device."""
 
     # -- host side: small matrices ---------------------------------------------------------------------------------
     def _constants(self, K, disparity):
@@ -86,6 +68,29 @@ class PairRenderer:
         dev = host.to(device=self.device, non_blocking=True)
         view = lambda i: dev[offs[i]:offs[i] + blocks[i].numel()]  # noqa: E731
         return [dict(P=2, blend=view(3 * r), warp=[view(3 * r + 1), view(3 * r + 2)], k_inv=k_inv, depths=d) for r in range(len(pose_pairs))]
+
+
+class PairRenderer(_PairHostSide):
+    """Preallocated fused renderer for one (S, H, W) on one device."""
+
+    def __init__(self, S, H, W, device, n_views=2):
+        self.S, self.H, self.W, self.device = S, H, W, torch.device(device)
+        f32 = torch.float32
+        dev = self.device
+        self.rgba = ops.alloc_rgba_stack(S, H, W, dev)                            # blended interleaved stack (+ tail padding)
+        self.flows = torch.empty((n_views, 2, H, W), dtype=f32, device=dev)
+        # the fused pipeline never reads depth / tgt_mask (the reference discards them too, utils/utils.py:210, :330):
+        # leaving them out selects the leaner Stage B body
+        self.views = [dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), objmask=torch.empty((H, W), dtype=f32, device=dev),
+                           rgb_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev)) for _ in range(n_views)]
+        self.quads = [torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)]    # obj_mask, 1 - obj_mask
+        self.src_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        self.n_views = n_views
+        # all Stage B views of a pair in ONE launch (mpf_warp_composite_views): with the strip-major tile order it wins at every shape
+        # measured - x1.06 (128 x 1024 x 1536) to x1.17 (64 x 640 x 960) for a pair, x1.20-1.42 for the 10 views of a `repeat` loop
+        # (profiles/r2/stage_b_views_strip_shapes.log).  False = one launch per view (bench.py's comparison record, tests).
+        self.multi_view = True
+        self._pair_bufs = []
 
     # -- device side: launches only ------------------------------------------------------------------------------------
     def blend(self, mpi, image, K, disparity, cum_mask=None):
@@ -154,6 +159,74 @@ class PairRenderer:
             flow_mix, frame_mix, fill = ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"][0], b["flows"][1], om, thresh)
             out.append(dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill))
         return out
+
+
+class OverlappedPairRenderer(_PairHostSide):
+    """A STREAM of dynamic pairs (one image each) rendered as a two-stage software pipeline: Stage B (both posed views) of pair i and
+    Stage A+C (blend + both flows + source frame + mask quads) of pair i+1 go into ONE launch whose grid interleaves the two kinds of
+    workgroups (mpf_warp_views_and_blend_next), so the HBM-bound source-frame pass runs underneath the issue-bound target-frame
+    passes instead of in front of them.  Per pair: one fused launch + one merge; the first pair of a run pays a stand-alone Stage A+C,
+    the last one (flush()) a stand-alone Stage B.  Same kernels bodies, same results, bit for bit, as PairRenderer.run() + merge.
+
+    push(mpi, image, prep, obj_mask, out) enqueues pair i+1 and completes pair i (its `out` = (flow_mix [H,W,2], frame_mix [H,W,3] u8,
+    fill_mask [H,W] u8) is written, stream-ordered, by the time push returns); flush() completes the last one.  Two slots of
+    per-pair buffers (blended stack, flows, quads, views) alternate: a slot is rewritten only after its pair has been merged."""
+
+    def __init__(self, S, H, W, device, thresh=MASK_THRESH):
+        self.S, self.H, self.W, self.device, self.thresh = S, H, W, torch.device(device), thresh
+        f32, dev = torch.float32, self.device
+        self.slots = [dict(rgba=ops.alloc_rgba_stack(S, H, W, dev), flows=torch.empty((2, 2, H, W), dtype=f32, device=dev),
+                           quads=[torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)],
+                           src_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev),
+                           views=[dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), objmask=torch.empty((H, W), dtype=f32, device=dev),
+                                       rgb_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev)) for _ in range(2)])
+                      for _ in range(2)]
+        self._next, self._pending = 0, None
+        self.on_fused = None                                         # optional hook(callable launching) -> used by bench.py to bracket with events
+
+    def _views(self, slot, prep):
+        return [dict(dparams=prep["warp"][v], quads=slot["quads"][v], out=slot["views"][v]) for v in range(2)]
+
+    def _finish(self, pend):
+        slot, om, out = pend["slot"], pend["om"], pend["out"]
+        v = slot["views"]
+        return ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], slot["flows"][0], slot["flows"][1], om, self.thresh, out=out)
+
+    def push(self, mpi, image, prep, obj_mask, out=None, cum_mask=None):
+        """Enqueue one pair (prep from prepare(K, disparity, [G_cam, G_dyn]); view 0 samples obj_mask, view 1 its complement).
+        Returns the (flow_mix, frame_mix, fill_mask) of the PREVIOUS pair, or None if there was none."""
+        assert prep["P"] == 2
+        slot = self.slots[self._next]
+        self._next ^= 1
+        done = None
+        if self._pending is None:
+            ops.src_blend_flow(mpi, image, out_rgba=slot["rgba"], out_flows=slot["flows"], dparams=prep["blend"], P=2, src_u8=slot["src_u8"],
+                               obj_mask=obj_mask, quads=slot["quads"][0], quads_complement=slot["quads"][1], cum_mask=cum_mask)
+        else:
+            pend = self._pending
+            launch = lambda: ops.warp_views_and_blend_next(                                                   # noqa: E731
+                pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), mpi, image, prep["blend"], 2, slot["rgba"],
+                out_flows_next=slot["flows"], src_u8_next=slot["src_u8"], obj_mask_next=obj_mask, quads_next=slot["quads"][0],
+                quads_complement_next=slot["quads"][1], cum_mask_next=cum_mask)
+            if self.on_fused is not None:
+                self.on_fused(launch)
+            else:
+                launch()
+            done = self._finish(pend)
+        self._pending = dict(slot=slot, prep=prep, om=obj_mask, out=out)
+        return done
+
+    def flush(self):
+        """Complete the last enqueued pair with a stand-alone Stage B launch; returns its (flow_mix, frame_mix, fill_mask) or None."""
+        if self._pending is None:
+            return None
+        pend, self._pending = self._pending, None
+        ops.warp_composite_views(pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), interleaved=2)
+        return self._finish(pend)
+
+    @property
+    def pending_slot(self):
+        return None if self._pending is None else self._pending["slot"]
 
 
 def hard_flows(mpi_S4HW, disparity_S, K, poses):

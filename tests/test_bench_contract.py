@@ -11,7 +11,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--planes", "16", "--height", "64", "--width", "96", "--images", "2", "--steps", "3", "--warmup", "1", "--cpu-pairs", "2"]
+SMALL = ["--planes", "16", "--height", "64", "--width", "96", "--images", "2", "--pairs-per-step", "0", "--steps", "3", "--warmup", "1", "--cpu-pairs", "2",
+         "--no-generator"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
         "config", "roofline"}
 
@@ -96,19 +97,48 @@ def test_batch_mode_two_ranks_over_gloo():
 
 
 def test_single_gpu_line_has_sub_records_and_names_the_dynamic_pair():
+    """The default-shaped line (2 steps): value = the pipelined dynamic pair with the heterogeneous-grid launch as roofline kernel; per-kernel
+    roofline entries from the NON-overlapped c3 sub-record, Stage A+C on SURVEY 8(d)'s bytes with the layout's byte count beside it; SURVEY
+    8(d)'s full c3 (pair + moving-object chain); c2 / c1 / c5; the two-pipeline record; the end-to-end generator; the on-box HBM figures."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--images", "2", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
-    assert "configs[2]" in d["config"]["workload"] and "dynamic pair" in d["config"]["workload"]
-    assert d["roofline"]["views_per_pair"] == 2 and 0.05 < d["roofline"]["frac"] < 1.0
+    cfg = d["config"]
+    assert "configs[2]" in cfg["workload"] and "dynamic pair" in cfg["workload"] and cfg["pipeline"] == "overlapped"
+    assert cfg["pairs_per_step_per_gpu"] == 104 and cfg["timed_seconds"] > 0 and cfg["world_size"] == 1 and len(cfg["ranks"]) == 1
+    S, N = 64, 640 * 960
+    rf = d["roofline"]
+    assert "k_pair_overlap" in rf["kernel"] and rf["views_per_pair"] == 2 and 0.05 < rf["frac"] < 1.0
+    assert rf["algorithmic_bytes_per_launch"] == 60.0 * S * N + 12.0 * N + 16.0 * N           # SURVEY 8(d): the pair's 60*S*N (+ image, flows)
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["launches_timed"] == 2 * 104 - 1
+    # the dominant kernel fits into the step: launches x mean duration <= timed seconds
+    assert rf["launches_timed"] * rf["avg_launch_ms"] * 1e-3 <= cfg["timed_seconds"]
+    ac, sb = d["roofline_stage_ac"], d["roofline_stage_b"]
+    assert ac["algorithmic_bytes_per_launch"] == 28.0 * S * N + 12.0 * N + 16.0 * N and ac["layout_bytes_per_launch"] == 32.0 * S * N + 12.0 * N + 16.0 * N
+    assert 0 < ac["frac"] < ac["frac_on_layout_bytes"] < 1 and sb["algorithmic_bytes_per_launch"] == 32.0 * S * N and 0.05 < sb["frac"] < 1
     names = [s_["workload"] for s_ in d["sub"]]
-    assert any(n.startswith("c2") for n in names) and any(n.startswith("c1") for n in names) and any(n.startswith("c5") for n in names)
+    for tag in ("c3 serial", "c3 + moving-object chain", "c2", "c1", "c5"):
+        assert any(n.startswith(tag) for n in names), tag
     for s_ in d["sub"]:
-        assert s_["stage_b"]["frac"] > 0 and s_["stage_ac"]["frac"] > 0
-    # the on-box streaming figures next to the 8 TB/s specification: plausible, and the kernels do not beat them
+        assert s_["pairs_per_s"] > 0 and ("pair" in s_ or (s_["stage_b"]["frac"] > 0 and s_["stage_ac"]["frac"] > 0))
+    by = {n.split(":")[0]: s_ for n, s_ in zip(names, d["sub"])}
+    assert by["c3 + moving-object chain (SURVEY 8(d)'s full c3)"]["us_per_pair"] > by["c3 serial"]["us_per_pair"]
     assert d["overlap"]["streams"] == 2 and d["overlap"]["pairs_per_s"] > 0.8 * d["value"]
+    g = d["generator"]
+    assert "error" not in g, g
+    assert g["pairs"] == 120 and g["flo_files_written"] == 120 and g["pairs_per_s_whole_process"] > 0 and g["pairs_per_s_steady_state"] > 0
+    # the on-box streaming figures next to the 8 TB/s specification (SURVEY.md 8(d)): plausible, and the kernels do not beat them
     hb = d["hbm_reference"]
     assert 1000.0 < hb["copy_GBps"] < 8000.0 and 1000.0 < hb["read_GBps"] < 8000.0
+
+
+def test_serial_pipeline_flag_keeps_the_round_2_structure():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pipeline", "serial", "--no-sub", "--no-cpu-baseline"] + SMALL, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["pipeline"] == "serial" and "k_warp_composite_views" in d["roofline"]["kernel"] and "roofline_stage_ac" in d

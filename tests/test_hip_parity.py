@@ -593,3 +593,86 @@ def test_select_truncate_degenerate_points(dev, oracle):
     px = N(p1)[..., 0]
     bad = ~np.isfinite(px) | (np.abs(px) >= 9.2e18)
     assert (N(sx)[bad] == 0).all() and (N(sy)[~np.isfinite(N(p1)[..., 1]) | (np.abs(N(p1)[..., 1]) >= 9.2e18)] == 0).all()
+
+
+@pytest.mark.parametrize("S,H,W", [(8, 32, 48), (20, 23, 37), (5, 17, 19), (1, 16, 24), (33, 64, 65), (64, 40, 72), (272, 8, 64), (12, 100, 130)])
+def test_overlapped_launch_equals_separate_launches(dev, kernel_exp, S, H, W):
+    """mpf_warp_views_and_blend_next = Stage B of image i and Stage A+C of image i+1 in one heterogeneous grid: every output of both
+    halves bit-identical to mpf_warp_composite_views + mpf_src_blend_flow run one after the other, for P = 0, 1, 2, with and without the
+    fused activation epilogue (cum_mask), both load-pipeline depths; grids where neither workgroup count is a multiple of 8."""
+    from mpiflow_amd import _lib, host_math, ops
+    o = kernel_exp
+    a, b = _inputs(S, H, W, seed=S + 5 * W), _inputs(S, H, W, seed=S + 5 * W + 1, kind="smooth")
+    G_cam, G_dyn = _poses(o, S + H)
+    mk = lambda x: T(x, dev)    # noqa: E731
+    k_inv, d = host_math.k_inverse(a["K"]), host_math.plane_depths(a["disparity"])
+    H_ts, H_st = host_math.homographies_multi([G_cam, G_dyn], k_inv, a["K"], d)
+    wp = [ops.upload_params(ops.warp_params(H_st[i], k_inv, G, d), dev) for i, G in enumerate((G_cam, G_dyn))]
+    # image i: blended stack + quads by the stand-alone kernel
+    rgba_a = ops.alloc_rgba_stack(S, H, W, dev)
+    qa = [torch.empty((H, W, 4), device=dev) for _ in range(2)]
+    ops.src_blend_flow(mk(a["mpi"]), mk(a["image"]), K_inv=k_inv, depth_S=d, homs_tgt_src=H_ts, out_rgba=rgba_a, obj_mask=mk(a["obj_mask"]),
+                       quads=qa[0], quads_complement=qa[1])
+
+    def views():
+        return [dict(dparams=wp[v], quads=qa[v], out=dict(rgb=torch.empty((3, H, W), device=dev), objmask=torch.empty((H, W), device=dev),
+                                                          depth=torch.empty((H, W), device=dev) if v == 0 else None,
+                                                          tgt_mask=torch.empty((H, W), device=dev) if v == 0 else None,
+                                                          rgb_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev))) for v in range(2)]
+    want_v = ops.warp_composite_views(rgba_a, views(), interleaved=2)
+    cum = torch.rand((S, H, W), device=dev)
+    for P in (2, 1, 0):
+        for cm in (None, cum):
+            bf, _ = ops.blend_flow_params(k_inv, d, H_ts[:P] if P else None)
+            dp = ops.upload_params(bf, dev)
+            w_rgba = ops.alloc_rgba_stack(S, H, W, dev)
+            w_fl = torch.empty((P, 2, H, W), device=dev) if P else None
+            w_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+            w_q = [torch.empty((H, W, 4), device=dev) for _ in range(2)]
+            ops.src_blend_flow(mk(b["mpi"]), mk(b["image"]), out_rgba=w_rgba, out_flows=w_fl, dparams=dp, P=P, src_u8=w_u8, obj_mask=mk(b["obj_mask"]),
+                               quads=w_q[0], quads_complement=w_q[1], cum_mask=cm)
+            for depth in (8, 4):
+                _lib.check(_lib.load().mpf_tune(b"ovl_depth", depth))
+                g_rgba = ops.alloc_rgba_stack(S, H, W, dev)
+                g_fl = torch.full((P, 2, H, W), float("nan"), device=dev) if P else None
+                g_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+                g_q = [torch.full((H, W, 4), float("nan"), device=dev) for _ in range(2)]
+                got_v = ops.warp_views_and_blend_next(rgba_a, views(), mk(b["mpi"]), mk(b["image"]), dp, P, g_rgba, out_flows_next=g_fl, src_u8_next=g_u8,
+                                                      obj_mask_next=mk(b["obj_mask"]), quads_next=g_q[0], quads_complement_next=g_q[1], cum_mask_next=cm)
+                tag = (P, cm is not None, depth)
+                for gv, wv in zip(got_v, want_v):
+                    for k in ("rgb", "objmask", "depth", "tgt_mask", "rgb_u8"):
+                        if wv.get(k) is not None:
+                            assert torch.equal(gv[k].view(torch.uint8), wv[k].view(torch.uint8)), (k, tag)
+                assert torch.equal(g_rgba.view(torch.int32), w_rgba.view(torch.int32)), tag
+                assert torch.equal(g_u8, w_u8) and all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(g_q, w_q)), tag
+                if P:
+                    assert torch.equal(g_fl.view(torch.int32), w_fl.view(torch.int32)), tag
+    _lib.check(_lib.load().mpf_tune(b"ovl_depth", 8))
+
+
+@pytest.mark.parametrize("S,H,W,n", [(8, 32, 48, 5), (20, 23, 37, 3), (16, 64, 96, 1)])
+def test_overlapped_pair_renderer_equals_render_pair(dev, kernel_exp, S, H, W, n):
+    """pipeline.OverlappedPairRenderer (the bench's and the batch driver's throughput form: Stage B of pair i beside Stage A+C of pair
+    i+1) returns, for every pair of a stream of n images, exactly what pipeline.render_pair returns - and that is the oracle's answer."""
+    from mpiflow_amd import pipeline
+    o = kernel_exp
+    ovl = pipeline.OverlappedPairRenderer(S, H, W, dev)
+    items, outs = [], []
+    for i in range(n):
+        inp = _inputs(S, H, W, seed=100 + i, kind="white" if i % 2 == 0 else "smooth")
+        G_cam, G_dyn = _poses(o, 50 + i)
+        items.append((inp, G_cam, G_dyn))
+        prep = ovl.prepare(inp["K"], inp["disparity"], [G_cam, G_dyn])
+        out = (torch.empty((H, W, 2), device=dev), torch.empty((H, W, 3), dtype=torch.uint8, device=dev), torch.empty((H, W), dtype=torch.uint8, device=dev))
+        outs.append(out)
+        done = ovl.push(T(inp["mpi"], dev), T(inp["image"], dev), prep, T(inp["obj_mask"], dev), out=out)
+        assert (done is None) == (i == 0)
+        if done is not None:
+            assert done[0] is outs[i - 1][0]
+    last = ovl.flush()
+    assert last[0] is outs[-1][0] and ovl.flush() is None
+    for (inp, G_cam, G_dyn), out in zip(items, outs):
+        ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
+        for k, t in zip(("flow_mix", "frame_mix", "fill_mask"), out):
+            assert bits_equal(N(t), ref[k]) == 0, k

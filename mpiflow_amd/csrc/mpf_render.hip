@@ -9,6 +9,7 @@
 // rows two neighbouring tiles share are found in the same L2, and keeping the whole S-plane recurrence in
 // registers so that no [S,...] intermediate is ever written (the reference materialises ~8 of them per view).
 #include <string.h>
+#include <type_traits>
 #include "mpf_common.h"
 #include "mpf_math.h"
 
@@ -1036,10 +1037,6 @@ MPF_DEV void mpf_sbf_body(const MpfSbfArgs &a, const int S, const int H, const i
         for (int i = 0; i < PX; ++i) {
 #pragma unroll
             for (int c = BLEND ? 0 : 3; c < 4; ++c) {
-#if defined(MPF_OVL_NT_LOAD)
-                if (DEPTH != 2) chs[i][c] = __builtin_nontemporal_load(pl + c * N + n[i]);
-                else
-#endif
                 chs[i][c] = pl[c * N + n[i]];
             }
             if (ACT) {
@@ -1080,17 +1077,8 @@ MPF_DEV void mpf_sbf_body(const MpfSbfArgs &a, const int S, const int H, const i
             if (BLEND && live[i]) {
                 if (out_rgba) {
                     typedef float mpf_v4f __attribute__((ext_vector_type(4)));
-                    mpf_v4f *dst = reinterpret_cast<mpf_v4f *>(out_rgba) + ((int64_t)s * N + n[i]);
                     const mpf_v4f val = { o[0], o[1], o[2], sg };
-#if defined(MPF_OVL_STORE_POLICY)
-                    if (DEPTH != 2) {                      // experiment build: cache policy of the overlapped role's stack stores
-                        if (MPF_OVL_STORE_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
-                        else if (MPF_OVL_STORE_POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(val) : "memory");
-                        else if (MPF_OVL_STORE_POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst), "v"(val) : "memory");
-                        else if (MPF_OVL_STORE_POLICY == 0) *dst = val;
-                        else __builtin_nontemporal_store(val, dst);
-                    } else
-#endif
+                    mpf_v4f *dst = reinterpret_cast<mpf_v4f *>(out_rgba) + ((int64_t)s * N + n[i]);
                     if (NT_STORE) __builtin_nontemporal_store(val, dst);
                     else *dst = val;
                 }
@@ -1216,6 +1204,170 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
 #undef MPF_SBF
 }
 
+// Stage A+C as the overlapped launch runs it (k_pair_overlap): the arithmetic of mpf_sbf_body<.., BLEND = true> - same IEEE operation
+// sequence per plane and pixel, bit-identical outputs (tests/test_hip_parity.py) - restated for a role that gets ~1 workgroup per CU
+// inside Stage B's register budget:
+//   * only what the pipeline needs: the interleaved blended stack, P flows, the per-pixel by-products; no planar / tacc outputs, so
+//     no pointer tests in the plane loop, and the last plane (thickness 1e3) is peeled off instead of tested for
+//   * buffer addressing: descriptor in SGPRs, plane / channel as the instruction's scalar offset, the pixel as a loop-invariant
+//     VGPR offset - no 64-bit VALU adds, no per-channel plane pointers; a dead lane's store offset is out of range, which the
+//     hardware drops: no exec-mask branch around the stores either.  Needs 16*S*N < 4 GiB (checked by the launcher).
+//   * DEPTH planes of loads in flight per wave (ring of register sets, loop unrolled DEPTH times)
+template <int PX, int P, int NL, bool ACT, int DEPTH>
+MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const int W, const int64_t t)
+{
+    const MpfConstParams params = (MpfConstParams)a.params;
+    const int64_t N = (int64_t)H * W;
+    if (t >= a.T) return;
+    constexpr int NP = (P > 0) ? P : 1;
+    constexpr int RS = MPF_PLANE_RECORD * NP;
+    typedef float mpf_v4f __attribute__((ext_vector_type(4)));
+
+    int64_t n[PX];
+    bool live[PX];
+    unsigned voff[PX], vout[PX];
+    float fx[PX], fy[PX], ray[PX][3], im[PX][3], cur[PX][3];
+    double acc[PX];
+    MpfCsum<NL> cf[PX][NP][2];
+    const float d0 = params[MPF_PARAMS_HEADER + 9];
+    const unsigned plane_bytes = (unsigned)N * 4u;
+    const __amdgpu_buffer_rsrc_t rs_mpi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mpi), 0, (unsigned)S * 4u * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ACT ? a.cum_mask : a.mpi), 0, (unsigned)S * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out_rgba, 0, (unsigned)S * 4u * plane_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int64_t ni = t + (int64_t)i * a.T;
+        live[i] = ni < N;
+        n[i] = live[i] ? ni : (N - 1);
+        voff[i] = (unsigned)n[i] * 4u;
+        vout[i] = live[i] ? (unsigned)n[i] * 16u : 0xFFFFFFF0u;                      // out of range: the store is dropped
+        fx[i] = (float)(n[i] % W);
+        fy[i] = (float)(n[i] / W);
+        ray[i][0] = mpf_row3_xy1(params[0], params[1], params[2], fx[i], fy[i]);      // mpi_rendering.py:234
+        ray[i][1] = mpf_row3_xy1(params[3], params[4], params[5], fx[i], fy[i]);
+        ray[i][2] = mpf_row3_xy1(params[6], params[7], params[8], fx[i], fy[i]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            im[i][c] = a.img[c * N + n[i]];
+            cur[i][c] = ray[i][c] * d0;                                               // :235-236
+        }
+        acc[i] = 1.0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { cf[i][p][0].init(); cf[i][p][1].init(); }
+        if (live[i] && a.src_u8) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.src_u8[3 * n[i] + c] = mpf_to_u8(im[i][2 - c]);          // utils/utils.py:174-177
+        }
+        if (live[i] && a.obj_mask) {
+            const int x = (int)(n[i] % W), y = (int)(n[i] / W);
+            const bool e = (x + 1) < W, so = (y + 1) < H;
+            const float a0 = a.obj_mask[n[i]];
+            const float b = e ? a.obj_mask[n[i] + 1] : 0.0f;
+            const float c2 = so ? a.obj_mask[n[i] + W] : 0.0f;
+            const float d2 = (e && so) ? a.obj_mask[n[i] + W + 1] : 0.0f;
+            if (a.quads) a.quads[n[i]] = make_float4(a0, b, c2, d2);
+            if (a.quads_c) a.quads_c[n[i]] = make_float4(1.0f - a0, e ? 1.0f - b : 0.0f, so ? 1.0f - c2 : 0.0f, (e && so) ? 1.0f - d2 : 0.0f);
+        }
+    }
+
+    float ch[DEPTH][PX][4];
+    auto load_plane = [&](int s, float (&chs)[PX][4]) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                chs[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_mpi, voff[i], (unsigned)(s * 4 + c) * plane_bytes, 0));
+            if (ACT) {                                                                // model/CPN/decoder.py:166-173
+                const float cm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_cm, voff[i], (unsigned)s * plane_bytes, 0));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) chs[i][c] = 1.0f / (1.0f + mpf_expf_fast(-chs[i][c]));
+                chs[i][3] = fmaxf(chs[i][3] * cm, 0.0f) + 1e-4f;
+            }
+        }
+    };
+    auto do_plane = [&](int s, const float (&chs)[PX][4], auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const MpfConstParams rec = params + MPF_PARAMS_HEADER + RS * s;
+        const float dn = LAST ? 0.0f : rec[RS + 9];
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            float dist = 1e3f;                                                        // mpi_rendering.py:73-78
+            if (!LAST) {
+                const float nx = ray[i][0] * dn, ny = ray[i][1] * dn, nz = ray[i][2] * dn;
+                dist = mpf_norm3_nr(nx - cur[i][0], ny - cur[i][1], nz - cur[i][2]);
+                cur[i][0] = nx; cur[i][1] = ny; cur[i][2] = nz;
+            }
+            const float sg = chs[i][3];
+            const float Tr = mpf_expf_fast(-sg * dist);
+            const float alpha = 1.0f - Tr;
+            const float tacc = (float)acc[i];
+            const float w = tacc * alpha;
+            acc[i] *= (double)(Tr + 1e-6f);
+            const float one_m = 1.0f - tacc;
+            float o[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float av = tacc * im[i][c];              // blend_weights * src_imgs          utils/utils.py:202-204
+                const float bb = one_m * chs[i][c];            // (1 - blend_weights) * mpi_rgb
+                o[c] = av + bb;
+            }
+            const mpf_v4f val = { o[0], o[1], o[2], sg };
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mpf_v4u, val), rs_out, vout[i], (unsigned)s * 4u * plane_bytes, 2 /* nt */);
+            if (P > 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const MpfConstParams h = rec + MPF_PLANE_RECORD * p;
+                    const float qx = mpf_row3_xy1(h[0], h[1], h[2], fx[i], fy[i]);
+                    const float qy = mpf_row3_xy1(h[3], h[4], h[5], fx[i], fy[i]);
+                    const float qz = mpf_row3_xy1(h[6], h[7], h[8], fx[i], fy[i]);
+                    const float rz = mpf_rcp_nr(qz);
+                    cf[i][p][0].push(w * (mpf_div_nr(qx, qz, rz) - fx[i]));
+                    cf[i][p][1].push(w * (mpf_div_nr(qy, qz, rz) - fy[i]));
+                }
+            }
+        }
+        if (P > 0 && ((s + 1) & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < PX; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { cf[i][p][0].fold(s + 1); cf[i][p][1].fold(s + 1); }
+        }
+    };
+    typedef std::integral_constant<bool, true> Yes;
+    typedef std::integral_constant<bool, false> No;
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1; ++k)
+        if (k < S) load_plane(k, ch[k]);
+    int s = 0;
+    for (; s + 2 * DEPTH - 2 < S; s += DEPTH) {                         // steady state: branch-free; none of these planes is the last
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            load_plane(s + k + DEPTH - 1, ch[(k + DEPTH - 1) % DEPTH]);
+            do_plane(s + k, ch[k], No());
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * DEPTH - 2; ++k) {                           // the last < 2 DEPTH - 2 planes (uniform branches)
+        if (s + k < S) {
+            if (s + k + DEPTH - 1 < S) load_plane(s + k + DEPTH - 1, ch[(k + DEPTH - 1) % DEPTH]);
+            if (s + k + 1 == S) do_plane(s + k, ch[k % DEPTH], Yes());
+            else do_plane(s + k, ch[k % DEPTH], No());
+        }
+    }
+    if (P > 0) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float f = cf[i][p][k].final();
+                    if (a.flow_clip > 0.0f) f = fminf(fmaxf(f, -a.flow_clip), a.flow_clip);   // utils/utils.py:348
+                    if (live[i]) a.flows[((int64_t)p * 2 + k) * N + n[i]] = f;
+                }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Stage B of image i  ||  Stage A+C of image i+1, in ONE launch (the reference's unit of work, utils/utils.py:190-236, is one
 // source-frame pass plus two target-frame passes; back to back they are an HBM-bound kernel followed by a VALU-issue-bound one).
@@ -1231,6 +1383,9 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
 //   * Stage A+C gets only ~1 workgroup per CU, so each wave carries DEPTH (4-8) planes of loads in flight instead of 2, one pixel
 //     per thread (46-62 VGPRs, inside Stage B's 96).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef MPF_OVL_PX
+#define MPF_OVL_PX 1            // pixels per thread of the overlapped Stage A+C role
+#endif
 template <bool HAS_MASK, int NL, int P, bool ACT, int DEPTH>
 __global__ void __launch_bounds__(256, 5)
 k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsigned V, const MpfSbfArgs ac, const int S, const int H, const int W,
@@ -1246,7 +1401,7 @@ k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsi
         if (((ablate >> 2) & 3) == 1) __builtin_amdgcn_s_setprio(1);      // bits 2-3: wave priority of the A+C role (tuning experiment)
         else if (((ablate >> 2) & 3) == 2) __builtin_amdgcn_s_setprio(2);
         else if (((ablate >> 2) & 3) == 3) __builtin_amdgcn_s_setprio(3);
-        mpf_sbf_body<1, P, NL, ACT, true, true, DEPTH>(ac, S, H, W, (int64_t)ja * 256 + threadIdx.x);
+        mpf_sbf_stream<MPF_OVL_PX, P, NL, ACT, DEPTH>(ac, S, H, W, (int64_t)ja * 256 + threadIdx.x);
     } else {
         const unsigned jb = (k - a0) * 8u + xcd;
         if (jb >= nB || (ablate & 3) == 2) return;
@@ -1261,7 +1416,7 @@ k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsi
     }
 }
 
-static int g_ovl_depth = 8;     // mpf_tune("ovl_depth", 4 | 8)
+static int g_ovl_depth = 4;     // mpf_tune("ovl_depth", 4 | 8): 4 measured best (490 vs 499 us per launch at 64x640x960)
 static int g_ovl_ablate = 0;    // mpf_tune("ovl_ablate", 0 | 1 | 2): bench-only, results invalid when non-zero
 
 template <bool HAS_MASK, int NL, int P, bool ACT>
@@ -1269,7 +1424,7 @@ static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V,
 {
     const unsigned tiles = ((W + 31) / 32) * ((H + 7) / 8);
     const unsigned nB = tiles * V;
-    const unsigned nA = (unsigned)((ac.T + 255) / 256);
+    const unsigned nA = (unsigned)((ac.T + 255) / 256);              // ac.T = threads of the A+C role (N / MPF_OVL_PX, rounded up)
     const unsigned KB = (nB + 7) / 8, KA = (nA + 7) / 8;
     dim3 grid(8u * (KB + KA)), block(256);
     if (g_ovl_depth == 4)
@@ -1290,6 +1445,7 @@ extern "C" int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpV
     MPF_REQUIRE(n_views >= 1 && n_views <= MPF_MAX_VIEWS, "mpf_warp_views_and_blend_next: n_views must be 1..%d (got %d)", MPF_MAX_VIEWS, n_views);
     MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_warp_views_and_blend_next: bad shape S=%d H=%d W=%d", S, H, W);
     MPF_REQUIRE((int64_t)H * W < ((int64_t)1 << 27), "mpf_warp_views_and_blend_next: H*W too large for 32-bit byte offsets");
+    MPF_REQUIRE((int64_t)S * H * W * 16 < ((int64_t)1 << 32), "mpf_warp_views_and_blend_next: the plane stack must be smaller than 4 GiB (buffer addressing); use the two separate calls");
     MPF_REQUIRE(mpf_aligned16(d_rgba) && mpf_aligned16(d_out_rgba_next), "mpf_warp_views_and_blend_next: the stacks must be 16-byte aligned");
     MPF_REQUIRE(P >= 0 && P <= 2 && (P == 0) == (d_flows_next == nullptr), "mpf_warp_views_and_blend_next: P must be 0..2, flows output iff P > 0");
     MPF_REQUIRE((d_quads_next == nullptr && d_quads_complement_next == nullptr) || d_obj_mask_next, "mpf_warp_views_and_blend_next: quads need d_obj_mask_next");
@@ -1306,7 +1462,7 @@ extern "C" int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpV
         vs.v[v] = w;
     }
     const int64_t N = (int64_t)H * W;
-    const MpfSbfArgs ac = { d_mpi_next, d_img_next, d_params_next, flow_clip, d_out_rgba_next, nullptr, nullptr, d_flows_next, N, d_src_u8_bgr_next,
+    const MpfSbfArgs ac = { d_mpi_next, d_img_next, d_params_next, flow_clip, d_out_rgba_next, nullptr, nullptr, d_flows_next, (N + MPF_OVL_PX - 1) / MPF_OVL_PX, d_src_u8_bgr_next,
                             (d_quads_next || d_quads_complement_next) ? d_obj_mask_next : nullptr, reinterpret_cast<float4 *>(d_quads_next),
                             reinterpret_cast<float4 *>(d_quads_complement_next), d_cum_mask_next };
     hipStream_t st = (hipStream_t)stream;
@@ -1327,7 +1483,7 @@ extern "C" int mpf_tune(const char *key, int value)
 {
     if (key && !strcmp(key, "sbf_px")) { g_sbf_px = value; return 0; }
     if (key && !strcmp(key, "stage_b")) { g_stage_b_variant = value; return 0; }
-    if (key && !strcmp(key, "ovl_depth")) { g_ovl_depth = (value == 4) ? 4 : 8; return 0; }
+    if (key && !strcmp(key, "ovl_depth")) { g_ovl_depth = (value == 8) ? 8 : 4; return 0; }
     if (key && !strcmp(key, "ovl_ablate")) { g_ovl_ablate = value; return 0; }
     if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
     mpf_set_error("mpf_tune: unknown key");

@@ -648,7 +648,7 @@ def test_overlapped_launch_equals_separate_launches(dev, kernel_exp, S, H, W):
                 assert torch.equal(g_u8, w_u8) and all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(g_q, w_q)), tag
                 if P:
                     assert torch.equal(g_fl.view(torch.int32), w_fl.view(torch.int32)), tag
-    _lib.check(_lib.load().mpf_tune(b"ovl_depth", 8))
+    _lib.check(_lib.load().mpf_tune(b"ovl_depth", 4))
 
 
 @pytest.mark.parametrize("S,H,W,n", [(8, 32, 48, 5), (20, 23, 37, 3), (16, 64, 96, 1)])

@@ -96,6 +96,21 @@ int mpf_warp_composite(const float *d_rgba, int interleaved, const float *d_mask
                        int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask, float *d_tgt_mask,
                        uint8_t *d_rgb_u8_bgr, void *stream);
 
+/* Stage B on the stack as render_novel_view_dynamic receives it (utils/utils.py:291-349: mpi_all_rgb_src [1,S,3,H,W] and
+ * mpi_all_sigma_src [1,S,1,H,W], two separate channel-planar tensors): the body of mpf_warp_composite reading the three colour planes
+ * and the sigma plane where they lie - a tap pair of one channel row is one 8-byte load - so the caller assembles nothing (the
+ * reference concatenates 8 channels per plane, utils/mpi/mpi_rendering.py:288-301).  Outputs as mpf_warp_composite; bit-identical to it.
+ * mpf_warp_composite(interleaved = 0) runs the same kernel on one [S,4,H,W] tensor. */
+int mpf_warp_composite_split(const float *d_rgb_S3HW, const float *d_sigma_SHW, const float *d_mask_quads, const float *d_params,
+                             int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask, float *d_tgt_mask,
+                             uint8_t *d_rgb_u8_bgr, void *stream);
+
+/* Stage C alone on a bare sigma tensor [S,H,W]: the volume-rendered flows of P = 1 or 2 poses (HomographySample.sample_inverse,
+ * utils/mpi/homography_sampler.py:160-220, + plane_volume_rendering_flow, utils/mpi/mpi_rendering.py:102-139) - what
+ * render_novel_view_dynamic needs besides the warp (utils/utils.py:340-348).  d_params as for mpf_src_blend_flow (S*P records);
+ * d_flows [P,2,H,W], clipped to +-flow_clip when flow_clip > 0.  Same arithmetic as mpf_src_blend_flow's flows: bit-identical. */
+int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int P, int S, int H, int W, float flow_clip, float *d_flows, void *stream);
+
 /* Stage B for SEVERAL views of one stack in one launch.  The reference renders two poses of every stack
  * (utils/utils.py:210-222 with obj_mask / cam_ext and :224-236 with 1 - obj_mask / cam_ext_dynamic) and `repeat` such
  * pairs per image (gen_3dphoto_dynamic_v2.py:99-118); launched together, the views' workgroups walk the planes side by

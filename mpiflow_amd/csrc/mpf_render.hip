@@ -251,13 +251,18 @@ MPF_DEV float mpf_geom_core(const ParamPtr params, int s, const MpfConsts &c, fl
     return valid;
 }
 
-template <bool KS, bool TP, bool WANT_VALID = true>
+template <bool KS, bool TP, bool WANT_VALID = true, bool PLANAR = false>
 MPF_DEV float mpf_geom(const MpfConstParams params, int s, const MpfConsts &c, MpfGeom &g)
 {
     int x0, y0;
     float qz;
     const float valid = mpf_geom_core<KS, WANT_VALID>(params, s, c, g.nw, g.ne, g.sw, g.se, g.X, g.Y, g.Z, x0, y0, qz);
     const unsigned o00 = __umul24((unsigned)y0, (unsigned)c.W) + (unsigned)x0;   // H*W < 2^27, W < 2^24
+    if (PLANAR) {                        // [S,4,H,W] stack: b00 = byte offset inside one fp32 channel plane, b01 = inside the [H,W,4] mask quads
+        g.b00 = o00 * 4u;
+        g.b01 = o00 * 16u;
+        return valid;
+    }
     g.b00 = o00 * 16u;
     if (TP) {
         g.b01 = g.b00 + 16u;
@@ -301,6 +306,42 @@ MPF_DEV void mpf_fetch2(const char *__restrict__ plane, const char *__restrict__
         r.t11 = *reinterpret_cast<const float4 *>(plane + g.b11);
         if (HAS_MASK) r.mq = *reinterpret_cast<const float4 *>(quads + g.b00);
     }
+}
+
+// Channel-planar stack [S,4,H,W] - the reference's own tensor layout, what render_tgt_rgb_depth /
+// render_novel_view_dynamic callers hand over.  A tap pair (x0, x0+1) of one channel row is ONE 8-byte load, so a plane costs 8
+// buffer_load_dwordx2 (4 channels x north / south row) on a single VGPR offset: the channel and the south row go into the instruction's
+// scalar offset.  The descriptor ends exactly where the tensor ends, so the east / south neighbour of the very last texel reads as 0
+// instead of faulting; inside the tensor an out-of-image neighbour is some finite texel of the next row / channel, and its weight is
+// exactly 0 (x0+1 == W only when the clamped coordinate is exactly W-1) - the same argument as for the tail-padded interleaved stack.
+typedef unsigned mpf_v2u __attribute__((ext_vector_type(2)));
+struct MpfPlanarSrc {                 // where plane s of a channel-planar stack lives: rgb = 3 channel planes, sigma = 1
+    const char *rgb, *sigma;          // [S,4,H,W]: sigma = rgb + 12 N, both strides 16 N;  rgb [S,3,H,W] + sigma [S,1,H,W]: strides 12 N / 4 N
+    size_t rgb_stride, sigma_stride;  // bytes between planes
+    unsigned rgb_last, sigma_last;    // bytes from the LAST plane's start to the end of the respective tensor: its descriptor limit (reads past
+                                      // it return 0); the east / south spill of an earlier plane lands in the next plane, i.e. in valid memory
+};
+template <bool HAS_MASK>
+MPF_DEV void mpf_fetch_planar(const MpfPlanarSrc &src, const int sp, const bool last, const char *__restrict__ quads, const unsigned quad_span,
+                              const MpfGeom &g, MpfRaw4 &r, const unsigned chan_bytes, const unsigned row_bytes)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src.rgb + (size_t)sp * src.rgb_stride), 0,
+                                                                   last ? src.rgb_last : 0xFFFFFFFCu, 0x00020000);
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src.sigma + (size_t)sp * src.sigma_stride), 0,
+                                                                   last ? src.sigma_last : 0xFFFFFFFCu, 0x00020000);
+    const mpf_v2u n0 = __builtin_amdgcn_raw_buffer_load_b64(rs, g.b00, 0, 0), s0 = __builtin_amdgcn_raw_buffer_load_b64(rs, g.b00, row_bytes, 0);
+    const mpf_v2u n1 = __builtin_amdgcn_raw_buffer_load_b64(rs, g.b00, chan_bytes, 0), s1 = __builtin_amdgcn_raw_buffer_load_b64(rs, g.b00, chan_bytes + row_bytes, 0);
+    const mpf_v2u n2 = __builtin_amdgcn_raw_buffer_load_b64(rs, g.b00, 2u * chan_bytes, 0), s2 = __builtin_amdgcn_raw_buffer_load_b64(rs, g.b00, 2u * chan_bytes + row_bytes, 0);
+    const mpf_v2u n3 = __builtin_amdgcn_raw_buffer_load_b64(rg, g.b00, 0, 0), s3 = __builtin_amdgcn_raw_buffer_load_b64(rg, g.b00, row_bytes, 0);
+    if (HAS_MASK) {
+        __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(quads), 0, quad_span, 0x00020000);
+        r.mq = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rq, g.b01, 0, 0));
+    }
+    auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
+    r.t00 = make_float4(f(n0.x), f(n1.x), f(n2.x), f(n3.x));
+    r.t01 = make_float4(f(n0.y), f(n1.y), f(n2.y), f(n3.y));
+    r.t10 = make_float4(f(s0.x), f(s1.x), f(s2.x), f(s3.x));
+    r.t11 = make_float4(f(s0.y), f(s1.y), f(s2.y), f(s3.y));
 }
 
 template <class Geom>
@@ -350,11 +391,11 @@ struct MpfAcc {
 
 // DBG (bench-only ablations, results are NOT valid): 1 = no gathers (taps synthesised from the geometry), 2 = gathers and
 // bilinear sums only (geometry of plane 0 reused for every plane, no distance / exp / composite)
-template <bool HAS_MASK, int NL, int TW, int TH, bool KS, bool TP, int DBG = 0, bool AUX = true>
+template <bool HAS_MASK, int NL, int TW, int TH, bool KS, bool TP, int DBG = 0, bool AUX = true, bool PLANAR = false>
 MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params_global,
                           int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
                           float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out,
-                          const unsigned tile)
+                          const unsigned tile, const MpfPlanarSrc *planar_src = nullptr)
 {
     const MpfConstParams params = (MpfConstParams)params_global;
     const int64_t N = (int64_t)H * W;
@@ -378,7 +419,7 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
     A.init();
     MpfGeom ga, gb;
     MpfRaw4 ra, rb;
-    A.nvalid += mpf_geom<KS, TP, AUX>(params, 0, c, ga);
+    A.nvalid += mpf_geom<KS, TP, AUX, PLANAR>(params, 0, c, ga);
     if (DBG == 1) {
         for (int s = 0; s < S; ++s) {
             A.nvalid += mpf_geom<KS, TP, AUX>(params, min(s + 1, S - 1), c, gb);
@@ -426,21 +467,30 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
         }
         A.c0.a[0] = acc4;
     } else {
-    mpf_fetch2<HAS_MASK, TP>(pbase, qbase, ga, ra, c.row_bytes, span);
+    // PLANAR: the stack is channel-planar as the reference holds it (planar_src says where: one [S,4,H,W] tensor, or rgb + sigma tensors)
+    const unsigned chan_bytes = (unsigned)N * 4u, row4 = (unsigned)W * 4u, quad_span = (unsigned)N * 16u;
+    auto FETCH = [&](int sp, const MpfGeom &g, MpfRaw4 &r) {
+        if (PLANAR) {
+            mpf_fetch_planar<HAS_MASK>(*planar_src, sp, sp + 1 == S, qbase, quad_span, g, r, chan_bytes, row4);
+        } else {
+            mpf_fetch2<HAS_MASK, TP>(pbase + (size_t)sp * plane_bytes, qbase, g, r, c.row_bytes, span);
+        }
+    };
+    FETCH(0, ga, ra);
 
     int s = 0;
     while (s + 2 < S) {
-        A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 1, c, gb);
-        mpf_fetch2<HAS_MASK, TP>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb, c.row_bytes, span);
+        A.nvalid += mpf_geom<KS, TP, AUX, PLANAR>(params, s + 1, c, gb);
+        FETCH(s + 1, gb, rb);
         A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
-        A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 2, c, ga);
-        mpf_fetch2<HAS_MASK, TP>(pbase + (size_t)(s + 2) * plane_bytes, qbase, ga, ra, c.row_bytes, span);
+        A.nvalid += mpf_geom<KS, TP, AUX, PLANAR>(params, s + 2, c, ga);
+        FETCH(s + 2, ga, ra);
         A.step(gb, rb, mpf_norm3_nr(ga.X - gb.X, ga.Y - gb.Y, ga.Z - gb.Z), s + 1);
         s += 2;
     }
     if (s + 1 < S) {
-        A.nvalid += mpf_geom<KS, TP, AUX>(params, s + 1, c, gb);
-        mpf_fetch2<HAS_MASK, TP>(pbase + (size_t)(s + 1) * plane_bytes, qbase, gb, rb, c.row_bytes, span);
+        A.nvalid += mpf_geom<KS, TP, AUX, PLANAR>(params, s + 1, c, gb);
+        FETCH(s + 1, gb, rb);
         A.step(ga, ra, mpf_norm3_nr(gb.X - ga.X, gb.Y - ga.Y, gb.Z - ga.Z), s);
         A.step(gb, rb, 1e3f, s + 1);
     } else {
@@ -504,6 +554,28 @@ MPF_DEV void mpf_wc2_select(const float *__restrict__ rgba, const float *__restr
         mpf_wc2_body<HAS_MASK, NL, TW, TH, true, TP, 0, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile);
     else
         mpf_wc2_body<HAS_MASK, NL, TW, TH, false, TP, 0, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile);
+}
+
+// the same body on the reference's own channel-planar [S,4,H,W] stack (mpf_warp_composite(interleaved = 0): what a caller of
+// render_tgt_rgb_depth / render_novel_view_dynamic, utils/mpi/mpi_rendering.py:259-349, hands over) - same tile shape, order and occupancy
+template <bool HAS_MASK, int NL>
+__global__ void __launch_bounds__(256, 5)
+k_warp_composite_planar(const MpfPlanarSrc src, const float *__restrict__ quads, const float *__restrict__ params,
+                        int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                        float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
+{
+    constexpr int TW = 32, TH = 8;
+    const unsigned tile = mpf_strip_order(mpf_xcd_remap(blockIdx.x, gridDim.x), (W + TW - 1) / TW, (H + TH - 1) / TH);
+    const MpfConstParams cp = (MpfConstParams)params;
+    const bool pinhole = (cp[1] == 0.0f) & (cp[3] == 0.0f) & (cp[6] == 0.0f) & (cp[7] == 0.0f) & (cp[8] == 1.0f);
+    const bool aux = (depth_out != nullptr) | (tgt_mask_out != nullptr);
+    const float *rgba = reinterpret_cast<const float *>(src.rgb);
+    if (pinhole && !aux)
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, false, 0, false, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, &src);
+    else if (pinhole)
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, true, false, 0, true, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, &src);
+    else
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, false, false, 0, true, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, &src);
 }
 
 template <bool HAS_MASK, int NL, int TW, int TH, int WPS, bool TP>
@@ -823,6 +895,31 @@ static int launch_warp_composite(const float *rgba, const float *quads, const fl
     return mpf_launch_status("k_warp_composite");
 }
 
+static int launch_planar(const MpfPlanarSrc &src, const float *quads, const float *params, int S, int H, int W, float *rgb, float *depth, float *om,
+                         float *tm, uint8_t *u8, hipStream_t st)
+{
+    const unsigned tiles = ((W + 31) / 32) * ((H + 7) / 8);
+#define MPF_WCP(HM, NLv) hipLaunchKernelGGL((k_warp_composite_planar<HM, NLv>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8)
+    if (S < 256) { if (quads) MPF_WCP(true, 2); else MPF_WCP(false, 2); }
+    else         { if (quads) MPF_WCP(true, 3); else MPF_WCP(false, 3); }
+#undef MPF_WCP
+    return mpf_launch_status("k_warp_composite_planar");
+}
+
+extern "C" int mpf_warp_composite_split(const float *d_rgb_S3HW, const float *d_sigma_SHW, const float *d_mask_quads, const float *d_params,
+                                        int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask, float *d_tgt_mask,
+                                        uint8_t *d_rgb_u8_bgr, void *stream)
+{
+    MPF_REQUIRE(d_rgb_S3HW && d_sigma_SHW && d_params && d_rgb, "mpf_warp_composite_split: null pointer");
+    MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_warp_composite_split: bad shape S=%d H=%d W=%d", S, H, W);
+    MPF_REQUIRE((int64_t)H * W < ((int64_t)1 << 27), "mpf_warp_composite_split: H*W too large for 32-bit byte offsets");
+    MPF_REQUIRE((d_mask_quads == nullptr) == (d_objmask == nullptr), "mpf_warp_composite_split: mask quads and objmask output go together");
+    MPF_REQUIRE(!d_mask_quads || mpf_aligned16(d_mask_quads), "mpf_warp_composite_split: mask quads must be 16-byte aligned");
+    const size_t N4 = (size_t)H * W * 4;
+    const MpfPlanarSrc src = { reinterpret_cast<const char *>(d_rgb_S3HW), reinterpret_cast<const char *>(d_sigma_SHW), 3 * N4, N4, (unsigned)(3 * N4), (unsigned)N4 };
+    return launch_planar(src, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, (hipStream_t)stream);
+}
+
 extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const float *d_mask_quads, const float *d_params,
                                   int S, int H, int W, float *d_rgb, float *d_depth, float *d_objmask,
                                   float *d_tgt_mask, uint8_t *d_rgb_u8_bgr, void *stream)
@@ -849,6 +946,12 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
     if (interleaved) {
         if (d_mask_quads) return launch_warp_composite<true, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
         return launch_warp_composite<true, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, d_rgb_u8_bgr, st);
+    }
+    if (g_stage_b_variant > 0 && (int64_t)H * W < ((int64_t)1 << 27)) {       // planar stack, fast body
+        const size_t N4 = (size_t)H * W * 4;
+        const char *base = reinterpret_cast<const char *>(d_rgba);
+        const MpfPlanarSrc src = { base, base + 3 * N4, 4 * N4, 4 * N4, (unsigned)(4 * N4), (unsigned)N4 };
+        return launch_planar(src, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
     }
     if (d_mask_quads) return launch_warp_composite<false, true>(d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
     return launch_warp_composite<false, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, d_rgb_u8_bgr, st);
@@ -960,6 +1063,8 @@ struct MpfSbfArgs {
     const float *obj_mask;
     float4 *quads, *quads_c;
     const float *cum_mask;
+    int64_t plane_stride, sigma_off;   // floats: plane s starts at mpi + s * plane_stride, its sigma channel sigma_off further
+                                       // ([S,4,H,W]: 4 N and 3 N; a bare sigma tensor [S,H,W] for the flow-only pass: N and 0)
 };
 
 template <int PX, int P, int NL, bool ACT, bool BLEND, bool NT_STORE, int DEPTH>
@@ -1004,7 +1109,7 @@ MPF_DEV void mpf_sbf_body(const MpfSbfArgs &a, const int S, const int H, const i
         ray[i][2] = mpf_row3_xy1(params[6], params[7], params[8], fx[i], fy[i]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            im[i][c] = img[c * N + n[i]];
+            im[i][c] = img ? img[c * N + n[i]] : 0.0f;                                // no image: the flow-only pass on a bare sigma tensor
             cur[i][c] = ray[i][c] * d0;                                               // :235-236
         }
         acc[i] = 1.0;
@@ -1032,13 +1137,14 @@ MPF_DEV void mpf_sbf_body(const MpfSbfArgs &a, const int S, const int H, const i
     // sets, the loop unrolled DEPTH times) - the kernel is pure streaming and latency x bandwidth decides.
     float ch[DEPTH][PX][4];
     auto load_plane = [&](int s, float (&chs)[PX][4]) {
-        const float *pl = mpi + (int64_t)s * 4 * N;
+        const float *pl = mpi + (int64_t)s * a.plane_stride;
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
+            if (BLEND) {
 #pragma unroll
-            for (int c = BLEND ? 0 : 3; c < 4; ++c) {
-                chs[i][c] = pl[c * N + n[i]];
+                for (int c = 0; c < 3; ++c) chs[i][c] = pl[c * N + n[i]];
             }
+            chs[i][3] = pl[a.sigma_off + n[i]];
             if (ACT) {
                 const float cm = cum_mask[(int64_t)s * N + n[i]];
                 if (BLEND) {
@@ -1146,23 +1252,24 @@ k_src_blend_flow(const float *__restrict__ mpi, const float *__restrict__ img, c
                  int H, int W, float flow_clip, float *__restrict__ out_rgba, float *__restrict__ out_planar,
                  float *__restrict__ out_tacc, float *__restrict__ flows, int64_t T, uint8_t *__restrict__ src_u8,
                  const float *__restrict__ obj_mask, float4 *__restrict__ quads, float4 *__restrict__ quads_c,
-                 const float *__restrict__ cum_mask)
+                 const float *__restrict__ cum_mask, int64_t plane_stride, int64_t sigma_off)
 {
-    const MpfSbfArgs a = { mpi, img, params, flow_clip, out_rgba, out_planar, out_tacc, flows, T, src_u8, obj_mask, quads, quads_c, cum_mask };
+    const MpfSbfArgs a = { mpi, img, params, flow_clip, out_rgba, out_planar, out_tacc, flows, T, src_u8, obj_mask, quads, quads_c, cum_mask, plane_stride, sigma_off };
     mpf_sbf_body<PX, P, NL, ACT, BLEND, NT_STORE, 2>(a, S, H, W, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 template <int PX, int P>
 static int launch_sbf(const float *mpi, const float *img, const float *params, int S, int H, int W, float clip,
                       float *rgba, float *planar, float *tacc, float *flows, uint8_t *src_u8, const float *om, float *q0, float *q1,
-                      const float *cum_mask, hipStream_t st)
+                      const float *cum_mask, hipStream_t st, int64_t plane_stride = 0, int64_t sigma_off = 0)
 {
     const int64_t N = (int64_t)H * W;
     const int64_t T = (N + PX - 1) / PX;
+    if (plane_stride == 0) { plane_stride = 4 * N; sigma_off = 3 * N; }          // the [S,4,H,W] stack
     dim3 grid((unsigned)((T + 255) / 256)), block(256);
     const bool blend = rgba || planar || tacc;
 #define MPF_SBF_GO(NLv, ACTv, BLv) hipLaunchKernelGGL((k_src_blend_flow<PX, P, NLv, ACTv, BLv>), grid, block, 0, st, mpi, img, params, S, H, W, clip, rgba, \
-                                              planar, tacc, flows, T, src_u8, om, reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1), cum_mask)
+                                              planar, tacc, flows, T, src_u8, om, reinterpret_cast<float4 *>(q0), reinterpret_cast<float4 *>(q1), cum_mask, plane_stride, sigma_off)
 #define MPF_SBF_NL(NLv)                                                                              \
     if (cum_mask) { if (blend) MPF_SBF_GO(NLv, true, true); else MPF_SBF_GO(NLv, true, false); }    \
     else          { if (blend) MPF_SBF_GO(NLv, false, true); else MPF_SBF_GO(NLv, false, false); }
@@ -1464,7 +1571,7 @@ extern "C" int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpV
     const int64_t N = (int64_t)H * W;
     const MpfSbfArgs ac = { d_mpi_next, d_img_next, d_params_next, flow_clip, d_out_rgba_next, nullptr, nullptr, d_flows_next, (N + MPF_OVL_PX - 1) / MPF_OVL_PX, d_src_u8_bgr_next,
                             (d_quads_next || d_quads_complement_next) ? d_obj_mask_next : nullptr, reinterpret_cast<float4 *>(d_quads_next),
-                            reinterpret_cast<float4 *>(d_quads_complement_next), d_cum_mask_next };
+                            reinterpret_cast<float4 *>(d_quads_complement_next), d_cum_mask_next, 4 * N, 3 * N };
     hipStream_t st = (hipStream_t)stream;
 #define MPF_OVL(HM, NLv)                                                                                                        \
     switch (P) {                                                                                                                \
@@ -1475,6 +1582,18 @@ extern "C" int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpV
     if (S < 256) { if (has_mask) { MPF_OVL(true, 2) } else { MPF_OVL(false, 2) } }
     else         { if (has_mask) { MPF_OVL(true, 3) } else { MPF_OVL(false, 3) } }
 #undef MPF_OVL
+}
+
+extern "C" int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int P, int S, int H, int W, float flow_clip, float *d_flows, void *stream)
+{
+    MPF_REQUIRE(d_sigma_SHW && d_params && d_flows, "mpf_src_flow: null pointer");
+    MPF_REQUIRE(P >= 1 && P <= 2, "mpf_src_flow: P must be 1 or 2 (got %d)", P);
+    MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_src_flow: bad shape S=%d H=%d W=%d", S, H, W);
+    const int64_t N = (int64_t)H * W;
+    hipStream_t st = (hipStream_t)stream;
+    // flow-only body (BLEND = false): reads nothing but the sigma planes; no image, no by-products
+    if (P == 1) return launch_sbf<1, 1>(d_sigma_SHW, nullptr, d_params, S, H, W, flow_clip, nullptr, nullptr, nullptr, d_flows, nullptr, nullptr, nullptr, nullptr, nullptr, st, N, 0);
+    return launch_sbf<1, 2>(d_sigma_SHW, nullptr, d_params, S, H, W, flow_clip, nullptr, nullptr, nullptr, d_flows, nullptr, nullptr, nullptr, nullptr, nullptr, st, N, 0);
 }
 
 void mpf_fwarp_set_path(int v);      // mpf_fwarp.hip

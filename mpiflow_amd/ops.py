@@ -158,6 +158,46 @@ def warp_composite(rgba, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None
 
 
 @_on_device
+def warp_composite_split(rgb_S3HW, sigma_S1HW, quads, H_src_tgt=None, K_inv=None, G=None, depth_S=None, want_depth=True, want_tgt_mask=True,
+                         dparams=None, out=None):
+    """Stage B on the two channel-planar tensors render_novel_view_dynamic receives (mpi_all_rgb_src [S,3,H,W], mpi_all_sigma_src
+    [S,1,H,W] | [S,H,W]), read in place: no concatenation, no repack (mpf_warp_composite_split).  Returns warp_composite's dict."""
+    lib = _lib.load()
+    rgb_in = _dev(rgb_S3HW, "rgb stack")
+    S, C, H, W = rgb_in.shape
+    assert C == 3
+    sig = _dev(sigma_S1HW, "sigma stack").reshape(S, H, W)
+    if dparams is None:
+        dparams = upload_params(warp_params(H_src_tgt, K_inv, G, depth_S), rgb_in.device)
+    q = _dev(quads, "mask quads") if quads is not None else None
+    u8 = out.get("rgb_u8") if out is not None else None
+    if out is not None:
+        rgb, depth, om, tm = out["rgb"], out.get("depth"), out.get("objmask"), out.get("tgt_mask")
+    else:
+        rgb = torch.empty((3, H, W), dtype=_f32, device=rgb_in.device)
+        depth = torch.empty((H, W), dtype=_f32, device=rgb_in.device) if want_depth else None
+        om = torch.empty((H, W), dtype=_f32, device=rgb_in.device) if q is not None else None
+        tm = torch.empty((H, W), dtype=_f32, device=rgb_in.device) if want_tgt_mask else None
+    _lib.check(lib.mpf_warp_composite_split(_ptr(rgb_in), _ptr(sig), _ptr(q), _ptr(dparams), S, H, W, _ptr(rgb), _ptr(depth), _ptr(om), _ptr(tm),
+                                            _ptr(u8), _stream()), "mpf_warp_composite_split")
+    return dict(rgb=rgb, depth=depth, objmask=om, tgt_mask=tm, rgb_u8=u8)
+
+
+@_on_device
+def src_flow(sigma_S1HW, K_inv, depth_S, homs_tgt_src, flow_clip=200.0):
+    """Stage C alone (mpf_src_flow): volume-rendered flows [P,2,H,W] of P <= 2 poses from a bare sigma tensor [S,1,H,W] | [S,H,W]."""
+    lib = _lib.load()
+    sig = _dev(sigma_S1HW, "sigma stack")
+    S, H, W = sig.shape[0], sig.shape[-2], sig.shape[-1]
+    sig = sig.reshape(S, H, W)
+    params, P = blend_flow_params(K_inv, depth_S, homs_tgt_src)
+    dparams = upload_params(params, sig.device)
+    flows = torch.empty((P, 2, H, W), dtype=_f32, device=sig.device)
+    _lib.check(lib.mpf_src_flow(_ptr(sig), _ptr(dparams), P, S, H, W, float(flow_clip), _ptr(flows), _stream()), "mpf_src_flow")
+    return flows
+
+
+@_on_device
 def warp_composite_views(rgba, views, interleaved=2):
     """Stage B for several views of one interleaved stack in ONE launch (mpf_warp_composite_views): the stack crosses the HBM
     interface once instead of once per view.  views: list of dicts(dparams=, quads= | None, out=dict(rgb, objmask?, depth?,

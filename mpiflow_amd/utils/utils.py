@@ -124,17 +124,19 @@ def render_novel_view_dynamic(obj_mask, mpi_all_rgb_src, mpi_all_sigma_src, disp
     """One posed view of an already-blended MPI (reference utils/utils.py:291-349).
     :return: (tgt_imgs_syn [1,3,H,W], tgt_depth_syn [1,1,H,W], flow_syn [1,2,H,W] clipped to +-200, obj_mask [1,1,H,W])
 
-    Fused path: planar rgb/sigma are consumed in place (no repack), xyz channels are evaluated analytically, the flow
-    comes from the source-frame weights of the same stack."""
+    Fused path: the two channel-planar tensors are consumed IN PLACE - Stage B reads the three colour planes and the sigma plane where
+    they lie (mpf_warp_composite_split; no concatenation, no repack: the reference builds an 8-channel copy of the stack per call,
+    utils/mpi/mpi_rendering.py:288-301), xyz channels are evaluated analytically, and the flow comes from the source-frame weights of
+    the sigma tensor alone (mpf_src_flow)."""
     B, S = disparity_all_src.size()
     assert B == 1, "the reference's entry point is batch-1 (utils/utils.py:314 indexes [0])"
     H, W = mpi_all_rgb_src.shape[-2:]
     dev = mpi_all_rgb_src.device
     d = host_math.plane_depths(disparity_all_src[0])
     H_ts, H_st = host_math.homographies(G_tgt_src, K_src_inv, K_tgt, d)
-    planar = torch.cat((mpi_all_rgb_src[0].to(torch.float32), mpi_all_sigma_src[0].to(torch.float32)), dim=1).contiguous()
+    rgb_S3HW, sigma_S1HW = mpi_all_rgb_src[0], mpi_all_sigma_src[0]
     quads = ops.mask_quads(obj_mask.reshape(H, W).to(dev, torch.float32), False)
-    v = ops.warp_composite(planar, quads, H_st, K_src_inv, G_tgt_src, d, interleaved=False)
+    v = ops.warp_composite_split(rgb_S3HW, sigma_S1HW, quads, H_st, K_src_inv, G_tgt_src, d)
     if hard_flow:
         hs = homography_sampler or HomographySample(H, W, dev)
         xyz_src = mpi_rendering.get_src_xyz_from_plane_disparity(hs.meshgrid, disparity_all_src, K_src_inv)
@@ -142,8 +144,6 @@ def render_novel_view_dynamic(obj_mask, mpi_all_rgb_src, mpi_all_sigma_src, disp
         flow = mpi_rendering.plane_volume_rendering_flow(mpi_all_sigma_src.to(torch.float32), flow_s, xyz_src, False, hard_flow=True)
         flow = torch.clip(flow, -200, 200)
     else:
-        # source-frame weights: Stage A+C kernel without the blend outputs (flow only)
-        zeros = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-        a = ops.src_blend_flow(planar, zeros, K_src_inv, d, H_ts.unsqueeze(0), flow_clip=200.0, want_rgba=False)
-        flow = a["flows"][0:1]
+        # source-frame weights: the Stage A+C kernel's flow-only body on the sigma tensor
+        flow = ops.src_flow(sigma_S1HW, K_src_inv, d, H_ts.unsqueeze(0), flow_clip=200.0)[0:1]
     return v["rgb"].unsqueeze(0), v["depth"].reshape(1, 1, H, W), flow.reshape(1, 2, H, W), v["objmask"].reshape(1, 1, H, W)

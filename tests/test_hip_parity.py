@@ -676,3 +676,37 @@ def test_overlapped_pair_renderer_equals_render_pair(dev, kernel_exp, S, H, W, n
         ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
         for k, t in zip(("flow_mix", "frame_mix", "fill_mask"), out):
             assert bits_equal(N(t), ref[k]) == 0, k
+
+
+@pytest.mark.parametrize("S,H,W", [(8, 32, 48), (20, 23, 37), (1, 16, 24), (2, 9, 70), (3, 1, 64), (6, 64, 1), (33, 64, 65), (272, 8, 64)])
+def test_planar_and_split_stage_b_equal_the_interleaved_kernel(dev, kernel_exp, S, H, W):
+    """The reference's own tensor layouts - one channel-planar [S,4,H,W] stack (mpf_warp_composite, interleaved = 0) and the separate rgb
+    [S,3,H,W] / sigma [S,1,H,W] tensors render_novel_view_dynamic receives (mpf_warp_composite_split) - go through the fast Stage B body
+    with 8-byte tap-pair loads: every output bit-identical to the oracle, with and without a mask, incl. the very last texel of the tensor
+    (its east / south neighbours lie past the end: the buffer descriptor returns 0 there, weight 0).  mpf_src_flow on the bare sigma
+    tensor equals mpf_src_blend_flow's flows."""
+    from mpiflow_amd import ops
+    o = kernel_exp
+    inp = _inputs(S, H, W, seed=S + 11 * H)
+    G_cam, G_dyn = _poses(o, S + W + 1)
+    d, k_inv = o.plane_depths(inp["disparity"]), o.k_inverse(inp["K"])
+    (Hts_c, Hst_c), (Hts_d, Hst_d) = o.homographies(G_cam, k_inv, inp["K"], d), o.homographies(G_dyn, k_inv, inp["K"], d)
+    stack = T(inp["mpi"], dev)                                               # used as is: Stage B does not care whether it was blended
+    inter = stack.permute(0, 2, 3, 1).contiguous()
+    # exact-size allocations, so that the last texel's neighbours really are past the end of the tensor
+    rgb3, sig1 = stack[:, :3].contiguous().clone(), stack[:, 3:].contiguous().clone()
+    for comp, Hst, G in ((False, Hst_c, G_cam), (True, Hst_d, G_dyn)):
+        m = (1.0 - inp["obj_mask"]) if comp else inp["obj_mask"]
+        want = o.warp_composite(N(inter), m, Hst, k_inv, G, d)
+        q = ops.mask_quads(T(inp["obj_mask"], dev), complement=comp)
+        for quads in (q, None):
+            a = ops.warp_composite(stack, quads, Hst, k_inv, G, d, interleaved=False)
+            b = ops.warp_composite_split(rgb3, sig1, quads, Hst, k_inv, G, d)
+            for got in (a, b):
+                for k in ("rgb", "depth", "tgt_mask") + (("objmask",) if quads is not None else ()):
+                    assert bits_equal(N(got[k]), want[k]) == 0, (k, comp, quads is not None)
+        lean = ops.warp_composite_split(rgb3, sig1, q, Hst, k_inv, G, d, want_depth=False, want_tgt_mask=False)
+        assert bits_equal(N(lean["rgb"]), want["rgb"]) == 0 and bits_equal(N(lean["objmask"]), want["objmask"]) == 0
+    ref = o.src_blend_flow(inp["mpi"], inp["image"], k_inv, d, np.stack([Hts_c, Hts_d]))
+    assert bits_equal(N(ops.src_flow(sig1, k_inv, d, np.stack([Hts_c, Hts_d]))), ref["flows"]) == 0
+    assert bits_equal(N(ops.src_flow(sig1.reshape(S, H, W), k_inv, d, Hts_d[None]))[0], ref["flows"][1]) == 0

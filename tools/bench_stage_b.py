@@ -25,7 +25,9 @@ p.add_argument("--launches", type=int, default=20)
 p.add_argument("--images", type=int, default=4)
 p.add_argument("--mask", type=int, default=1)
 p.add_argument("--aux", type=int, default=1, help="0 = no depth / tgt_mask outputs (as the fused pipeline runs it)")
-p.add_argument("--layout", type=int, default=1, help="1 = interleaved, 2 = interleaved + tail padding")
+p.add_argument("--layout", type=int, default=1, help="1 = interleaved, 2 = interleaved + tail padding, 0 = the reference's channel-planar [S,4,H,W] "
+               "(variant 0 = round-1 planar kernel, any other variant = k_warp_composite_planar), 3 = separate rgb [S,3,H,W] / sigma [S,1,H,W] "
+               "tensors as render_novel_view_dynamic receives them (mpf_warp_composite_split; variant 0 = torch.cat + round-1 planar kernel)")
 a = p.parse_args()
 
 lib = _lib.load()
@@ -37,7 +39,9 @@ for i in range(a.images):
     rgba = ops.alloc_rgba_stack(S, H, W, dev)
     rgba.copy_(torch.rand((S, H, W, 4), generator=g, device=dev))
     rgba[..., 3] = torch.relu(3.0 * torch.randn((S, H, W), generator=g, device=dev) - 4.0) + 1e-4
-    stacks.append(rgba)
+    stacks.append(rgba.permute(0, 3, 1, 2).contiguous() if a.layout in (0, 3) else rgba)
+if a.layout == 3:
+    stacks = [(st[:, :3].contiguous(), st[:, 3:].contiguous()) for st in stacks]
 K = synth.intrinsics(H, W)
 k_inv = host_math.k_inverse(K)
 d = host_math.plane_depths(synth.plane_disparities(S))
@@ -52,7 +56,11 @@ variants = [int(v) for v in a.variants.split(",")]
 
 def run(v, rgba, out=None):
     _lib.check(lib.mpf_tune(b"stage_b", v))
-    return ops.warp_composite(rgba, quads, dparams=dparams, out=out, interleaved=(a.layout if v > 0 else 1))
+    if a.layout == 3:
+        if v == 0:          # what the mirror did before: assemble [S,4,H,W], then the planar kernel
+            return ops.warp_composite(torch.cat(rgba, dim=1).contiguous(), quads, dparams=dparams, out=out, interleaved=0)
+        return ops.warp_composite_split(rgba[0], rgba[1], quads, dparams=dparams, out=out)
+    return ops.warp_composite(rgba, quads, dparams=dparams, out=out, interleaved=(0 if a.layout == 0 else (a.layout if v > 0 else 1)))
 
 
 ref = run(0, stacks[0])

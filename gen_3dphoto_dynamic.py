@@ -65,9 +65,11 @@ def parse(argv=None):
                    help="model: the AdaMPI network from --ckpt_path, as the reference always does; npz: precomputed stacks base/mpis/NAME.npz; "
                         "disparity: a hard-assignment stand-in built from the disparity map (NOT the reference's producer - for smoke runs)")
     p.add_argument("--model-dtype", choices=["fp32", "fp16", "bf16"], default="fp32", help="autocast dtype of the network's convolutions")
-    p.add_argument("--model-engine", choices=["torch", "hip"], default="torch",
-                   help="torch: every convolution on PyTorch/MIOpen (fp32 = the reference's CPU numerics); hip: the per-plane networks on "
-                        "the MFMA convolution engine (fp16 storage, fp32 accumulate - the reference's GPU precision), one hipGraph per image")
+    p.add_argument("--model-engine", choices=["hip", "torch"], default="hip",
+                   help="hip (default): the per-plane networks - feature-mask UNet and gated decoder, > 98 %% of the network's flops - on the MFMA "
+                        "convolution engine (fp16 storage, fp32 accumulate: the precision of the reference's own GPU run, which calls .half() on model "
+                        "and inputs, gen_3dphoto_dynamic_v2.py:46,59,82-84), one hipGraph per image, 8.5 ms per 64 x 384 x 1280 image; torch: every "
+                        "convolution on PyTorch/MIOpen (fp32 with --model-dtype fp32 = the reference's CPU numerics, 115 ms per image)")
     p.add_argument("--inpaint", choices=list(U.INPAINT_METHODS), default="auto",
                    help="hole filling of the rendered frame (reference: cv2.inpaint NS radius 3).  auto = cv2 when OpenCV is installed, else "
                         "builtin = the same algorithm restated in libmpiflow_hip.so, run on the writer threads; peel (alias hip) = the onion-peel "

@@ -191,13 +191,31 @@ struct MpfGeom {
     unsigned b00, b01, b10, b11;     // byte offsets of the four taps inside one [H,W,4] fp32 plane
 };
 
+#ifndef MPF_XYZ_MFMA
+#define MPF_XYZ_MFMA 0          // 1: xyz_tgt = G . (r; 1) on the matrix cores (4 x v_mfma_f32_4x4x1 instead of 12 VALU ops), see mpf_geom_core
+#endif
 struct MpfConsts {
     float fx, fy;
     float halfW, halfH, rhalfW, rhalfH, maxx, maxy;
     float Wf, Hf;
     int W, H;
     unsigned row_bytes;
+#if MPF_XYZ_MFMA
+    float G0, G1, G2, G3;        // column k of G_tgt_src's 3x4 block, row (lane % 4) - the A operands of the 4x4x1 outer products (row 3: zero)
+#endif
 };
+
+template <class ParamPtr>
+MPF_DEV void mpf_consts_pose(MpfConsts &c, const ParamPtr params)
+{
+#if MPF_XYZ_MFMA
+    const unsigned r = threadIdx.x & 3u;
+    c.G0 = r == 0 ? params[9] : (r == 1 ? params[13] : (r == 2 ? params[17] : 0.0f));
+    c.G1 = r == 0 ? params[10] : (r == 1 ? params[14] : (r == 2 ? params[18] : 0.0f));
+    c.G2 = r == 0 ? params[11] : (r == 1 ? params[15] : (r == 2 ? params[19] : 0.0f));
+    c.G3 = r == 0 ? params[12] : (r == 1 ? params[16] : (r == 2 ? params[20] : 0.0f));
+#endif
+}
 
 // KS: K_src^-1 has the pinhole form [[a,0,b],[0,c,e],[0,0,1]] (checked at run time, uniform).  Then the reference's dense
 //     3x3 . (ix,iy,1) chain collapses exactly: a*ix + 0*iy is a*ix, 0*ix + c*iy is c*iy, the third row is exactly 1, and
@@ -245,9 +263,23 @@ MPF_DEV float mpf_geom_core(const ParamPtr params, int s, const MpfConsts &c, fl
         ry = mpf_row3_xy1(params[3], params[4], params[5], ix, iy) * d;
         rzz = mpf_row3_xy1(params[6], params[7], params[8], ix, iy) * d;
     }
+#if MPF_XYZ_MFMA
+    // v_mfma_f32_4x4x1_16b_f32: D_v(lane) = A(lane 4 * (lane / 4) + v) * B(lane) + C_v(lane), one exact IEEE fma per element - identical to
+    // v_fma_f32 on 2 * 10^10 operand triples of this path's ranges (tools/mfma_fma_exact.hip, profiles/r3/mfma_fma_exact.log) - so the chain
+    // a0*X, fma(a1,Y,.), fma(a2,Z,.), fma(a3,1,.) of the three rows of G becomes 4 dependent outer products: rows in the accumulator index,
+    // this lane's (rx, ry, rz, 1) as B.  (The first step is fma(a0, X, +0): equal to the product except for the sign of an exact zero.)
+    typedef float mpf_f4 __attribute__((ext_vector_type(4)));
+    mpf_f4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(c.G0, rx, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(c.G1, ry, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(c.G2, rzz, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(c.G3, 1.0f, acc, 0, 0, 0);
+    X = acc[0]; Y = acc[1]; Z = acc[2];
+#else
     X = mpf_row4_xyz1(params[9], params[10], params[11], params[12], rx, ry, rzz);
     Y = mpf_row4_xyz1(params[13], params[14], params[15], params[16], rx, ry, rzz);
     Z = mpf_row4_xyz1(params[17], params[18], params[19], params[20], rx, ry, rzz);
+#endif
     return valid;
 }
 
@@ -410,6 +442,7 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
     c.rhalfW = 1.0f / c.halfW; c.rhalfH = 1.0f / c.halfH;      // IEEE division (build flag): RN(1/d), which mpf_div_by_const relies on
     c.maxx = (float)(W - 1); c.maxy = (float)(H - 1);
     c.row_bytes = (unsigned)W * 16u;
+    mpf_consts_pose(c, params);
     const char *qbase = reinterpret_cast<const char *>(quads);
     const char *pbase = reinterpret_cast<const char *>(rgba);
     const size_t plane_bytes = (size_t)N * 16;
@@ -677,6 +710,7 @@ MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restric
     c.rhalfW = 1.0f / c.halfW; c.rhalfH = 1.0f / c.halfH;      // IEEE division (build flag): RN(1/d), which mpf_div_by_const relies on
     c.maxx = (float)(W - 1); c.maxy = (float)(H - 1);
     c.row_bytes = (unsigned)W * 16u;
+    mpf_consts_pose(c, (MpfConstParams)params);
     const char *qbase = reinterpret_cast<const char *>(quads);
     const char *pbase = reinterpret_cast<const char *>(rgba);
     const size_t plane_bytes = (size_t)N * 16;

@@ -30,8 +30,10 @@ def means(pattern, counter):
 fetch, write = means("pmc_fetch", "FETCH_SIZE"), means("pmc_write", "WRITE_SIZE")
 kb = [k for k in fetch if "k_warp_composite" in k]
 kac = [k for k in fetch if "k_src_blend_flow" in k]
+kp = [k for k in fetch if "k_pair_overlap" in k]
 assert kb and kac, (list(fetch), list(write))
 kb, kac = max(kb, key=lambda k: fetch[k]), max(kac, key=lambda k: fetch[k])
+kp = max(kp, key=lambda k: fetch[k]) if kp else None
 S, H, W = 64, 640, 960
 N = H * W
 views = 2 if "views" in kb else 1
@@ -47,5 +49,10 @@ rec = {
     "algorithmic_bytes_per_launch": alg_b,
     "kernel_source_sha256": hashlib.sha256(src).hexdigest(),
 }
+if kp:      # the heterogeneous-grid launch: Stage B of pair i (2 views) + Stage A+C of pair i + 1
+    rec.update({"pair_kernel": kp, "pair_FETCH_SIZE_KB_mean": fetch[kp], "pair_WRITE_SIZE_KB_mean": write.get(kp),
+                "pair_hbm_bytes_per_launch": fetch[kp] * 2 * 1024 + write.get(kp, 0) * 1024,
+                "pair_algorithmic_bytes_per_launch": 60.0 * S * N + 28.0 * N,
+                "pair_separate_kernels_hbm_bytes": fetch[kb] * 2 * 1024 + write.get(kb, 0) * 1024 + fetch[kac] * 2 * 1024 + write.get(kac, 0) * 1024})
 json.dump(rec, open(os.path.join(root, "roofline_traffic.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))

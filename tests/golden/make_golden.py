@@ -468,6 +468,8 @@ JOBS = {
     # at 128 x 512 x 768 - same plane count (the 128-addend cascade sums), a quarter of the pixels; the full-size frame is
     # covered by HIP-vs-pinned-oracle on every pixel (tests/test_full_frame.py).
     "c5": lambda: gen_big("c5q_white", 128, 512, 768, "white", 14, 24, stack_px=1024),
+    # the generator's real shape (gen_3dphoto_dynamic_v2.py:22-23 defaults: 64 planes, 384 x 1280 - KITTI)
+    "kitti": lambda: (gen_big("kitti_smooth", 64, 384, 1280, "smooth", 15, 25, stack_px=2048), gen_big("kitti_white", 64, 384, 1280, "white", 16, 26, stack_px=2048)),
     "fwarp": lambda: (gen_fwarp("fwarp_small", 96, 128, 31, True), gen_fwarp("fwarp_c2", 640, 960, 32, False),
                       gen_collision_stress()),
     "inputs": gen_input_stage,

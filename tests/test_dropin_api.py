@@ -399,7 +399,8 @@ def test_cli_with_network_producer(dev, tmp_path):
     Image.fromarray(m).save(base / "masks" / "a.png")
     out = tmp_path / "out"
     r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--base", str(base), "--out", str(out), "--width", "128",
-                        "--height", "128", "--repeat", "1", "--planes", "8", "--inpaint", "hip", "--mpi-from", "model", "--ckpt_path", "random:3"],
+                        "--height", "128", "--repeat", "1", "--planes", "8", "--inpaint", "hip", "--mpi-from", "model", "--ckpt_path", "random:3",
+                        "--model-engine", "torch"],                                        # the opt-out: every convolution on torch / MIOpen
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     flow = io_formats.read_flo(str(out / "flows" / "a_0.flo"))
@@ -408,8 +409,8 @@ def test_cli_with_network_producer(dev, tmp_path):
 
 
 def test_cli_with_network_on_hip_engine(dev, tmp_path):
-    """--model-engine hip: the per-plane networks on the MFMA engine, replayed from one hipGraph per image; two images so the
-    captured graph is replayed with new inputs (replay == eager is checked in tests/test_conv_engine.py)."""
+    """The default producer (--model-engine hip): the per-plane networks on the MFMA engine, replayed from one hipGraph per image; two
+    images so the captured graph is replayed with new inputs (replay == eager is checked in tests/test_conv_engine.py)."""
     import subprocess, sys, os
     from PIL import Image
     from mpiflow_amd import io_formats
@@ -425,8 +426,8 @@ def test_cli_with_network_on_hip_engine(dev, tmp_path):
         Image.fromarray(m).save(base / "masks" / (n + ".png"))
     out = tmp_path / "out"
     r = subprocess.run([sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--base", str(base), "--out", str(out), "--width", "128",
-                        "--height", "128", "--repeat", "1", "--planes", "8", "--inpaint", "hip", "--mpi-from", "model", "--ckpt_path", "random:3",
-                        "--model-engine", "hip"], capture_output=True, text=True, timeout=900)
+                        "--height", "128", "--repeat", "1", "--planes", "8", "--inpaint", "hip", "--mpi-from", "model", "--ckpt_path", "random:3"],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     flows = [io_formats.read_flo(str(out / "flows" / (n + "_0.flo"))) for n in ("a", "b")]
     for f in flows:

@@ -57,23 +57,90 @@ def _report(tag, rec):
     print("\n[full-frame parity] %s: %s" % (tag, json.dumps(rec, sort_keys=True)))
 
 
-def _full_frame(dev, oracle, tag, S, H, W, seed, kind, pose_seed, golden=None, multi_view=True):
+def _render_pair(dev, inp, G_cam, G_dyn, S, H, W, multi_view):
+    from mpiflow_amd import pipeline
+    r = pipeline.PairRenderer(S, H, W, dev)
+    r.multi_view = multi_view
+    out = pipeline.render_pair(T(inp["image"], dev), T(inp["obj_mask"], dev), T(inp["mpi"], dev), inp["disparity"], inp["K"],
+                               G_cam, G_dyn, renderer=r)
+    torch.cuda.synchronize()
+    return dict(flow_mix=N(out["flow_mix"]), frame_mix=N(out["frame_mix"]), fill_mask=N(out["fill_mask"]), src_np=N(out["src_np"]),
+                flows=N(out["flows"]), cam_rgb=N(out["view_cam"]["rgb"]), dyn_rgb=N(out["view_dyn"]["rgb"]),
+                cam_om=N(out["view_cam"]["objmask"]), dyn_om=N(out["view_dyn"]["objmask"]))
+
+
+def _render_overlapped(dev, inp, G_cam, G_dyn, S, H, W):
+    """The pair as the bench / batch driver render it: inside an OverlappedPairRenderer stream, between two other images - its Stage A+C
+    shares a launch with the previous image's Stage B, its Stage B with the next image's Stage A+C."""
     from mpiflow_amd import pipeline, synth
+    ovl = pipeline.OverlappedPairRenderer(S, H, W, dev)
+    K, disp = inp["K"], inp["disparity"]
+    rng = random.Random(5)
+    others = [synth.make_inputs(S, H, W, seed=900 + k, kind="smooth") for k in range(2)]
+    from mpiflow_amd import host_math
+
+    def push(x, Gc, Gd):
+        return ovl.push(T(x["mpi"], dev), T(x["image"], dev), ovl.prepare(K, disp, [Gc, Gd]), T(x["obj_mask"], dev))
+    push(others[0], host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng), host_math.generate_random_pose(0.15, rng=rng))
+    del others[0]
+    push(inp, G_cam, G_dyn)
+    slot = ovl.pending_slot
+    done = push(others[0], host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng), host_math.generate_random_pose(0.15, rng=rng))
+    torch.cuda.synchronize()
+    got = dict(flow_mix=N(done[0]), frame_mix=N(done[1]), fill_mask=N(done[2]), src_np=None, flows=N(slot["flows"]),
+               cam_rgb=N(slot["views"][0]["rgb"]), dyn_rgb=N(slot["views"][1]["rgb"]), cam_om=N(slot["views"][0]["objmask"]),
+               dyn_om=N(slot["views"][1]["objmask"]))
+    ovl.flush()
+    torch.cuda.synchronize()
+    return got
+
+
+def _render_run_pairs(dev, oracle, inp, G_cam, G_dyn, S, H, W, R=5):
+    """The pair as the generator renders it (PairRenderer.blend once, then run_pairs: the 2 R views of the image's R pairs in ONE Stage B
+    launch, gen_3dphoto_dynamic_v2.py:99-118 with repeat = 5).  Pair 0 is the pair under test; the other R - 1 pairs (other poses, shifted
+    masks) are checked bit for bit against the oracle in kernel-exp mode here."""
+    from mpiflow_amd import host_math, pipeline
+    r = pipeline.PairRenderer(S, H, W, dev)
+    rng = random.Random(77)
+    mpi, img = T(inp["mpi"], dev), T(inp["image"], dev)
+    masks_np = [inp["obj_mask"]] + [np.ascontiguousarray(np.roll(inp["obj_mask"], 37 * k, axis=1)) for k in range(1, R)]
+    poses = [(torch.from_numpy(G_cam), torch.from_numpy(G_dyn))]
+    for _ in range(1, R):
+        dyn = host_math.generate_random_pose(0.15, rng=rng)
+        poses.append((host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng), dyn))
+    r.blend(mpi, img, inp["K"], inp["disparity"])
+    res = r.run_pairs(mpi, img, inp["K"], inp["disparity"], [T(m, dev) for m in masks_np], poses)
+    torch.cuda.synchronize()
+    b = r._pair_bufs[0]
+    got = dict(flow_mix=N(res[0]["flow_mix"]), frame_mix=N(res[0]["frame_mix"]), fill_mask=N(res[0]["fill_mask"]), src_np=N(r.src_u8),
+               flows=N(b["flows"]), cam_rgb=N(b["views"][0]["rgb"]), dyn_rgb=N(b["views"][1]["rgb"]), cam_om=N(b["views"][0]["objmask"]),
+               dyn_om=N(b["views"][1]["objmask"]))
+    oracle.set_exp_mode(1)
+    try:
+        for k in range(1, R):
+            o = oracle.render_pair(inp["image"], masks_np[k], inp["mpi"], inp["disparity"], inp["K"], poses[k][0].numpy(), poses[k][1].numpy())
+            for key in ("flow_mix", "frame_mix", "fill_mask"):
+                assert bits_equal(N(res[k][key]), o[key]) == 0, "pair %d of the image: %s differs from the oracle" % (k, key)
+            del o
+    finally:
+        oracle.set_exp_mode(0)
+    return got
+
+
+def _full_frame(dev, oracle, tag, S, H, W, seed, kind, pose_seed, golden=None, multi_view=True, mode="pair"):
+    from mpiflow_amd import synth
     inp = synth.make_inputs(S, H, W, seed=seed, kind=kind)
     rng = random.Random(pose_seed)
     G_dyn = oracle.random_pose(rng, 0.15)                                  # utils/utils.py:207-208 draw order
     G_cam = oracle.random_pose(rng, 0.15, base_motions=(0, 0, 0))
     if golden is not None:
         assert bits_equal(G_cam, golden["G_cam"]) == 0 and bits_equal(G_dyn, golden["G_dyn"]) == 0
-    r = pipeline.PairRenderer(S, H, W, dev)
-    r.multi_view = multi_view
-    out = pipeline.render_pair(T(inp["image"], dev), T(inp["obj_mask"], dev), T(inp["mpi"], dev), inp["disparity"], inp["K"],
-                               G_cam, G_dyn, renderer=r)
-    torch.cuda.synchronize()
-    got = dict(flow_mix=N(out["flow_mix"]), frame_mix=N(out["frame_mix"]), fill_mask=N(out["fill_mask"]), src_np=N(out["src_np"]),
-               flows=N(out["flows"]), cam_rgb=N(out["view_cam"]["rgb"]), dyn_rgb=N(out["view_dyn"]["rgb"]),
-               cam_om=N(out["view_cam"]["objmask"]), dyn_om=N(out["view_dyn"]["objmask"]))
-    del out, r
+    if mode == "overlapped":
+        got = _render_overlapped(dev, inp, G_cam, G_dyn, S, H, W)
+    elif mode == "run_pairs":
+        got = _render_run_pairs(dev, oracle, inp, G_cam, G_dyn, S, H, W)
+    else:
+        got = _render_pair(dev, inp, G_cam, G_dyn, S, H, W, multi_view)
     torch.cuda.empty_cache()
 
     def ref(mode):
@@ -88,6 +155,8 @@ def _full_frame(dev, oracle, tag, S, H, W, seed, kind, pose_seed, golden=None, m
 
     # 1. same op sequence on CPU and GPU: every bit of every pixel
     r1 = ref(1)
+    if got["src_np"] is None:                                              # not kept by this render mode
+        got["src_np"] = r1["src_np"]
     for k in got:
         assert bits_equal(got[k], r1[k]) == 0, "%s: HIP differs from the oracle (kernel exp) on %d values" % (k, bits_equal(got[k], r1[k]))
     del r1
@@ -153,6 +222,24 @@ def test_every_pixel_c2_one_launch_per_view(dev, oracle):
     g = load_golden("c2_white")
     _full_frame(dev, oracle, "c2_white_single_view_launches", int(g["S"]), int(g["H"]), int(g["W"]), int(g["seed"]), str(g["kind"]),
                 int(g["pose_seed"]), golden=g, multi_view=False)
+
+
+def test_every_pixel_c2_overlapped_pipeline(dev, oracle):
+    """The c2 / c3 frame as bench.py's `value` renders it: Stage A+C in one heterogeneous-grid launch with the previous image's Stage B,
+    Stage B in the next one with the following image's Stage A+C (mpf_warp_views_and_blend_next) - every pixel, same bars, same golden."""
+    g = load_golden("c2_white")
+    _full_frame(dev, oracle, "c2_white_overlapped_pipeline", int(g["S"]), int(g["H"]), int(g["W"]), int(g["seed"]), str(g["kind"]),
+                int(g["pose_seed"]), golden=g, mode="overlapped")
+
+
+@pytest.mark.parametrize("name,mode", [("kitti_smooth", "run_pairs"), ("kitti_white", "run_pairs"), ("kitti_white", "overlapped")])
+def test_every_pixel_generator_shape(dev, oracle, name, mode):
+    """The generator's real shape and launch form: 64 planes x 384 x 1280 (gen_3dphoto_dynamic_v2.py:22-23 defaults), blend once, then the
+    image's repeat = 5 pairs through PairRenderer.run_pairs - TEN views in one Stage B launch (:99-118) - every pixel of the first pair
+    against the oracle and against the golden recorded from the reference at this shape; the other four pairs bit for bit against the oracle."""
+    g = load_golden(name)
+    _full_frame(dev, oracle, "%s_%s" % (name, mode), int(g["S"]), int(g["H"]), int(g["W"]), int(g["seed"]), str(g["kind"]), int(g["pose_seed"]),
+                golden=g, mode=mode)
 
 
 def test_every_pixel_c1(dev, oracle):

@@ -1351,8 +1351,8 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
 //   * only what the pipeline needs: the interleaved blended stack, P flows, the per-pixel by-products; no planar / tacc outputs, so
 //     no pointer tests in the plane loop, and the last plane (thickness 1e3) is peeled off instead of tested for
 //   * buffer addressing: descriptor in SGPRs, plane / channel as the instruction's scalar offset, the pixel as a loop-invariant
-//     VGPR offset - no 64-bit VALU adds, no per-channel plane pointers; a dead lane's store offset is out of range, which the
-//     hardware drops: no exec-mask branch around the stores either.  Needs 16*S*N < 4 GiB (checked by the launcher).
+//     VGPR offset - no 64-bit VALU adds, no per-channel plane pointers; a dead lane (past the last pixel) shadows the last pixel and
+//     stores the same texels again: no exec-mask branch around the stores either.  Needs 16*S*N < 4 GiB (checked by the launcher).
 //   * DEPTH planes of loads in flight per wave (ring of register sets, loop unrolled DEPTH times)
 template <int PX, int P, int NL, bool ACT, int DEPTH>
 MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const int W, const int64_t t)
@@ -1381,7 +1381,7 @@ MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const
         live[i] = ni < N;
         n[i] = live[i] ? ni : (N - 1);
         voff[i] = (unsigned)n[i] * 4u;
-        vout[i] = live[i] ? (unsigned)n[i] * 16u : 0xFFFFFFF0u;                      // out of range: the store is dropped
+        vout[i] = (unsigned)n[i] * 16u;           // a dead lane shadows the last pixel: it stores that pixel's (identical) texels once more
         fx[i] = (float)(n[i] % W);
         fy[i] = (float)(n[i] / W);
         ray[i][0] = mpf_row3_xy1(params[0], params[1], params[2], fx[i], fy[i]);      // mpi_rendering.py:234
@@ -1453,7 +1453,12 @@ MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const
                 o[c] = av + bb;
             }
             const mpf_v4f val = { o[0], o[1], o[2], sg };
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mpf_v4u, val), rs_out, vout[i], (unsigned)s * 4u * plane_bytes, 2 /* nt */);
+            // The plane offset is added to the VGPR offset (one VALU add), NOT passed as the instruction's scalar offset.  With an SGPR
+            // soffset hipcc assumes the "VMEM store of more than 64 bits, then VALU write of its data VGPRs" hazard away and puts the next
+            // plane's first VALU op - which reuses the first data register - right behind the store; on gfx950 the store then sent THAT
+            // op's result for lanes 12-15 of every 16 (found by the every-pixel test at 64 x 640 x 960: red channel of every fourth plane,
+            // only under load).  With an immediate soffset the hazard recogniser keeps the wait state.
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mpf_v4u, val), rs_out, vout[i] + (unsigned)s * 4u * plane_bytes, 0, 2 /* nt */);
             if (P > 0) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {

@@ -435,7 +435,7 @@ def overlap_record(S, H, W, dev, n_streams=2, images=4, steps=8):
             "streams": n_streams, "pairs_per_s": n / dt, "us_per_pair": dt / n * 1e6, "pairs_timed": n}
 
 
-def generator_record(n_images=24, repeat=5, timeout=600):
+def generator_record(n_images=64, repeat=5, timeout=600):
     """The data generator end to end (gen_3dphoto_dynamic.py, the reference's entry point gen_3dphoto_dynamic_v2.py:20-122): PNG decode,
     input stage, AdaMPI network (random weights of the reference's architecture: no checkpoint offline) on the HIP engine, blend once per
     image, `repeat` pairs per image, hole filling (cv2.inpaint's NS restated, on the writer threads), PNG + .flo files - on a synthetic

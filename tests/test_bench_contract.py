@@ -129,7 +129,7 @@ def test_single_gpu_line_has_sub_records_and_names_the_dynamic_pair():
     assert d["overlap"]["streams"] == 2 and d["overlap"]["pairs_per_s"] > 0.8 * d["value"]
     g = d["generator"]
     assert "error" not in g, g
-    assert g["pairs"] == 120 and g["flo_files_written"] == 120 and g["pairs_per_s_whole_process"] > 0 and g["pairs_per_s_steady_state"] > 0
+    assert g["pairs"] == 320 and g["flo_files_written"] == 320 and g["pairs_per_s_whole_process"] > 0 and g["pairs_per_s_steady_state"] > 0
     # the on-box streaming figures next to the 8 TB/s specification: plausible, and the kernels do not beat them
     hb = d["hbm_reference"]
     assert 1000.0 < hb["copy_GBps"] < 8000.0 and 1000.0 < hb["read_GBps"] < 8000.0

@@ -2,9 +2,12 @@
 collision / validity masks (Depthstillation heritage; reference moving_obj.py:16-168).
 
 The reference's function returns None and its only product is a debug PNG (temp/res-%06d.png).  This version keeps
-the name and positional signature, runs every per-pixel step in HIP (mpf_disp_to_depth, mpf_backproject_project,
-mpf_select_truncate, mpf_forward_warp - byte-identical to the C routine - and mpf_warp_masks) and *returns* the
-intermediates so they can be used and tested; the debug PNG is written only when `write_debug_png=True`.
+the name, the positional signature AND that behaviour - called as the reference calls it, it writes that PNG (the
+source frame, the inpainted and the raw forward-warped frame and the validity mask stacked as at moving_obj.py:164-168;
+the fifth panel, a colour-wheel rendering of the flow from the reference's visualisation module, is left out) and
+returns None - while every per-pixel step runs in HIP (mpf_moving_object_project, mpf_forward_warp - byte-identical to
+the C routine - and mpf_warp_masks); `return_intermediates=True` hands the device tensors back instead (tests, and
+callers that want the forward-warped frame, masks and flow rather than a picture of them).
 """
 import math
 import random
@@ -30,15 +33,16 @@ def object_pose(rng=None):
     return host_math.transformation_from_parameters(ai, tri)
 
 
-def moveing_object_with_mask(depth_path, disp, rgb, K, inv_K, instance_mask, i, T_obj=None, write_debug_png=False,
-                             inpaint="auto"):
+def moveing_object_with_mask(depth_path, disp, rgb, K, inv_K, instance_mask, i, T_obj=None, write_debug_png=True,
+                             inpaint="auto", return_intermediates=False):
     """(sic) reference moving_obj.py:16-168.
 
     :param disp: [1,1,h,w] disparity tensor;  :param rgb: [h,w,3] numpy holding 0..255;  :param K, inv_K: [3,3]
     :param instance_mask: [1,1,h,w] tensor (> 0 = the moving instance);  :param i: index for the debug file name
     :param T_obj: optional [1,4,4] object pose; default = drawn from `random` exactly as the reference does
-    :return: dict(p1, z1, safe_x, safe_y, flow_01, warped, masks{H,M,M',P,H'}, im1_raw, im1) - device tensors
-             (the reference returns None)"""
+    :param write_debug_png: write temp/res-%06d.png as the reference does (moving_obj.py:164-168); its only product
+    :return: None, like the reference; with return_intermediates=True dict(p1, z1, safe_x, safe_y, flow_01, warped,
+             masks{H,M,M',P,H'}, im1_raw, im1) - device tensors"""
     h, w = rgb.shape[:2]
     dev = disp.device if disp.is_cuda else torch.device("cuda")
     disp_d = disp.to(dev, torch.float32).reshape(h, w)
@@ -69,4 +73,4 @@ def moveing_object_with_mask(depth_path, disp, rgb, K, inv_K, instance_mask, i, 
         m3 = (masks["H"] * 255).unsqueeze(-1).repeat(1, 1, 3)
         res = np.vstack([np.asarray(rgb).astype(np.uint8), im1.cpu().numpy(), im1_raw.cpu().numpy(), m3.cpu().numpy()])
         Image.fromarray(res[:, :, ::-1].copy()).save("temp/res-{:06d}.png".format(i))
-    return out
+    return out if return_intermediates else None

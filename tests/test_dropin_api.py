@@ -164,12 +164,20 @@ def test_geometry_classes(dev):
     assert bits_equal(N(M), g["M"]) == 0
 
 
-def test_moveing_object_with_mask(dev):
+def test_moveing_object_with_mask(dev, tmp_path, monkeypatch):
     from mpiflow_amd import moving_obj
     g = load_golden("fwarp_small")
-    out = moving_obj.moveing_object_with_mask(None, T(g["disp"], dev)[None, None], g["rgb"].astype(np.float32), torch.from_numpy(g["K"]),
-                                              torch.from_numpy(g["inv_K"]), T(g["inst"], dev)[None, None], 0,
-                                              T_obj=torch.from_numpy(g["T_obj"])[None], inpaint="hip")
+    args = (None, T(g["disp"], dev)[None, None], g["rgb"].astype(np.float32), torch.from_numpy(g["K"]), torch.from_numpy(g["inv_K"]),
+            T(g["inst"], dev)[None, None])
+    # called exactly as the reference calls it (moving_obj.py:16 signature, positional): returns None, its product is temp/res-%06d.png
+    monkeypatch.chdir(tmp_path)
+    random.seed(int(g["seed"]))
+    assert moving_obj.moveing_object_with_mask(*args, 7, inpaint="hip") is None
+    from PIL import Image
+    h, w = g["rgb"].shape[:2]
+    assert Image.open(tmp_path / "temp" / "res-000007.png").size == (w, 4 * h)          # rgb | inpainted | forward-warped | validity mask
+    out = moving_obj.moveing_object_with_mask(*args, 0, T_obj=torch.from_numpy(g["T_obj"])[None], inpaint="hip", write_debug_png=False,
+                                              return_intermediates=True)
     assert bits_equal(N(out["safe_x"]), g["safe_x"]) == 0 and bits_equal(N(out["safe_y"]), g["safe_y"]) == 0
     assert bits_equal(N(out["z1"]), g["z1"]) == 0
     assert bits_equal(N(out["warped"]), g["warped"]) == 0

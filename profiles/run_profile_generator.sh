@@ -14,9 +14,9 @@ for i in range(40):
     m=np.zeros((375,1242),np.uint8); m[150:300,300:600]=1; m[200:330,800:1000]=2
     Image.fromarray(m).save(os.path.join(base,"masks","%04d.png"%i))
 PY
-python $REPO/gen_3dphoto_dynamic.py --base /tmp/clidata --out /tmp/cliout0 --repeat 5 --mpi-from model --ckpt_path random:0 --inpaint builtin --model-engine hip --writers 16 > /dev/null 2>&1
+python $REPO/gen_3dphoto_dynamic.py --base /tmp/clidata --out /tmp/cliout0 --repeat 5 --mpi-from model --ckpt_path random:0 --inpaint builtin > /dev/null 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o c -- python $REPO/gen_3dphoto_dynamic.py --base /tmp/clidata --out /tmp/cliout1 --repeat 5 --mpi-from model --ckpt_path random:0 --inpaint builtin --model-engine hip --writers 16 > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o c -- python $REPO/gen_3dphoto_dynamic.py --base /tmp/clidata --out /tmp/cliout1 --repeat 5 --mpi-from model --ckpt_path random:0 --inpaint builtin > $OUT/run.log 2>&1
 cd $REPO
 python profiles/summarize_kernels.py $OUT/t | head -40
 tail -2 $OUT/run.log

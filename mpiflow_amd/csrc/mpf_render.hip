@@ -1562,7 +1562,7 @@ k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsi
     }
 }
 
-static int g_ovl_depth = 4;     // mpf_tune("ovl_depth", 4 | 8): 4 measured best (490 vs 499 us per launch at 64x640x960)
+static int g_ovl_depth = 4;     // mpf_tune("ovl_depth", 4 | 8): no measurable difference at 64x640x960 (both 492-523 us per launch on one box)
 static int g_ovl_ablate = 0;    // mpf_tune("ovl_ablate", 0 | 1 | 2): bench-only, results invalid when non-zero
 
 template <bool HAS_MASK, int NL, int P, bool ACT>

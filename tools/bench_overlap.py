@@ -27,6 +27,7 @@ ap.add_argument("--images", type=int, default=4)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--skip-streams", action="store_true")
 ap.add_argument("--only-fused", action="store_true", help="fused depth 4, one and two pipelines, nothing else (A/B of library builds via MPIFLOW_HIP_LIB)")
+ap.add_argument("--depth-ab", action="store_true", help="alternate 4 and 8 planes in flight three times (same-box A/B of the A+C role's load depth)")
 ap.add_argument("--pmc", action="store_true", help="counter runs: serial single stream + fused depth 4 only")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -128,6 +129,13 @@ def fused(n_pipes, depth, ablate=0):
     torch.cuda.empty_cache()
 
 
+if a.depth_ab:
+    for _ in range(3):
+        for depth in (4, 8):
+            fused(1, depth)
+    for depth in (4, 8):
+        fused(2, depth)
+    sys.exit(0)
 if a.only_fused:
     fused(1, 4)
     fused(2, 4)

@@ -710,3 +710,38 @@ def test_planar_and_split_stage_b_equal_the_interleaved_kernel(dev, kernel_exp, 
     ref = o.src_blend_flow(inp["mpi"], inp["image"], k_inv, d, np.stack([Hts_c, Hts_d]))
     assert bits_equal(N(ops.src_flow(sig1, k_inv, d, np.stack([Hts_c, Hts_d]))), ref["flows"]) == 0
     assert bits_equal(N(ops.src_flow(sig1.reshape(S, H, W), k_inv, d, Hts_d[None]))[0], ref["flows"][1]) == 0
+
+
+def test_new_entry_points_reject_bad_arguments(dev):
+    """mpf_warp_views_and_blend_next / mpf_warp_composite_split / mpf_src_flow: bad arguments come back as MPF_ERR_BAD_ARGUMENT with a message,
+    nothing is launched (the two halves of the overlapped launch are unordered, so aliasing the stack being read with the one being written
+    must be refused; its buffer addressing limits the stack to 4 GiB)."""
+    import ctypes
+    from mpiflow_amd import _lib, ops
+    lib = _lib.load()
+    S, H, W = 4, 8, 16
+    rgba, rgba2 = ops.alloc_rgba_stack(S, H, W, dev), ops.alloc_rgba_stack(S, H, W, dev)
+    mpi, img = torch.rand((S, 4, H, W), device=dev), torch.rand((3, H, W), device=dev)
+    dp = torch.zeros(32 + 16 * S * 2, device=dev)
+    flows = torch.empty((2, 2, H, W), device=dev)
+    view = dict(dparams=dp, quads=None, out=dict(rgb=torch.empty((3, H, W), device=dev)))
+    with pytest.raises(AssertionError):
+        ops.warp_views_and_blend_next(rgba, [view], mpi, img, dp, 2, rgba, out_flows_next=flows)            # same stack read and written
+    arr = (_lib.MpfWarpView * 1)()
+    arr[0] = _lib.MpfWarpView(dp.data_ptr(), None, view["out"]["rgb"].data_ptr(), None, None, None, None)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())    # noqa: E731
+    call = lambda out_rgba, P, fl, s=S, h=H, w=W: lib.mpf_warp_views_and_blend_next(   # noqa: E731
+        p(rgba), arr, 1, p(mpi), p(img), p(dp), P, 200.0, out_rgba, fl, None, None, None, None, None, s, h, w, None)
+    assert call(p(rgba), 2, p(flows)) == 10001 and b"different buffers" in lib.mpf_last_error()
+    assert call(p(rgba2), 2, None) == 10001 and b"flows" in lib.mpf_last_error()                                # P > 0 without a flows output
+    assert call(p(rgba2), 3, p(flows)) == 10001
+    assert call(p(rgba2), 2, p(flows), 4000, 1024, 1024) == 10001 and b"4 GiB" in lib.mpf_last_error()        # 64 GiB stack: use the separate calls
+    assert call(p(rgba2), 2, p(flows)) == 0                                                                    # and the well-formed call goes through
+    torch.cuda.synchronize()
+    rgb3, sig = torch.rand((S, 3, H, W), device=dev), torch.rand((S, H, W), device=dev)
+    o = torch.empty((3, H, W), device=dev)
+    assert lib.mpf_warp_composite_split(p(rgb3), None, None, p(dp), S, H, W, p(o), None, None, None, None, None) == 10001
+    assert lib.mpf_warp_composite_split(p(rgb3), p(sig), None, p(dp), S, H, W, p(o), None, p(o), None, None, None) == 10001      # objmask without quads
+    assert lib.mpf_src_flow(p(sig), p(dp), 0, S, H, W, 200.0, p(flows), None) == 10001 and b"P must be 1 or 2" in lib.mpf_last_error()
+    assert lib.mpf_src_flow(p(sig), p(dp), 2, S, H, W, 200.0, p(flows), None) == 0
+    torch.cuda.synchronize()

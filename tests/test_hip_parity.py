@@ -745,3 +745,32 @@ def test_new_entry_points_reject_bad_arguments(dev):
     assert lib.mpf_src_flow(p(sig), p(dp), 0, S, H, W, 200.0, p(flows), None) == 10001 and b"P must be 1 or 2" in lib.mpf_last_error()
     assert lib.mpf_src_flow(p(sig), p(dp), 2, S, H, W, 200.0, p(flows), None) == 0
     torch.cuda.synchronize()
+
+
+def test_planar_stage_b_never_reads_past_the_tensor(dev, kernel_exp):
+    """The last texel of a planar stack has its east / south bilinear neighbours PAST the end of the tensor; their weight is exactly 0, but
+    0 * NaN is NaN - so whatever lies behind the tensor must not be read (the buffer descriptor ends where the tensor ends and an
+    out-of-range dword reads as 0).  Here the stack is the head of a larger allocation whose remainder is NaN, for both planar forms, with
+    the identity pose (every target pixel samples exactly its own texel, the last one included) and with a random one."""
+    from mpiflow_amd import ops
+    o = kernel_exp
+    S, H, W = 6, 24, 40
+    inp = _inputs(S, H, W, seed=91)
+    d, k_inv = o.plane_depths(inp["disparity"]), o.k_inverse(inp["K"])
+    n4 = S * 4 * H * W
+    buf = torch.full((n4 + 4096,), float("nan"), device=dev)
+    stack = buf[:n4].view(S, 4, H, W)
+    stack.copy_(T(inp["mpi"], dev))
+    b3 = torch.full((S * 3 * H * W + 4096,), float("nan"), device=dev)
+    b1 = torch.full((S * H * W + 4096,), float("nan"), device=dev)
+    rgb3, sig1 = b3[:S * 3 * H * W].view(S, 3, H, W), b1[:S * H * W].view(S, 1, H, W)
+    rgb3.copy_(stack[:, :3])
+    sig1.copy_(stack[:, 3:])
+    inter = N(stack.permute(0, 2, 3, 1).contiguous())
+    eye = np.eye(4, dtype=np.float32)
+    for G in (eye, _poses(o, 4)[1]):
+        _, Hst = o.homographies(G, k_inv, inp["K"], d)
+        want = o.warp_composite(inter, None, Hst, k_inv, G, d)
+        for got in (ops.warp_composite(stack, None, Hst, k_inv, G, d, interleaved=False), ops.warp_composite_split(rgb3, sig1, None, Hst, k_inv, G, d)):
+            assert torch.isfinite(got["rgb"]).all() and torch.isfinite(got["depth"]).all()
+            assert bits_equal(N(got["rgb"]), want["rgb"]) == 0 and bits_equal(N(got["depth"]), want["depth"]) == 0

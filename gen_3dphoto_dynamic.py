@@ -162,6 +162,9 @@ def main(argv=None):
         else:
             dist.init_process_group(backend=backend)
 
+    # the host side of a pair is a few batched 3x3 / 4x4 matrix operations: intra-op threading only adds fork / join latency to them (and the
+    # writer threads want the cores); per-matrix results do not depend on the thread count
+    torch.set_num_threads(1)
     random.seed(opt.seed)                         # gen_3dphoto_dynamic_v2.py:38-39
     np.random.seed(opt.seed)
     K = torch.tensor([[0.58, 0, 0.5], [0, 0.58, 0.5], [0, 0, 1]])      # :42-49

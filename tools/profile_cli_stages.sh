@@ -9,14 +9,14 @@ for d in ("images", "disps", "masks"):
     os.makedirs(os.path.join(base, d))
 rs = np.random.RandomState(0)
 yy, xx = np.mgrid[0:375, 0:1242]
-for i in range(40):
+for i in range(120):
     img = (np.clip(0.5 + 0.25 * np.sin(xx / (17.0 + i)) + 0.25 * np.cos(yy / 23.0) + 0.05 * rs.randn(375, 1242), 0, 1) * 255).astype(np.uint8)
     Image.fromarray(np.stack([img, np.roll(img, 7, 1), np.roll(img, 13, 0)], -1)).save(os.path.join(base, "images", "%04d.png" % i))
     Image.fromarray((255 * (0.1 + 0.8 * yy / 375)).astype(np.uint8)).save(os.path.join(base, "disps", "%04d.png" % i))
     m = np.zeros((375, 1242), np.uint8); m[150:300, 300:600] = 1; m[200:330, 800:1000] = 2
     Image.fromarray(m).save(os.path.join(base, "masks", "%04d.png" % i))
-for env in ({"MPIFLOW_PROFILE": "1"}, {"MPIFLOW_PROFILE": "host"}):
+for env, fill in (({"MPIFLOW_PROFILE": "host"}, "builtin"), ({"MPIFLOW_PROFILE": "host"}, "none"), ({"MPIFLOW_PROFILE": "host", "OMP_NUM_THREADS": "1"}, "builtin"), ({"MPIFLOW_PROFILE": "host", "OMP_NUM_THREADS": "1"}, "none")):
     r = subprocess.run([sys.executable, "gen_3dphoto_dynamic.py", "--base", base, "--out", os.path.join(tmp, "o" + env["MPIFLOW_PROFILE"]), "--ckpt_path", "random:0",
-                        "--model-engine", "hip", "--inpaint", "builtin"], capture_output=True, text=True, env=dict(os.environ, **env))
-    print(env, "\n", "\n".join(l for l in r.stdout.splitlines() if l.startswith("  ") or l.startswith("pairs") or l.startswith("steady")), r.stderr[-500:] if r.returncode else "")
+                        "--inpaint", fill], capture_output=True, text=True, env=dict(os.environ, **env))
+    print(env, fill, "\n", "\n".join(l for l in r.stdout.splitlines() if l.startswith("  ") or l.startswith("pairs") or l.startswith("steady")), r.stderr[-500:] if r.returncode else "")
 PY

@@ -33,3 +33,20 @@ for key, d in rows.items():
         print("    per wave: " + "  ".join("%s %.0f" % (n[9:], sum(d[n]) / len(d[n]) / w) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_MFMA") if n in d))
     print("    " + "  ".join("%s=%.4g" % (n, sum(v) / len(v)) for n, v in sorted(d.items())))
 PY
+# MFMA-busy share per layer: SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
+python - <<PY
+import csv, glob, collections, re
+rows = collections.OrderedDict()
+for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"(k_conv3x3<[^>]*>)", r["Kernel_Name"])
+        if m:
+            rows.setdefault((m.group(1).replace(" ", ""), r.get("Grid_Size", "")), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("\n# MFMA-busy share per conv layer (kernel instance, grid): MFMA busy SIMD-cycles / (kernel cycles x 1024 SIMDs); VALU-active share beside it")
+for key, d in rows.items():
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+        cyc = sum(d["GRBM_GUI_ACTIVE"]) / len(d["GRBM_GUI_ACTIVE"]) / 8.0
+        mf = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(d["SQ_VALU_MFMA_BUSY_CYCLES"])
+        va = sum(d["SQ_ACTIVE_INST_VALU"]) / len(d["SQ_ACTIVE_INST_VALU"]) * 4.0 if "SQ_ACTIVE_INST_VALU" in d else float("nan")
+        print("%-40s grid %-10s  %7.1f us   MFMA busy %5.1f %%   VALU issue %5.1f %%" % (key[0], key[1], cyc / 2400.0, 100.0 * mf / (cyc * 1024.0), 100.0 * va / (cyc * 1024.0)))
+PY

@@ -271,11 +271,16 @@ class PipelinedWorkload:
     i+1 in one heterogeneous-grid launch.  finish() flushes the pipeline (the last pair's stand-alone Stage B)."""
     dynamic = True
 
-    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514):
+    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False):
         self.S, self.H, self.W, self.B, self.N = S, H, W, B, H * W
         K, disp = synth.intrinsics(H, W), synth.plane_disparities(S)
         rng = random.Random(pose_seed)
         self.r = pipeline.OverlappedPairRenderer(S, H, W, dev)
+        # SURVEY 8(d)'s full c3: the moving-object chain of every completed pair runs on a SIDE stream underneath the next pair's launch
+        # (its few small kernels are latency-sized); the main stream waits for it before the slot's source frame is rewritten
+        self.mo = MovingObjectChain(H, W, K, dev, seed0) if moving_object else None
+        self.side = torch.cuda.Stream(dev) if moving_object else None
+        self.side_done = {}
         self.images, self.preps = [], []
         for i in range(B):
             self.images.append(make_image(S, H, W, dev, seed=seed0 + i))
@@ -303,11 +308,33 @@ class PipelinedWorkload:
         self.timed = timed
         for i in idx:
             mpi, img = self.images[i % self.B]
+            done_slot = self.r.pending_slot                                    # the pair this push completes (None for the first)
+            if self.mo is not None:
+                nxt = self.r.slots[self.r._next]                               # the slot this push's Stage A+C role is about to rewrite
+                ev = self.side_done.pop(id(nxt), None)
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
             self.r.push(mpi, img, self.preps[i % self.B], self.om, out=self.mix)
+            if self.mo is not None and done_slot is not None:
+                self._side_chain(done_slot)
         return len(idx)
 
+    def _side_chain(self, slot):
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            self.mo.run(slot["src_u8"], self.om)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.side_done[id(slot)] = ev
+
     def finish(self):
+        slot = self.r.pending_slot
         self.r.flush()
+        if self.mo is not None and slot is not None:
+            self._side_chain(slot)
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def rooflines(self):
         t = float(np.mean([a.elapsed_time(b) for a, b in self.ev])) * 1e-3
@@ -382,7 +409,7 @@ def cpu_baseline(S, H, W, pairs):
 def sub_record(name, S, H, W, B, dev, dynamic, steps, multi_view=True, pipelined=False, moving_object=False):
     """One workload outside the timed region (rank 0, N=1): pairs/s plus per-kernel roofline entries from HIP-event brackets."""
     if pipelined:
-        w = PipelinedWorkload(S, H, W, B, dev, seed0=500)
+        w = PipelinedWorkload(S, H, W, B, dev, seed0=500, moving_object=moving_object)
     else:
         w = Workload(S, H, W, B, dev, dynamic, seed0=500, multi_view=multi_view, moving_object=moving_object)
     w.step(False)
@@ -580,6 +607,8 @@ def main():
                 sub.append(sub_record("c3 pipelined: Stage B of pair i + Stage A+C of pair i+1 per launch", 64, 640, 960, 4, dev, True, 5, pipelined=True))
             sub.append(sub_record("c3 + moving-object chain (SURVEY 8(d)'s full c3): serial pair + depth->flow projection, forward warp, masks on disp = rand",
                                   64, 640, 960, 4, dev, True, 5, moving_object=True))
+            sub.append(sub_record("c3 pipelined + moving-object chain on a side stream (SURVEY 8(d)'s full c3 in the throughput form)", 64, 640, 960, 4, dev, True, 5,
+                                  pipelined=True, moving_object=True))
             sub.append(sub_record("c2: BASELINE configs[1], 64x640x960 camera-only pair", 64, 640, 960, 4, dev, False, 5))
             sub.append(sub_record("c1: BASELINE configs[0] shape, 32x384x512 dynamic pair, pipelined (on the GPU: the product has no CPU path)", 32, 384, 512, 8, dev, True, 10, pipelined=True))
             sub.append(sub_record("c1 serial", 32, 384, 512, 8, dev, True, 10))

@@ -120,7 +120,7 @@ def test_single_gpu_line_has_sub_records_and_names_the_dynamic_pair():
     assert ac["algorithmic_bytes_per_launch"] == 28.0 * S * N + 12.0 * N + 16.0 * N and ac["layout_bytes_per_launch"] == 32.0 * S * N + 12.0 * N + 16.0 * N
     assert 0 < ac["frac"] < ac["frac_on_layout_bytes"] < 1 and sb["algorithmic_bytes_per_launch"] == 32.0 * S * N and 0.05 < sb["frac"] < 1
     names = [s_["workload"] for s_ in d["sub"]]
-    for tag in ("c3 serial", "c3 + moving-object chain", "c2", "c1", "c5"):
+    for tag in ("c3 serial", "c3 + moving-object chain", "c3 pipelined + moving-object chain", "c2", "c1", "c5"):
         assert any(n.startswith(tag) for n in names), tag
     for s_ in d["sub"]:
         assert s_["pairs_per_s"] > 0 and ("pair" in s_ or (s_["stage_b"]["frac"] > 0 and s_["stage_ac"]["frac"] > 0))

@@ -350,9 +350,10 @@ def host_side_group(group=None):
     global _side_group
     if dist.get_backend(group) == "gloo":
         return group
-    if _side_group is None:
-        _side_group = dist.new_group(backend="gloo")
-    return _side_group
+    world = dist.group.WORLD                                  # a side group belongs to ONE default group: never reuse it after a re-init
+    if _side_group is None or _side_group[0] is not world:
+        _side_group = (world, dist.new_group(backend="gloo"))
+    return _side_group[1]
 
 
 def exchange_device_records(local_index, group=None):

@@ -183,6 +183,8 @@ class OverlappedPairRenderer(_PairHostSide):
                       for _ in range(2)]
         self._next, self._pending = 0, None
         self.on_fused = None                                         # optional hook(callable launching) -> used by bench.py to bracket with events
+        # the overlapped launch addresses the stack through 32-bit buffer offsets: stacks of 4 GiB and more take the two separate launches
+        self.fusable = S * H * W * 16 < (1 << 32)
 
     def _views(self, slot, prep):
         return [dict(dparams=prep["warp"][v], quads=slot["quads"][v], out=slot["views"][v]) for v in range(2)]
@@ -202,6 +204,12 @@ class OverlappedPairRenderer(_PairHostSide):
         if self._pending is None:
             ops.src_blend_flow(mpi, image, out_rgba=slot["rgba"], out_flows=slot["flows"], dparams=prep["blend"], P=2, src_u8=slot["src_u8"],
                                obj_mask=obj_mask, quads=slot["quads"][0], quads_complement=slot["quads"][1], cum_mask=cum_mask)
+        elif not self.fusable:
+            pend = self._pending
+            ops.warp_composite_views(pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), interleaved=2)
+            ops.src_blend_flow(mpi, image, out_rgba=slot["rgba"], out_flows=slot["flows"], dparams=prep["blend"], P=2, src_u8=slot["src_u8"],
+                               obj_mask=obj_mask, quads=slot["quads"][0], quads_complement=slot["quads"][1], cum_mask=cum_mask)
+            done = self._finish(pend)
         else:
             pend = self._pending
             launch = lambda: ops.warp_views_and_blend_next(                                                   # noqa: E731

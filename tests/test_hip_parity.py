@@ -672,6 +672,19 @@ def test_overlapped_pair_renderer_equals_render_pair(dev, kernel_exp, S, H, W, n
             assert done[0] is outs[i - 1][0]
     last = ovl.flush()
     assert last[0] is outs[-1][0] and ovl.flush() is None
+    # stacks of 4 GiB and more cannot take the overlapped launch (32-bit buffer offsets): the renderer then issues the two launches one
+    # after the other - same interface, same results (forced here on a small shape)
+    sep = pipeline.OverlappedPairRenderer(S, H, W, dev)
+    assert sep.fusable
+    sep.fusable = False
+    outs2 = []
+    for i, (inp, G_cam, G_dyn) in enumerate(items):
+        done = sep.push(T(inp["mpi"], dev), T(inp["image"], dev), sep.prepare(inp["K"], inp["disparity"], [G_cam, G_dyn]), T(inp["obj_mask"], dev))
+        if done is not None:
+            outs2.append(done)
+    outs2.append(sep.flush())
+    for a, b in zip(outs, outs2):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
     for (inp, G_cam, G_dyn), out in zip(items, outs):
         ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
         for k, t in zip(("flow_mix", "frame_mix", "fill_mask"), out):

@@ -630,11 +630,15 @@ struct MpfViewSet { MpfWarpView v[MPF_MAX_VIEWS]; };
 
 template <bool HAS_MASK, int NL, int TW, int TH, int WPS, bool TP>
 __global__ void __launch_bounds__(TW *TH, WPS)
-k_warp_composite_views(const float *__restrict__ rgba, const MpfViewSet vs, const unsigned V, int S, int H, int W)
+k_warp_composite_views(const float *__restrict__ rgba, const MpfViewSet vs, const unsigned V, int S, int H, int W, const unsigned view_shift)
 {
     const unsigned l = mpf_xcd_remap(blockIdx.x, gridDim.x);
     const unsigned view = l % V;
-    const unsigned tile = mpf_strip_order(l / V, (W + TW - 1) / TW, (H + TH - 1) / TH);
+    // view_shift (mpf_tune("view_shift", k), default 8): the odd views walk the strip-major tile sequence k positions ahead of the even ones
+    // (see g_view_shift).  A rotation of the sequence is a bijection: every tile of every view is still rendered exactly once.
+    const unsigned tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = tiles_x * tiles_y;
+    const unsigned seq = (view & 1u) ? (l / V + view_shift) % ntiles : l / V;
+    const unsigned tile = mpf_strip_order(seq, tiles_x, tiles_y);
     const MpfWarpView &w = vs.v[view];
     mpf_wc2_select<HAS_MASK, NL, TW, TH, TP>(rgba, w.d_mask_quads, w.d_params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask,
                                              w.d_rgb_u8_bgr, tile);
@@ -991,13 +995,20 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
     return launch_warp_composite<false, false>(d_rgba, nullptr, d_params, S, H, W, d_rgb, d_depth, nullptr, d_tgt_mask, d_rgb_u8_bgr, st);
 }
 
+// mpf_tune("view_shift", k), scheduling only: the odd views of a multi-view launch walk the tile sequence k positions ahead of the even ones.
+// With k = 0 the two views of a tile are dispatched back to back, run in lockstep and miss on the same lines at the same moment; a small offset
+// (any of +-4 .. +-32, or a whole strip) takes 5-7 % off the two-view launch of bench.py's serial c3 pairs (302-312 -> 288-291 us, the same for
+// every sign and size tried: it is the de-synchronisation that helps, not an alignment of the footprints) and 3 % off the pair launch's L2-miss
+// traffic at unchanged time; neutral (+-1 %) for the fixed-pose launches of tools/bench_stage_b_views.py (profiles/r3/stage_b_view_shift.log).
+static int g_view_shift = 8;
+
 template <bool HAS_MASK>
 static int launch_views(bool tp, const float *rgba, const MpfViewSet &vs, int V, int S, int H, int W, hipStream_t st)
 {
     constexpr int TW = 32, TH = 8, WPS = 5;
     const unsigned tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     dim3 grid(tiles * (unsigned)V), block(TW * TH);
-#define MPF_WCV(NLv, TPv) hipLaunchKernelGGL((k_warp_composite_views<HAS_MASK, NLv, TW, TH, WPS, TPv>), grid, block, 0, st, rgba, vs, (unsigned)V, S, H, W)
+#define MPF_WCV(NLv, TPv) hipLaunchKernelGGL((k_warp_composite_views<HAS_MASK, NLv, TW, TH, WPS, TPv>), grid, block, 0, st, rgba, vs, (unsigned)V, S, H, W, (unsigned)g_view_shift % tiles)
     if (S < 256) { if (tp) MPF_WCV(2, true); else MPF_WCV(2, false); }
     else         { if (tp) MPF_WCV(3, true); else MPF_WCV(3, false); }
 #undef MPF_WCV
@@ -1535,7 +1546,7 @@ MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const
 template <bool HAS_MASK, int NL, int P, bool ACT, int DEPTH>
 __global__ void __launch_bounds__(256, 5)
 k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsigned V, const MpfSbfArgs ac, const int S, const int H, const int W,
-               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate)
+               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate, const unsigned view_shift)
 {
     constexpr int TW = 32, TH = 8;
     const unsigned xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;          // the k-th workgroup of this XCD
@@ -1555,7 +1566,9 @@ k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsi
         else if (((ablate >> 4) & 3) == 3) __builtin_amdgcn_s_setprio(3);
         const unsigned l = mpf_xcd_remap(jb, nB);
         const unsigned view = l % V;
-        const unsigned tile = mpf_strip_order(l / V, (W + TW - 1) / TW, (H + TH - 1) / TH);
+        const unsigned tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = tiles_x * tiles_y;
+        const unsigned seq = (view & 1u) ? (l / V + view_shift) % ntiles : l / V;        // see k_warp_composite_views
+        const unsigned tile = mpf_strip_order(seq, tiles_x, tiles_y);
         const MpfWarpView &w = vs.v[view];
         mpf_wc2_select<HAS_MASK, NL, TW, TH, true>(rgba_b, w.d_mask_quads, w.d_params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask,
                                                    w.d_rgb_u8_bgr, tile);
@@ -1574,9 +1587,9 @@ static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V,
     const unsigned KB = (nB + 7) / 8, KA = (nA + 7) / 8;
     dim3 grid(8u * (KB + KA)), block(256);
     if (g_ovl_depth == 4)
-        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate);
+        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles);
     else
-        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 8>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate);
+        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 8>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles);
     return mpf_launch_status("k_pair_overlap");
 }
 
@@ -1643,6 +1656,7 @@ extern "C" int mpf_tune(const char *key, int value)
     if (key && !strcmp(key, "stage_b")) { g_stage_b_variant = value; return 0; }
     if (key && !strcmp(key, "ovl_depth")) { g_ovl_depth = (value == 8) ? 8 : 4; return 0; }
     if (key && !strcmp(key, "ovl_ablate")) { g_ovl_ablate = value; return 0; }
+    if (key && !strcmp(key, "view_shift")) { g_view_shift = value < 0 ? 0 : value; return 0; }
     if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
     mpf_set_error("mpf_tune: unknown key");
     return MPF_ERR_BAD_ARGUMENT;

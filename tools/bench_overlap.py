@@ -33,6 +33,8 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 S, H, W, B = a.planes, a.height, a.width, a.images
 lib = _lib.load()
+if os.environ.get("MPF_VIEW_SHIFT"):                      # experiment: odd views walk the tile sequence this many positions ahead (tools/bench_view_shift.py)
+    _lib.check(lib.mpf_tune(b"view_shift", int(os.environ["MPF_VIEW_SHIFT"])))
 
 
 def serial(n_streams):

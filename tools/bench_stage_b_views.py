@@ -28,6 +28,8 @@ p.add_argument("--variants", type=str, default="1,20", help="mpf_tune stage_b va
 a = p.parse_args()
 
 lib = _lib.load()
+if os.environ.get("MPF_VIEW_SHIFT"):
+    _lib.check(lib.mpf_tune(b"view_shift", int(os.environ["MPF_VIEW_SHIFT"])))
 dev = torch.device("cuda:0")
 S, H, W = a.planes, a.height, a.width
 g = torch.Generator(device=dev).manual_seed(0)

@@ -15,8 +15,10 @@ for i in range(120):
     Image.fromarray((255 * (0.1 + 0.8 * yy / 375)).astype(np.uint8)).save(os.path.join(base, "disps", "%04d.png" % i))
     m = np.zeros((375, 1242), np.uint8); m[150:300, 300:600] = 1; m[200:330, 800:1000] = 2
     Image.fromarray(m).save(os.path.join(base, "masks", "%04d.png" % i))
-for env, fill in (({"MPIFLOW_PROFILE": "host"}, "builtin"), ({"MPIFLOW_PROFILE": "host"}, "none"), ({"MPIFLOW_PROFILE": "host", "OMP_NUM_THREADS": "1"}, "builtin"), ({"MPIFLOW_PROFILE": "host", "OMP_NUM_THREADS": "1"}, "none")):
-    r = subprocess.run([sys.executable, "gen_3dphoto_dynamic.py", "--base", base, "--out", os.path.join(tmp, "o" + env["MPIFLOW_PROFILE"]), "--ckpt_path", "random:0",
+import json
+variants = json.loads(os.environ.get("VARIANTS", "null")) or [[{"MPIFLOW_PROFILE": "host"}, "builtin"], [{"MPIFLOW_PROFILE": "host"}, "none"]]
+for env, fill in variants:
+    r = subprocess.run([sys.executable, "gen_3dphoto_dynamic.py", "--base", base, "--out", os.path.join(tmp, "o"), "--ckpt_path", "random:0",
                         "--inpaint", fill], capture_output=True, text=True, env=dict(os.environ, **env))
     print(env, fill, "\n", "\n".join(l for l in r.stdout.splitlines() if l.startswith("  ") or l.startswith("pairs") or l.startswith("steady")), r.stderr[-500:] if r.returncode else "")
 PY

@@ -79,3 +79,27 @@ def test_product_never_imports_the_oracle():
         p = os.path.join(ROOT, f)
         if os.path.exists(p):
             assert not pat.search(open(p).read())
+
+
+def test_no_wide_buffer_store_uses_a_register_soffset(built, tmp_path):
+    """gfx950: a buffer_store_dwordx3/x4 whose soffset is an SGPR, followed at once by a VALU write of its data registers, stores the NEW
+    values in lanes 12-15 of every 16 (hipcc's hazard recogniser exempts that form; DESIGN.md §5 - found by the every-pixel test at
+    64 x 640 x 960, invisible at small sizes).  The kernels keep the plane offset in the VGPR offset; this pins it in the BUILT code
+    objects, so a later edit (or compiler) that moves a uniform offset into soffset is caught on the CPU."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    so = tmp_path / "lib.so"
+    shutil.copy(built.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", so.name], cwd=tmp_path, check=True, capture_output=True)
+    objs = [p for p in tmp_path.iterdir() if "amdgcn" in p.name and p.stat().st_size > 0]
+    assert objs, "no gfx950 code object found in the library"
+    n_wide = 0
+    for o in objs:
+        text = subprocess.run([objdump, "-d", o.name], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"buffer_store_dwordx[34] (v\[\d+:\d+\]), (\w+), (s\[\d+:\d+\]), (\S+)", text):
+            n_wide += 1
+            assert not m.group(4).startswith("s"), "wide buffer store with a register soffset: %s" % m.group(0)
+    assert n_wide > 100                                     # the Stage A+C role of the overlapped launch stores this way

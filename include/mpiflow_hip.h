@@ -151,6 +151,14 @@ int mpf_merge(const float *d_frame, const float *d_frame_dyn, const float *d_mas
               const float *d_flow, const float *d_flow_dyn, const float *d_obj_mask, float thresh, int H, int W,
               float *d_flow_mix, uint8_t *d_frame_mix, uint8_t *d_fill_mask, void *stream);
 
+/* The depth-ordered variant of Stage D's frame ("utils/utils copy.py":278-303, the reference's older per-image module): frame_mix as
+ * mpf_merge computes it, except that where both layers cover the pixel (both masks non-zero) and depth > depth_dyn the dynamic layer's
+ * pixel is taken.  depths [H,W] are the two views' composited depths (mpf_warp_composite's d_depth).
+ * -> d_frame_mix_depth [H,W,3] u8 BGR; d_depth_mask [H,W] u8 (optional, may be NULL): 1 where the dynamic layer was picked. */
+int mpf_merge_depth_ordered(const float *d_frame, const float *d_frame_dyn, const float *d_mask, const float *d_mask_dyn,
+                            const float *d_depth, const float *d_depth_dyn, float thresh, int H, int W,
+                            uint8_t *d_frame_mix_depth, uint8_t *d_depth_mask, void *stream);
+
 /* Built-in hole fill used when OpenCV is absent (NOT cv2.inpaint's Navier-Stokes / Telea, utils/utils.py:284-286,
  * moving_obj.py:162; row A13 is parity-unpinned): onion peel - pass k gives every hole pixel that touches
  * a pixel known after pass k-1 the rounded mean of those 8-neighbours.  In place on d_img u8 [H,W,3]; d_hole u8 [H,W]

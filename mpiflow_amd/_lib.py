@@ -57,6 +57,7 @@ SIGNATURES = {
     "mpf_warp_composite_views": (c_i, [c_p, c_i, ctypes.POINTER(MpfWarpView), c_i, c_i, c_i, c_i, c_p]),
     "mpf_warp_views_and_blend_next": (c_i, [c_p, ctypes.POINTER(MpfWarpView), c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "mpf_merge": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "mpf_merge_depth_ordered": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p]),
     "mpf_fill_holes_workspace": (c_sz, [c_i, c_i]),
     "mpf_fill_holes": (c_i, [c_p, c_p, c_i, c_i, c_p, c_sz, c_p]),
     "mpf_prepare_inputs": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),

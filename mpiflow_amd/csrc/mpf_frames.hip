@@ -193,6 +193,54 @@ extern "C" int mpf_fill_holes(uint8_t *d_img, uint8_t *d_hole, int H, int W, voi
     return mpf_launch_status("k_fill_peel");
 }
 
+// Depth-ordered layer pick of the reference's older per-image module ("utils/utils copy.py":283-303): where BOTH
+// rendered layers cover a target pixel (np.logical_and(mask, mask_dync): both masks NON-ZERO, not thresholded) and the object layer lies
+// behind the background layer (depth > depth_dync), the merged frame takes the dynamic layer's pixel instead.  Everything else is
+// Stage D's frame_mix (utils/utils.py:237-276; same quantisation, whitening and select as k_merge).
+namespace {
+__device__ __forceinline__ uint8_t frames_to_u8(float v)            // np.clip(np.round(x*255), 0, 255).astype(uint8), as mpf_math.h:mpf_to_u8
+{
+    return (uint8_t)fminf(fmaxf(rintf(v * 255.0f), 0.0f), 255.0f);
+}
+
+__global__ void __launch_bounds__(256)
+k_merge_depth_ordered(const float *__restrict__ frame, const float *__restrict__ frame_dyn, const float *__restrict__ mask,
+                      const float *__restrict__ mask_dyn, const float *__restrict__ depth, const float *__restrict__ depth_dyn, float th,
+                      int64_t N, uint8_t *__restrict__ frame_mix_depth, uint8_t *__restrict__ depth_mask)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float m = mask[n], md = mask_dyn[n], z = depth[n], zd = depth_dyn[n];
+    float fr[3], fd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        fr[c] = frame[c * N + n];
+        fd[c] = frame_dyn[c * N + n];
+    }
+    const bool sel = m >= th;                                           // "utils copy.py":281-282
+    const bool pick = (z > zd) && (m != 0.0f) && (md != 0.0f);          // :295, :301 (NaN masks are truthy, NaN depths compare false, as numpy)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                                       // BGR
+        const uint8_t a = (m < th) ? (uint8_t)255 : frames_to_u8(fr[2 - c]);       // :278
+        const uint8_t b = (md < th) ? (uint8_t)255 : frames_to_u8(fd[2 - c]);      // :279
+        frame_mix_depth[3 * n + c] = pick ? b : (sel ? a : b);          // :302-303
+    }
+    if (depth_mask) depth_mask[n] = pick ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int mpf_merge_depth_ordered(const float *d_frame, const float *d_frame_dyn, const float *d_mask, const float *d_mask_dyn,
+                                       const float *d_depth, const float *d_depth_dyn, float thresh, int H, int W,
+                                       uint8_t *d_frame_mix_depth, uint8_t *d_depth_mask, void *stream)
+{
+    MPF_REQUIRE(d_frame && d_frame_dyn && d_mask && d_mask_dyn && d_depth && d_depth_dyn && d_frame_mix_depth && H >= 1 && W >= 1,
+                "mpf_merge_depth_ordered: bad argument");
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_merge_depth_ordered, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_frame, d_frame_dyn,
+                       d_mask, d_mask_dyn, d_depth, d_depth_dyn, thresh, N, d_frame_mix_depth, d_depth_mask);
+    return mpf_launch_status("k_merge_depth_ordered");
+}
+
 extern "C" int mpf_png_filter_up(const uint8_t *d_bgr, int H, int W, uint8_t *d_scanlines, void *stream)
 {
     MPF_REQUIRE(d_bgr && d_scanlines && H >= 1 && W >= 1 && H <= 65535, "mpf_png_filter_up: bad argument");

@@ -280,6 +280,25 @@ def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.9
 
 
 @_on_device
+def merge_depth_ordered(frame, frame_dyn, mask, mask_dyn, depth, depth_dyn, thresh=0.99, out=None, want_depth_mask=False):
+    """The depth-ordered frame of the reference's older module ("utils/utils copy.py":278-303): Stage D's frame_mix, except that where both
+    layers cover the pixel (both masks non-zero) and depth > depth_dyn the dynamic layer's pixel is taken.
+    -> frame_mix_depth [H,W,3] u8 BGR (, depth_mask [H,W] u8 when want_depth_mask)."""
+    import numpy as np
+    lib = _lib.load()
+    frame = _dev(frame, "frame")
+    _, H, W = frame.shape
+    dev = frame.device
+    fmd = out if out is not None else torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    dm = torch.empty((H, W), dtype=torch.uint8, device=dev) if want_depth_mask else None
+    args = [_dev(frame_dyn, "frame_dyn").reshape(3, H, W), _dev(mask, "mask").reshape(H, W), _dev(mask_dyn, "mask_dyn").reshape(H, W),
+            _dev(depth, "depth").reshape(H, W), _dev(depth_dyn, "depth_dyn").reshape(H, W)]
+    _lib.check(lib.mpf_merge_depth_ordered(_ptr(frame), *[_ptr(a) for a in args], float(np.float32(thresh)), H, W, _ptr(fmd), _ptr(dm),
+                                           _stream()), "mpf_merge_depth_ordered")
+    return (fmd, dm) if want_depth_mask else fmd
+
+
+@_on_device
 def fill_holes(img_HW3_u8, hole_HW_u8, out=None, hole_out=None, workspace=None):
     """Built-in deterministic hole fill (onion peel; NOT OpenCV's algorithm - see DESIGN.md, row A13).  Stream-ordered, no
     host synchronisation.  Returns the filled copy (`out`); `hole_out` (optional) receives the holes still open."""

@@ -73,7 +73,7 @@ class _PairHostSide:
 class PairRenderer(_PairHostSide):
     """Preallocated fused renderer for one (S, H, W) on one device."""
 
-    def __init__(self, S, H, W, device, n_views=2):
+    def __init__(self, S, H, W, device, n_views=2, with_depth=False):
         self.S, self.H, self.W, self.device = S, H, W, torch.device(device)
         f32 = torch.float32
         dev = self.device
@@ -83,6 +83,9 @@ class PairRenderer(_PairHostSide):
         # leaving them out selects the leaner Stage B body
         self.views = [dict(rgb=torch.empty((3, H, W), dtype=f32, device=dev), objmask=torch.empty((H, W), dtype=f32, device=dev),
                            rgb_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev)) for _ in range(n_views)]
+        if with_depth:                       # the depth-ordered variant ("utils/utils copy.py":295-303) reads both views' composited depth
+            for v in self.views:
+                v["depth"] = torch.empty((H, W), dtype=f32, device=dev)
         self.quads = [torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)]    # obj_mask, 1 - obj_mask
         self.src_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         self.n_views = n_views
@@ -255,12 +258,14 @@ def hard_flows(mpi_S4HW, disparity_S, K, poses):
 
 
 def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, thresh=MASK_THRESH, renderer=None, cum_mask=None,
-                hard_flow=False, reuse_blend=False):
+                hard_flow=False, reuse_blend=False, depth_ordered=False):
     """Everything render_3dphoto_dynamic does up to the inputs of cv2.inpaint (reference utils/utils.py:159-283), for
-    explicit poses: G_cam renders with obj_mask, G_dyn with 1 - obj_mask (sic - SURVEY §3.2).  Device tensors in/out."""
+    explicit poses: G_cam renders with obj_mask, G_dyn with 1 - obj_mask (sic - SURVEY §3.2).  Device tensors in/out.
+    depth_ordered: also the older module's depth-ordered frame ("utils/utils copy.py":295-303) as `frame_mix_depth` (+ `depth_mask`);
+    the renderer then needs the views' depth (PairRenderer(with_depth=True))."""
     mpi = mpi_S4HW
     S, _, H, W = mpi.shape
-    r = renderer or PairRenderer(S, H, W, mpi.device)
+    r = renderer or PairRenderer(S, H, W, mpi.device, with_depth=depth_ordered)
     om = obj_mask_HW.reshape(H, W).to(torch.float32)
     prep = r.prepare(K, disparity_S, [G_cam, G_dyn])
     flows, views = r.run(mpi, image_3HW.reshape(3, H, W), prep, om, cum_mask=cum_mask, reuse_blend=reuse_blend)
@@ -269,8 +274,15 @@ def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, 
         flows = hard_flows(mpi, disparity_S, K, [G_cam, G_dyn])
     flow_mix, frame_mix, fill = ops.merge(views[0]["rgb"], views[1]["rgb"], views[0]["objmask"], views[1]["objmask"],
                                           flows[0], flows[1], om, thresh)
-    return dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill, src_np=r.src_u8,
-                view_cam=views[0], view_dyn=views[1], flows=flows, rgba=r.rgba)
+    out = dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill, src_np=r.src_u8,
+               view_cam=views[0], view_dyn=views[1], flows=flows, rgba=r.rgba)
+    if depth_ordered:
+        if views[0].get("depth") is None or views[1].get("depth") is None:
+            raise ValueError("depth_ordered needs a PairRenderer(with_depth=True)")
+        out["frame_mix_depth"], out["depth_mask"] = ops.merge_depth_ordered(
+            views[0]["rgb"], views[1]["rgb"], views[0]["objmask"], views[1]["objmask"], views[0]["depth"], views[1]["depth"], thresh,
+            want_depth_mask=True)
+    return out
 
 
 # ---- multi-GPU: image sharding + end-of-batch statistics ------------------------------------------------------------

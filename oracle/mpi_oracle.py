@@ -304,6 +304,26 @@ def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.9
     return flow_mix, frame_mix, fill
 
 
+def merge_depth_ordered(frame, frame_dyn, mask, mask_dyn, depth, depth_dyn, thresh=0.99):
+    """The depth-ordered frame of the reference's older module, line by line ("utils/utils copy.py":240-253 quantisation, :278-282 merge,
+    :295 mix_mask, :301-303 pick).  numpy, as the reference.  -> (frame_mix_depth [H,W,3] u8 BGR, depth_mask [H,W] bool)"""
+    def u8_bgr(f):
+        f = np.transpose(np.asarray(f, np.float32), (1, 2, 0))
+        return np.clip(np.round(f * 255), a_min=0, a_max=255).astype(np.uint8)[:, :, [2, 1, 0]]
+    th = thresh
+    mask, mask_dyn = np.asarray(mask, np.float32), np.asarray(mask_dyn, np.float32)
+    frame_np, frame_dync_np = u8_bgr(frame), u8_bgr(frame_dyn)
+    frame_np[mask < th] = 255
+    frame_dync_np[mask_dyn < th] = 255
+    frame_mix = frame_dync_np.copy()
+    frame_mix[mask >= th] = frame_np[mask >= th]
+    mix_mask = np.logical_and(mask, mask_dyn).astype(np.uint8)
+    depth_mask = np.logical_and(np.asarray(depth) > np.asarray(depth_dyn), mix_mask)
+    frame_mix_depth = frame_mix.copy()
+    frame_mix_depth[depth_mask] = frame_dync_np[depth_mask]
+    return frame_mix_depth, depth_mask
+
+
 def render_pair(image_3HW, obj_mask_HW, mpi_S4HW, disparity_S, K, G_cam, G_dyn, thresh=0.99, exact_xyz=False):
     """The whole of render_3dphoto_dynamic (utils/utils.py:159-288) up to the inputs of cv2.inpaint, for given
     poses: cam pose G_cam renders with obj_mask, dynamic pose G_dyn with 1 - obj_mask (sic)."""

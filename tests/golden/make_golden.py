@@ -455,6 +455,55 @@ def gen_input_stage(seed=41):
     save("input_stage", **arrays)
 
 
+def gen_copy_variant(name="copy_variant", cases=((8, 96, 128, "smooth", 51, 71), (12, 72, 96, "white", 52, 70))):
+    """The reference's OLDER per-image module, "utils/utils copy.py" (own pose constants, :121-160; depth-ordered frame, :295-303): its
+    render_3dphoto_dynamic end to end under random.seed, with what it hands to its two cv2.inpaint calls (:309-315) - the merged frame
+    and the depth-ordered frame - and the two views' depths it compares."""
+    import tempfile
+    V = ref_harness.variant_utils().copy
+    arrays = dict(n_cases=len(cases))
+    for ci, (S, H, W, kind, seed, pose_seed) in enumerate(cases):
+        inp = synth.make_inputs(S, H, W, seed=seed, kind=kind)
+        # a large binary object (the synthetic default is a small soft box): the depth-ordered pick only changes pixels where the object
+        # layer's rendered mask reaches the threshold AND the background layer's is non-zero, i.e. in a band along the object's outline
+        box = np.zeros((H, W), np.float32)
+        box[H // 5:4 * H // 5, W // 6:5 * W // 6] = 1.0
+        inp["obj_mask"] = box
+        mpi, disp = torch.from_numpy(inp["mpi"])[None], torch.from_numpy(inp["disparity"])[None]
+        K, img = torch.from_numpy(inp["K"])[None], torch.from_numpy(inp["image"])[None]
+        om = torch.from_numpy(inp["obj_mask"])[None, None]
+        random.seed(pose_seed)
+        G_dyn = V.generate_random_pose()
+        G_cam = V.generate_random_pose(base_motions=[0, 0, 0])
+        seen, real = [], V.render_novel_view_dynamic
+
+        def spy(*a, **k):
+            out = real(*a, **k)
+            seen.append(out)
+            return out
+        V.render_novel_view_dynamic = spy
+        random.seed(pose_seed)
+        ref_harness.captured.clear()
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                flow_mix, src_np, inpainted, res = V.render_3dphoto_dynamic(img, om, None, mpi, disp, K, K, data_path=d, name="golden")
+        finally:
+            V.render_novel_view_dynamic = real
+        calls = ref_harness.captured["inpaint_calls"]
+        assert len(calls) == 2 and len(seen) == 2 and np.array_equal(calls[0]["mask"], calls[1]["mask"])
+        pre = "c%d_" % ci
+        arrays.update({pre + "S": S, pre + "H": H, pre + "W": W, pre + "kind": kind, pre + "seed": seed, pre + "pose_seed": pose_seed,
+                       pre + "mpi": inp["mpi"], pre + "disparity": inp["disparity"], pre + "image": inp["image"], pre + "obj_mask": inp["obj_mask"],
+                       pre + "K": inp["K"], pre + "G_cam": G_cam.numpy(), pre + "G_dyn": G_dyn.numpy(), pre + "flow_mix": flow_mix,
+                       pre + "src_np": src_np, pre + "frame_mix": calls[0]["img"], pre + "fill_mask": calls[0]["mask"].astype(np.uint8),
+                       pre + "frame_mix_depth": calls[1]["img"],
+                       pre + "cam_rgb": seen[0][0][0].numpy(), pre + "cam_depth": seen[0][1][0, 0].numpy(), pre + "cam_objmask": seen[0][3][0, 0].numpy(),
+                       pre + "dyn_rgb": seen[1][0][0].numpy(), pre + "dyn_depth": seen[1][1][0, 0].numpy(), pre + "dyn_objmask": seen[1][3][0, 0].numpy()})
+        n_pick = int((calls[1]["img"] != calls[0]["img"]).any(-1).sum())
+        print("   case %d: %d x %d x %d %s: depth-ordered frame differs from the merged one on %d px" % (ci, S, H, W, kind, n_pick))
+    save(name, **arrays)
+
+
 JOBS = {
     "tiny": lambda: (gen_small("tiny_white", 8, 32, 48, "white", 1, 7, True),
                      gen_small("tiny_smooth", 8, 32, 48, "smooth", 2, 8, True)),
@@ -480,6 +529,7 @@ JOBS = {
     "geometry": gen_geometry,
     "model": gen_model,
     "hard": gen_hard_flow,
+    "copy": gen_copy_variant,
 }
 
 if __name__ == "__main__":

@@ -42,6 +42,7 @@ def _install_cv2_stub():
     def inpaint(img, mask, radius, flags):
         captured["inpaint"] = dict(img=np.array(img, copy=True), mask=np.array(mask, copy=True),
                                    radius=radius, flags=flags)
+        captured.setdefault("inpaint_calls", []).append(captured["inpaint"])     # "utils/utils copy.py" fills two frames per pair
         return np.array(img, copy=True)
 
     def dilate(img, kernel, iterations=1):

@@ -526,3 +526,58 @@ def test_full_size_properties_c5(dev):
     v = ops.warp_composite(rgba, None, H_st, k_inv, G, d, interleaved=2)
     assert float(v["tgt_mask"].min()) == S and float(v["tgt_mask"].max()) == S
     assert bool(torch.isfinite(v["rgb"]).all()) and float(v["rgb"].min()) >= 0 and float(v["rgb"].max()) <= 1.0 + 1e-5
+
+
+def test_merge_depth_ordered_kernel_vs_restatement(dev):
+    """mpf_merge_depth_ordered against the numpy restatement of "utils/utils copy.py":278-303 on adversarial inputs: masks at 0, at the
+    threshold and NaN, equal depths, NaN depths."""
+    from mpiflow_amd import ops
+    from oracle import mpi_oracle as o
+    rs = np.random.RandomState(5)
+    H, W = 37, 53
+    frame, frame_dyn = rs.rand(3, H, W).astype(np.float32) * 1.2 - 0.1, rs.rand(3, H, W).astype(np.float32)
+    vals = np.array([0.0, -0.0, 1e-30, 0.5, np.float32(0.99), np.nextafter(np.float32(0.99), np.float32(0)), 1.0, np.nan], np.float32)
+    mask, mask_dyn = vals[rs.randint(0, len(vals), (H, W))], vals[rs.randint(0, len(vals), (H, W))]
+    depth = rs.rand(H, W).astype(np.float32) * 3
+    depth_dyn = np.where(rs.rand(H, W) < 0.3, depth, rs.rand(H, W).astype(np.float32) * 3).astype(np.float32)
+    depth[rs.rand(H, W) < 0.05] = np.nan
+    want, want_mask = o.merge_depth_ordered(frame, frame_dyn, mask, mask_dyn, depth, depth_dyn)
+    got, got_mask = ops.merge_depth_ordered(T(frame, dev), T(frame_dyn, dev), T(mask, dev), T(mask_dyn, dev), T(depth, dev), T(depth_dyn, dev),
+                                            want_depth_mask=True)
+    assert bits_equal(N(got), want) == 0 and bits_equal(N(got_mask).astype(bool), want_mask) == 0
+    assert want_mask.sum() > 100
+    assert bits_equal(N(ops.merge_depth_ordered(T(frame, dev), T(frame_dyn, dev), T(mask, dev), T(mask_dyn, dev), T(depth, dev), T(depth_dyn, dev))), want) == 0
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_older_module_entry_point_with_depth_ordered_frame(dev, case):
+    """utils_copy.render_3dphoto_dynamic = the reference's "utils/utils copy.py":164-326 (own pose constants, depth-ordered frame),
+    against what the reference produced under the same random.seed: merged frame / flow as in the v2 test; the depth-ordered frame
+    byte-exact wherever the depth comparison is not a float near-tie and the masks are off the threshold margin."""
+    from mpiflow_amd.utils import utils_copy as UC
+    g = load_golden("copy_variant")
+    p = "c%d_" % case
+    random.seed(int(g[p + "pose_seed"]))
+    K = T(g[p + "K"], dev)[None]
+    flow_mix, src_np, inpainted, res = UC.render_3dphoto_dynamic(
+        T(g[p + "image"], dev)[None], T(g[p + "obj_mask"], dev)[None, None], None, T(g[p + "mpi"], dev)[None], T(g[p + "disparity"], dev)[None],
+        K, K, data_path="outputs", name="demo.png", inpaint="none")
+    assert bits_equal(src_np, g[p + "src_np"]) == 0
+    th = np.float32(0.99)
+    margin = (np.abs(g[p + "cam_objmask"].astype(np.float64) - th) < 1e-5) | (np.abs(g[p + "dyn_objmask"].astype(np.float64) - th) < 1e-5)
+    ok = ~margin
+    assert max_abs(flow_mix[ok], g[p + "flow_mix"][ok]) < 1e-4
+    assert np.abs(inpainted[ok].astype(np.int32) - g[p + "frame_mix"][ok].astype(np.int32)).max() <= 1          # inpaint="none": the merged frame
+    zc, zd = g[p + "cam_depth"], g[p + "dyn_depth"]
+    assert max_abs(res["depth"], zc) < 2e-5 * max(1.0, float(np.abs(zc).max())) and max_abs(res["depth_dync"], zd) < 2e-5 * max(1.0, float(np.abs(zd).max()))
+    tie = np.abs(zc - zd) < 1e-4 * np.maximum(np.abs(zc), 1.0)
+    # a mask that is zero in the reference must be zero here too for the non-zero test to agree: the composited masks are sums of
+    # non-negative terms, exactly 0 iff every term is
+    sure = ok & ~tie
+    want_pick = (zc > zd) & (g[p + "cam_objmask"] != 0) & (g[p + "dyn_objmask"] != 0)
+    assert (res["depth_mask"][sure] == want_pick[sure]).all()
+    d = np.abs(res["frame_mix_depth"][sure].astype(np.int32) - g[p + "frame_mix_depth"][sure].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    changed = (g[p + "frame_mix_depth"] != g[p + "frame_mix"]).any(-1)
+    assert (changed & sure).sum() >= 5 and (res["frame_mix_depth"][changed & sure] != inpainted[changed & sure]).any(-1).sum() >= 5
+    assert res["frame_mix_depth_inpainted"].shape == g[p + "frame_mix"].shape

@@ -288,3 +288,25 @@ def test_select_truncate_degenerate_points_follow_torch_long(oracle):
     want_y = torch.clamp(t[..., 1].long(), 0, H - 1).numpy()
     assert np.array_equal(sx, want_x) and np.array_equal(sy, want_y)
     assert (sx[~np.isfinite(p1[..., 0])] == 0).all()
+
+
+# ------------------------------------------------------------------- the older module, "utils/utils copy.py" --------
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_depth_ordered_frame_of_the_older_module(oracle, case):
+    """"utils/utils copy.py":295-303: given the reference's own float views, masks and depths, the restated depth-ordered pick must give
+    the frame the reference handed to its second cv2.inpaint call, byte for byte - and that frame must differ from the merged one
+    (the golden cases were chosen so that the pick changes pixels)."""
+    g = load_golden("copy_variant")
+    p = "c%d_" % case
+    frame_mix_depth, depth_mask = oracle.merge_depth_ordered(g[p + "cam_rgb"], g[p + "dyn_rgb"], g[p + "cam_objmask"], g[p + "dyn_objmask"],
+                                                             g[p + "cam_depth"], g[p + "dyn_depth"])
+    assert bits_equal(frame_mix_depth, g[p + "frame_mix_depth"]) == 0
+    changed = (g[p + "frame_mix_depth"] != g[p + "frame_mix"]).any(-1)
+    assert changed.sum() >= 9 and not (changed & ~depth_mask).any()
+    # the copy module's pose constants, drawn in its order (:210-211), under the recorded seed
+    from mpiflow_amd import host_math
+    random.seed(int(g[p + "pose_seed"]))
+    G_dyn = host_math.generate_random_pose(0.1, profile="copy")
+    G_cam = host_math.generate_random_pose(0.1, base_motions=[0, 0, 0], profile="copy")
+    assert bits_equal(G_dyn.numpy(), g[p + "G_dyn"]) == 0 and bits_equal(G_cam.numpy(), g[p + "G_cam"]) == 0

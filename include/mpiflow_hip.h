@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPF_VERSION 300   /* round 3: + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow */
+#define MPF_VERSION 301   /* round 3: + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered */
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)

@@ -16,7 +16,6 @@ This module only PACKS parameters (host side, torch CPU) and sequences launches;
 import ctypes
 
 import torch
-import torch.nn.functional as F
 
 from .. import _lib
 

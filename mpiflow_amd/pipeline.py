@@ -15,7 +15,6 @@ gen_3dphoto_dynamic_v2.py:78-122), the only collective is one all-reduce of a ~1
 import os
 import random
 
-import numpy as np
 import torch
 
 from . import host_math, ops

@@ -219,7 +219,7 @@ def main(argv=None):
         Built ON the lane's stream, so that the zero-fill of the stack and the packed weights are ordered before its first use."""
 
         def __init__(self):
-            self.stream, self.tail_stream, self.tail_ready = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Event()
+            self.stream, self.tail_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
             self.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self.stream):
                 self.renderer = pipeline.PairRenderer(opt.planes, opt.height, opt.width, dev)
@@ -259,6 +259,19 @@ def main(argv=None):
     done_before = set(i for i in owned if opt.resume and outputs_exist(out, names[i].split(".")[0], opt.repeat))
     inputs = iter(io_formats.InputPrefetcher(names, img_base, disp_base, mask_base, [i for i in owned if i not in done_before]))
     skipped, n_resumed = [], 0                       # (image name, reason) of the images this rank owned and could not render
+    pending = []                                     # (name, pairs, hand_off) of the image whose pairs are rendered but not yet handed to the writers
+
+    def finish_pending():
+        done = 0
+        while pending:
+            nm, n_new, hand_off = pending.pop(0)
+            try:
+                hand_off()
+                done += n_new
+            except Exception as e:                                         # noqa: BLE001
+                torch.cuda.synchronize()
+                skipped.append((nm, "hand-off: %r" % (e,)))
+        return done
     n_pairs, t_first, n_first, n_owned = 0, None, 0, 0
     for i, img in enumerate(names):
         name = img.split(".")[0]
@@ -299,13 +312,17 @@ def main(argv=None):
         lane = lanes[n_owned % len(lanes)]
         n_owned += 1
         try:
-            n_pairs += render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, model, amp, ring, dstats, fill_mode, lap)
+            n_new, hand_off = render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, model, amp, ring, dstats, fill_mode, lap)
         except Exception as e:                                             # noqa: BLE001 - isolate the image, keep the batch going
             torch.cuda.synchronize()
             skipped.append((name, "render: %r" % (e,)))
+            n_pairs += finish_pending()                                    # the previous image is unaffected: its pairs still go out
             continue
+        n_pairs += finish_pending()                                        # the PREVIOUS image's pairs go to the writers now, behind this image's launches
+        pending.append((name, n_new, hand_off))
         if t_first is None and n_owned >= len(lanes):
-            t_first, n_first = time.perf_counter(), n_pairs       # start-up (graph capture, first MIOpen calls) ends once every lane has run
+            t_first, n_first = time.perf_counter(), n_pairs + sum(q[1] for q in pending)       # start-up (graph capture, first MIOpen calls) ends once every lane has run
+    n_pairs += finish_pending()
     with lap("drain writers"):
         torch.cuda.synchronize()
         ring.close()
@@ -338,8 +355,9 @@ def main(argv=None):
 
 
 def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, model, amp, ring, dstats, fill_mode, lap):
-    """One owned image: upload, input stage, MPI producer + blend (once), then `repeat` pairs.  Returns the pairs rendered."""
-    renderer, hip_model, tail_stream, tail_ready, fill_ws = lane.renderer, lane.hip_model, lane.tail_stream, lane.tail_ready, lane.fill_ws
+    """One owned image: upload, input stage, MPI producer + blend (once), then `repeat` pairs.  Returns (pairs rendered, hand_off): the pairs are
+    rendered (enqueued) on return; hand_off() enqueues their way out (statistics, scanlines / hole-fill inputs, device->host copies, writer jobs)."""
+    renderer, hip_model, tail_stream, fill_ws = lane.renderer, lane.hip_model, lane.tail_stream, lane.fill_ws
     H, W = opt.height, opt.width
     with torch.cuda.stream(lane.stream):                                  # everything this image enqueues goes to its lane's stream
         with lap("upload + resize image, disparity"):
@@ -375,10 +393,15 @@ def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, m
             results = renderer.run_pairs(mpi, image[0], K, planes, obj_masks, [(poses[2 * r + 1], poses[2 * r]) for r in range(opt.repeat)],
                                          cum_mask=cum_mask)
         # the tail of the pairs (scanlines / hole-fill hand-off, statistics, copies to the host) runs on a second stream, so it
-        # overlaps the next image's network and render
-        tail_ready.record()
+        # overlaps the next image's network and render - and the HOST enqueues it only after it has submitted the next image's
+        # network (main loop): handing five pairs to the writers takes the submitting thread ~1.5 ms, during which the main stream
+        # used to run dry at every image boundary (profiles/r3/generator_device_busy.txt: ~3 idle gaps of 0.1 ms per image)
+        ready = torch.cuda.Event()
+        ready.record()
+
+    def hand_off():
         with torch.cuda.stream(tail_stream):
-            tail_stream.wait_event(tail_ready)
+            tail_stream.wait_event(ready)
             for r, res in enumerate(results):
                 for tns in (res["frame_mix"], res["fill_mask"], res["flow_mix"]):
                     tns.record_stream(tail_stream)
@@ -390,7 +413,7 @@ def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, m
                     else:
                         frame = ops.fill_holes(res["frame_mix"], res["fill_mask"], workspace=fill_ws) if fill_mode == "peel" else res["frame_mix"]
                         ring.submit_pair(res["flow_mix"], ops.png_scanlines(frame), flo_path, png_path)
-    return opt.repeat
+    return opt.repeat, hand_off
 
 
 if __name__ == "__main__":

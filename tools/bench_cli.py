@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end generator throughput: gen_3dphoto_dynamic.py on a synthetic KITTI-shaped dataset (375x1242 PNGs -> 384x1280,
 64 planes, repeat 5), network on the HIP engine vs torch, with and without writer threads."""
-import os, subprocess, sys, tempfile, time
+import os, shutil, subprocess, sys, tempfile, time
 import numpy as np
 from PIL import Image
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,10 +26,11 @@ configs = [("hip engine, peel fill on the GPU, 16 writers (warm-up run)", ["--mo
            ("hip engine, cv2.inpaint NS restated on 96 writer threads", ["--model-engine", "hip", "--writers", "96", "--inpaint", "builtin"])]
 if "--torch" in sys.argv:
     configs.append(("torch fp16, 16 writers", ["--model-engine", "torch", "--model-dtype", "fp16", "--writers", "16", "--inpaint", "peel"]))
-for label, extra in configs:
+only = os.environ.get("ONLY")                  # substring filter on the configuration labels
+for label, extra in [c for c in configs if not only or any(o in c[0] for o in only.split("|"))]:
     out = os.path.join(tmp, "out_" + label.replace(" ", "_").replace(",", ""))
     t0 = time.perf_counter()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "gen_3dphoto_dynamic.py"), "--base", base, "--out", out, "--repeat", "5", "--mpi-from", "model",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, os.environ.get("GEN_SCRIPT", "gen_3dphoto_dynamic.py")), "--base", base, "--out", out, "--repeat", "5", "--mpi-from", "model",
                         "--ckpt_path", "random:0"] + extra, capture_output=True, text=True)
     dt = time.perf_counter() - t0
     last = [l for l in r.stdout.splitlines() if l.startswith("pairs")]
@@ -37,3 +38,5 @@ for label, extra in configs:
     for l in r.stdout.splitlines():
         if l.startswith("  ") or l.startswith("steady"):
             print("      " + l)
+    shutil.rmtree(out, ignore_errors=True)          # 800 pairs = ~4 GB of files per configuration: do not let them pile up on the box
+shutil.rmtree(tmp, ignore_errors=True)

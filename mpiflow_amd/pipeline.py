@@ -49,24 +49,48 @@ class _PairHostSide:
     def prepare_many(self, K, disparity, pose_pairs):
         """prepare() for the R pairs of one image at once: ONE batched homography evaluation over the 2R poses (bit-identical to the
         per-pair ones: every matrix goes through the same per-matrix code) and ONE pinned buffer / H2D copy for the 3R parameter
-        blocks (each block starts on a 256-byte boundary).  -> R dicts like prepare()'s."""
+        blocks (each block starts on a 256-byte boundary), filled by a dozen strided assignments (pack_pair_blocks) instead of 3R
+        pack_params calls.  -> R dicts like prepare()'s."""
         k_inv, d = self._constants(K, disparity)
         flat = [G for pair in pose_pairs for G in pair]
         H_ts, H_st = host_math.homographies_multi(flat, k_inv, K, d)
-        blocks = []
-        for r, pair in enumerate(pose_pairs):
-            blocks.append(ops.blend_flow_params(k_inv, d, H_ts[2 * r:2 * r + 2])[0])
-            blocks += [ops.warp_params(H_st[2 * r + v], k_inv, pair[v], d) for v in range(2)]
-        offs, n = [], 0
-        for b in blocks:
-            offs.append(n)
-            n += (b.numel() + 63) // 64 * 64
-        host = torch.zeros(n, dtype=torch.float32).pin_memory()
-        for o, b in zip(offs, blocks):
-            host[o:o + b.numel()] = b
+        host, offs, sizes = pack_pair_blocks(k_inv, d, H_ts, H_st, flat, pin=True)
         dev = host.to(device=self.device, non_blocking=True)
-        view = lambda i: dev[offs[i]:offs[i] + blocks[i].numel()]  # noqa: E731
-        return [dict(P=2, blend=view(3 * r), warp=[view(3 * r + 1), view(3 * r + 2)], k_inv=k_inv, depths=d) for r in range(len(pose_pairs))]
+        view = lambda r, j: dev[offs[r][j]:offs[r][j] + sizes[j]]  # noqa: E731
+        return [dict(P=2, blend=view(r, 0), warp=[view(r, 1), view(r, 2)], k_inv=k_inv, depths=d) for r in range(len(pose_pairs))]
+
+
+def pack_pair_blocks(k_inv, depths, H_ts, H_st, poses, pin=False):
+    """Host image of the parameter blocks of R pairs in one buffer: per pair [blend_flow_params(k_inv, d, H_ts[2r:2r+2]) |
+    warp_params(H_st[2r], k_inv, poses[2r], d) | warp_params(H_st[2r+1], k_inv, poses[2r+1], d)], every block padded to a multiple of
+    64 floats.  H_ts / H_st: [2R,S,3,3], poses: 2R [4,4].  The same floats ops.blend_flow_params / ops.warp_params pack one block at a
+    time (tests/test_host_logic.py compares them).  -> (buffer [R * stride] f32, offsets[r] = (blend, warp0, warp1), sizes (blend, warp, warp))"""
+    HDR, REC = host_math.PARAMS_HEADER, host_math.PLANE_RECORD
+    d = host_math._cpu32(depths).reshape(-1)
+    S, R = d.numel(), len(poses) // 2
+    nb, nw = HDR + REC * 2 * S, HDR + REC * S
+    ab, aw = (nb + 63) // 64 * 64, (nw + 63) // 64 * 64
+    stride = ab + 2 * aw
+    host = torch.zeros(R * stride, dtype=torch.float32)
+    if pin:
+        host = host.pin_memory()
+    rows = host.view(R, stride)
+    k9 = host_math._cpu32(k_inv).reshape(9)
+    G = torch.stack([host_math._cpu32(g).reshape(4, 4)[0:3, :].reshape(12) for g in poses]).view(R, 2, 12)
+    Hts = host_math._cpu32(H_ts).reshape(R, 2, S, 9)
+    Hst = host_math._cpu32(H_st).reshape(R, 2, S, 9)
+    rows[:, 0:9] = k9
+    rec = rows[:, HDR:HDR + REC * 2 * S].view(R, S, 2, REC)                 # record = s * P + p
+    rec[..., 0:9] = Hts.permute(0, 2, 1, 3)
+    rec[..., 9] = d.view(1, S, 1)
+    for v in range(2):
+        o = ab + v * aw
+        rows[:, o:o + 9] = k9
+        rows[:, o + 9:o + 21] = G[:, v]
+        rec = rows[:, o + HDR:o + HDR + REC * S].view(R, S, REC)
+        rec[..., 0:9] = Hst[:, v]
+        rec[..., 9] = d.view(1, S)
+    return host, [(r * stride, r * stride + ab, r * stride + ab + aw) for r in range(R)], (nb, nw, nw)
 
 
 class PairRenderer(_PairHostSide):

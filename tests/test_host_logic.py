@@ -282,3 +282,26 @@ def test_bench_gpus_flag_is_never_silently_ignored():
                        env=dict(clean, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "they must agree" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_parameter_blocks_of_all_pairs_in_one_buffer_equal_the_per_block_packing():
+    """pipeline.pack_pair_blocks (one strided fill for the 3R blocks of an image) against ops.blend_flow_params / ops.warp_params block by block."""
+    import random as _random
+    from mpiflow_amd import host_math, ops, pipeline, synth
+    for S, R, seed in ((7, 3, 3), (64, 5, 4), (1, 1, 5)):
+        K = torch.from_numpy(synth.intrinsics(48, 64))
+        d = host_math.plane_depths(torch.from_numpy(synth.plane_disparities(S)))
+        k_inv = host_math.k_inverse(K)
+        rng = _random.Random(seed)
+        poses = [host_math.generate_random_pose(0.15, rng=rng) for _ in range(2 * R)]
+        H_ts, H_st = host_math.homographies_multi(poses, k_inv, K, d)
+        host, offs, sizes = pipeline.pack_pair_blocks(k_inv, d, H_ts, H_st, poses)
+        used = torch.zeros(host.numel(), dtype=torch.bool)
+        for r in range(R):
+            blocks = [ops.blend_flow_params(k_inv, d, H_ts[2 * r:2 * r + 2])[0]] + [ops.warp_params(H_st[2 * r + v], k_inv, poses[2 * r + v], d) for v in range(2)]
+            for j, blk in enumerate(blocks):
+                o = offs[r][j]
+                assert o % 64 == 0 and blk.numel() == sizes[j]
+                assert torch.equal(host[o:o + sizes[j]].view(torch.int32), blk.view(torch.int32)), (S, r, j)
+                used[o:o + sizes[j]] = True
+        assert not host[~used].any()                      # padding stays zero

@@ -79,6 +79,11 @@ def parse():
                    help="pairs every rank renders per step, cycling through its resident stacks (104 x 20 steps > 1 s of timed work); 0 = --images")
     p.add_argument("--pipeline", choices=["overlapped", "serial"], default="overlapped",
                    help="overlapped: Stage B of pair i and Stage A+C of pair i+1 in one heterogeneous-grid launch; serial: one kernel after the other")
+    p.add_argument("--no-moving-object", action="store_true",
+                   help="c3 without the moving-object chain (depth->flow projection, forward warp, masks): the render-only pair of rounds 1-3")
+    p.add_argument("--chain-priority", type=int, default=0, help="tuning: 1 = the chain's side stream gets the highest stream priority")
+    p.add_argument("--chain-ordered", type=int, default=0,
+                   help="1 = the chain's results are stream-ordered on the main stream at every pair (event record + wait per pair); 0 = independent side pipeline, joined at the end")
     p.add_argument("--no-generator", action="store_true", help="skip the end-to-end generator record")
     p.add_argument("--batch", type=int, default=512, help="--mode batch: images of the whole job per step (BASELINE configs[3]: 512)")
     p.add_argument("--planes", type=int, default=64)
@@ -88,6 +93,8 @@ def parse():
     p.add_argument("--no-sub", action="store_true", help="skip the c2 / c1 / c5 sub-records")
     p.add_argument("--cpu-pairs", type=int, default=64, help="most pairs the CPU oracle renders for cpu_baseline (it stops after ~12 s of CPU work)")
     p.add_argument("--sbf-px", type=int, default=0, help="tuning: pixels/thread of Stage A+C (0 = library default)")
+    p.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                   help="tuning: mpf_tune(KEY, INT) before anything runs (ovl_xcd_a, chain_prio, view_shift, ...); recorded in config.tune")
     p.add_argument("--single-view-launches", action="store_true", help="tuning: one Stage B launch per view instead of one per pair")
     return p.parse_args()
 
@@ -185,7 +192,7 @@ class Workload:
         self.mix = (torch.empty((H, W, 2), dtype=torch.float32, device=dev), torch.empty((H, W, 3), dtype=torch.uint8, device=dev),
                     torch.empty((H, W), dtype=torch.uint8, device=dev))
         self.ev_b, self.ev_ac = [], []
-        self.mo = MovingObjectChain(H, W, K, dev, seed0) if moving_object else None
+        self.mo, self.mo_disp = make_moving_object_chain(H, W, K, dev, seed0) if moving_object else (None, None)
 
     def pair(self, i, timed):
         r, (mpi, img), prep = self.r, self.images[i], self.preps[i]
@@ -211,7 +218,7 @@ class Workload:
             v = r.views
             ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], r.flows[0], r.flows[1], self.om, out=self.mix)
         if self.mo is not None:
-            self.mo.run(r.src_u8, self.om)
+            self.mo.run(self.mo_disp, self.om, r.src_u8)
 
     def step(self, timed, which=None):
         idx = range(self.B) if which is None else which
@@ -242,28 +249,16 @@ class Workload:
                               "gathers from re-writes sigma, so the kernel really moves layout_bytes_per_launch"})
 
 
-class MovingObjectChain:
+def make_moving_object_chain(H, W, K, dev, seed):
     """SURVEY 8(d)'s c3 adds "forward-warp on disp = rs.rand(H, W)": the moving-object chain of moving_obj.py:29-150 on device-resident
-    inputs - fused depth->flow projection (two poses, instance select, truncate + clamp), order-preserving forward splat, masks."""
-
-    def __init__(self, H, W, K, dev, seed):
-        g = torch.Generator(device=dev).manual_seed(4242 + seed)
-        self.H, self.W = H, W
-        self.disp = torch.rand((H, W), generator=g, device=dev)
-        K3 = torch.from_numpy(np.asarray(K, dtype=np.float32)).reshape(3, 3)
-        self.inv_K = torch.inverse(K3.double()).float()
-        K4 = torch.zeros((1, 4, 4))
-        K4[0, -1, -1] = 1.0
-        K4[:, :3, :3] = K3
-        T1 = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.zeros(1, 3))                 # moving_obj.py:43-47
-        Ti = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.tensor([[0.07, -0.06, 0.08]]))  # :81-98 (angles are zeroed there)
-        self.P1, self.Pi = torch.matmul(K4, T1)[:, :3, :][0], torch.matmul(K4, Ti)[:, :3, :][0]
-
-    def run(self, src_u8_HW3, obj_mask):
-        from mpiflow_amd import ops as _ops
-        p1, z1, sx, sy, fl = _ops.moving_object_project(self.disp, self.inv_K, self.P1, self.Pi, obj_mask)
-        warped = _ops.forward_warp(src_u8_HW3.reshape(-1), sx, sy, z1, self.H, self.W)
-        return _ops.warp_masks(warped)
+    inputs (mpiflow_amd.moving_obj.MovingObjectChain: projection fused into the forward splat's first sort pass, splat, masks - one C call,
+    5 launches), a fixed object pose of the reference's magnitude (moving_obj.py:81-98; the angles are zeroed there).  -> (chain, disp)"""
+    from mpiflow_amd import moving_obj
+    g = torch.Generator(device=dev).manual_seed(4242 + seed)
+    disp = torch.rand((H, W), generator=g, device=dev)
+    K3 = torch.from_numpy(np.asarray(K, dtype=np.float32)).reshape(3, 3)
+    Ti = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.tensor([[0.07, -0.06, 0.08]]))
+    return moving_obj.MovingObjectChain(H, W, K3, torch.inverse(K3.double()).float(), dev, T_obj=Ti, n_buffers=2), disp
 
 
 class PipelinedWorkload:
@@ -271,16 +266,18 @@ class PipelinedWorkload:
     i+1 in one heterogeneous-grid launch.  finish() flushes the pipeline (the last pair's stand-alone Stage B)."""
     dynamic = True
 
-    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False):
+    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False, chain_priority=False, chain_ordered=False):
         self.S, self.H, self.W, self.B, self.N = S, H, W, B, H * W
         K, disp = synth.intrinsics(H, W), synth.plane_disparities(S)
         rng = random.Random(pose_seed)
         self.r = pipeline.OverlappedPairRenderer(S, H, W, dev)
-        # SURVEY 8(d)'s full c3: the moving-object chain of every completed pair runs on a SIDE stream underneath the next pair's launch
-        # (its few small kernels are latency-sized); the main stream waits for it before the slot's source frame is rewritten
-        self.mo = MovingObjectChain(H, W, K, dev, seed0) if moving_object else None
-        self.side = torch.cuda.Stream(dev) if moving_object else None
-        self.side_done = {}
+        # SURVEY 8(d)'s full c3: the moving-object chain of every pair runs on the renderer's SIDE stream, issued right behind the launch whose
+        # Stage A+C role wrote the pair's uint8 source frame and handed back with the pair one launch later (OverlappedPairRenderer.attach_chain)
+        self.mo, self.mo_disp = make_moving_object_chain(H, W, K, dev, seed0) if moving_object else (None, None)
+        if moving_object:
+            # the chain as an independent side pipeline (attach_chain(ordered=False)): nothing of it is inserted into the main stream; the
+            # inputs are resident since set-up (ready event recorded once), finish() joins the side stream inside the timed region
+            self.r.attach_chain(self.mo, high_priority=chain_priority, ordered=chain_ordered)
         self.images, self.preps = [], []
         for i in range(B):
             self.images.append(make_image(S, H, W, dev, seed=seed0 + i))
@@ -292,6 +289,8 @@ class PipelinedWorkload:
                     torch.empty((H, W), dtype=torch.uint8, device=dev))
         self.ev = []
         self.timed = False
+        self.inputs_ready = torch.cuda.Event()
+        self.inputs_ready.record()                                   # everything the chain reads (images, disparity, mask) is resident from here on
 
         def hook(launch):
             if not self.timed:
@@ -306,35 +305,14 @@ class PipelinedWorkload:
     def step(self, timed, which=None):
         idx = range(self.B) if which is None else which
         self.timed = timed
+        moving = (self.mo_disp, self.om) if self.mo is not None else None
         for i in idx:
             mpi, img = self.images[i % self.B]
-            done_slot = self.r.pending_slot                                    # the pair this push completes (None for the first)
-            if self.mo is not None:
-                nxt = self.r.slots[self.r._next]                               # the slot this push's Stage A+C role is about to rewrite
-                ev = self.side_done.pop(id(nxt), None)
-                if ev is not None:
-                    torch.cuda.current_stream().wait_event(ev)
-            self.r.push(mpi, img, self.preps[i % self.B], self.om, out=self.mix)
-            if self.mo is not None and done_slot is not None:
-                self._side_chain(done_slot)
+            self.r.push(mpi, img, self.preps[i % self.B], self.om, out=self.mix, moving=moving, moving_ready=self.inputs_ready if moving else None)
         return len(idx)
 
-    def _side_chain(self, slot):
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            self.mo.run(slot["src_u8"], self.om)
-            ev = torch.cuda.Event()
-            ev.record()
-        self.side_done[id(slot)] = ev
-
     def finish(self):
-        slot = self.r.pending_slot
         self.r.flush()
-        if self.mo is not None and slot is not None:
-            self._side_chain(slot)
-            torch.cuda.current_stream().wait_stream(self.side)
 
     def rooflines(self):
         t = float(np.mean([a.elapsed_time(b) for a, b in self.ev])) * 1e-3
@@ -519,6 +497,9 @@ def main():
     _lib.load()
     if a.sbf_px:
         _lib.check(_lib.load().mpf_tune(b"sbf_px", a.sbf_px))
+    for kv in a.tune:
+        key, val = kv.split("=")
+        _lib.check(_lib.load().mpf_tune(key.encode(), int(val)), "mpf_tune(%s)" % kv)
     S, H, W = a.planes, a.height, a.width
     dynamic = a.workload == "c3"
     pipelined = dynamic and a.pipeline == "overlapped" and not a.single_view_launches
@@ -530,10 +511,11 @@ def main():
     else:
         B = a.images
         order = list(range(a.pairs_per_step if a.pairs_per_step > 0 else B))
+    chain = dynamic and not a.no_moving_object
     if pipelined:
-        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank)
+        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank, moving_object=chain, chain_priority=bool(a.chain_priority), chain_ordered=bool(a.chain_ordered))
     else:
-        wl = Workload(S, H, W, B, dev, dynamic, seed0=rank * 1000, multi_view=not a.single_view_launches, pose_seed=114514 + rank)
+        wl = Workload(S, H, W, B, dev, dynamic, seed0=rank * 1000, multi_view=not a.single_view_launches, pose_seed=114514 + rank, moving_object=chain)
     torch.cuda.synchronize()
 
     def barrier():
@@ -576,14 +558,16 @@ def main():
             roof["traffic_source"] = traffic_src
         how = ("pipelined: per pair one heterogeneous-grid launch (Stage B of this pair, 2 views + Stage A+C of the next pair) + merge" if pipelined
                else "one kernel after the other: blend + 2 flows, 2 warped views in one launch, merge")
-        cfg_name = ("BASELINE configs[2]: %d planes, %dx%d, full dynamic pair (" + how + ")" if dynamic
+        mo = (" + the moving-object chain of every pair (depth->flow projection, order-preserving forward warp of the uint8 source frame, masks on "
+              "disp = rand(H, W): SURVEY 8(d)'s full c3)" + (" on a side stream underneath the next pair launch" if pipelined else "")) if chain else " (render only, no moving-object chain)"
+        cfg_name = ("BASELINE configs[2]: %d planes, %dx%d, full dynamic pair (" + how + ")" + mo if dynamic
                     else "BASELINE configs[1]: %d planes, %dx%d, camera-only novel view (blend+flow, warp+composite, u8 frames)") % (S, H, W)
         out = {
             "metric": "image-pairs/sec (+flow) at 640x960x64 planes",
             "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.mode == "batch" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial",
+            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None, "tune": a.tune,
                        "pairs_per_step_per_gpu": len(order), "resident_stacks_per_gpu": B, "timed_seconds": dt,
                        "sharding": "independent images per rank (i % world == rank), stats all-reduce only",
                        "device": _lib.device_info(local),
@@ -608,10 +592,12 @@ def main():
                 out["roofline_stage_b"], out["roofline_stage_ac"] = c3["stage_b"], c3["stage_ac"]
             else:
                 sub.append(sub_record("c3 pipelined: Stage B of pair i + Stage A+C of pair i+1 per launch", 64, 640, 960, 4, dev, True, 5, pipelined=True))
-            sub.append(sub_record("c3 + moving-object chain (SURVEY 8(d)'s full c3): serial pair + depth->flow projection, forward warp, masks on disp = rand",
+            sub.append(sub_record("c3 + moving-object chain (SURVEY 8(d)'s full c3), serial: pair kernels one after the other + the chain's 5 launches on the same stream",
                                   64, 640, 960, 4, dev, True, 5, moving_object=True))
-            sub.append(sub_record("c3 pipelined + moving-object chain on a side stream (SURVEY 8(d)'s full c3 in the throughput form)", 64, 640, 960, 4, dev, True, 5,
-                                  pipelined=True, moving_object=True))
+            sub.append(sub_record("c3 render only, pipelined (no moving-object chain: the `value` of rounds 1-3)", 64, 640, 960, 4, dev, True, 5, pipelined=True))
+            if not (pipelined and chain):
+                sub.append(sub_record("c3 pipelined + moving-object chain on the side stream (SURVEY 8(d)'s full c3 in the throughput form)", 64, 640, 960, 4, dev, True, 5,
+                                      pipelined=True, moving_object=True))
             sub.append(sub_record("c2: BASELINE configs[1], 64x640x960 camera-only pair", 64, 640, 960, 4, dev, False, 5))
             sub.append(sub_record("c1: BASELINE configs[0] shape, 32x384x512 dynamic pair, pipelined (on the GPU: the product has no CPU path)", 32, 384, 512, 8, dev, True, 10, pipelined=True))
             sub.append(sub_record("c1 serial", 32, 384, 512, 8, dev, True, 10))

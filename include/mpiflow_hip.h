@@ -268,6 +268,23 @@ int mpf_forward_warp(const uint8_t *d_src, const int64_t *d_idx, const int64_t *
 int mpf_warp_masks(const uint8_t *d_warped, int H, int W, uint8_t *d_Hm, uint8_t *d_M, uint8_t *d_Md, uint8_t *d_P,
                    uint8_t *d_Hp, void *stream);
 
+/* moving_obj.py:29-150 in ONE call on device buffers: mpf_moving_object_project (fused into the first pass of the forward warp's sort:
+ * the int64 targets are written for the caller but never read back), mpf_forward_warp, mpf_warp_masks - 5 launches, no allocation.
+ * The source frame that is splatted (moving_obj.py:124), ONE of: d_src_u8 u8 [H,W,3], or d_src_f32_3HW float [3,H,W] in 0..1 whose
+ * uint8 BGR form (utils/utils.py:174-177: rint(255 v), clamped - what Stage A+C writes as the pair's source frame) is splatted, converted
+ * per winner on the fly, so that the chain needs no output of the render path.  Masks: all five pointers or none.
+ * d_workspace: mpf_forward_warp_workspace(H, W) bytes, 256-byte aligned. */
+typedef struct MpfMovingObjectOut {
+    float *d_p1, *d_z1;               /* [H,W,2], [H,W] */
+    int64_t *d_safe_x, *d_safe_y;     /* [H,W] */
+    float *d_flow01;                  /* [H,W,2] */
+    uint8_t *d_warped;                /* [H,W,5] */
+    uint8_t *d_Hm, *d_M, *d_Md, *d_P, *d_Hp;   /* [H,W] each */
+} MpfMovingObjectOut;
+int mpf_moving_object_chain(const float *d_disp, const float *h_inv_k9, const float *h_P_static12, const float *h_P_obj12,
+                            const float *d_inst, const uint8_t *d_src_u8, const float *d_src_f32_3HW, int H, int W,
+                            const MpfMovingObjectOut *out, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ================= MPI producer network: 3x3 convolution engine ====================== */
 
 /* One launch = one 3x3 / pad 1 / stride 1|2 convolution over S plane-images with its surrounding plumbing fused:

@@ -42,6 +42,12 @@ class MpfWarpView(ctypes.Structure):
                 ("d_tgt_mask", c_p), ("d_rgb_u8_bgr", c_p)]
 
 
+class MpfMovingObjectOut(ctypes.Structure):
+    """struct MpfMovingObjectOut of include/mpiflow_hip.h: the output buffers of mpf_moving_object_chain (device pointers)."""
+    _fields_ = [("d_p1", c_p), ("d_z1", c_p), ("d_safe_x", c_p), ("d_safe_y", c_p), ("d_flow01", c_p), ("d_warped", c_p),
+                ("d_Hm", c_p), ("d_M", c_p), ("d_Md", c_p), ("d_P", c_p), ("d_Hp", c_p)]
+
+
 MAX_VIEWS = 16          # MPF_MAX_VIEWS
 
 # name -> (restype, argtypes); must list every symbol include/mpiflow_hip.h declares (tests/test_capi.py checks)
@@ -82,6 +88,7 @@ SIGNATURES = {
     "mpf_forward_warp_workspace": (c_sz, [c_i, c_i]),
     "mpf_forward_warp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_sz, c_p]),
     "mpf_warp_masks": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "mpf_moving_object_chain": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, ctypes.POINTER(MpfMovingObjectOut), c_p, c_sz, c_p]),
     "forward_warping": (None, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
     "mpf_forward_warping_host": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
     "mpf_tune": (c_i, [ctypes.c_char_p, c_i]),
@@ -104,12 +111,17 @@ def load():
             "libmpiflow_hip.so not found at %s - build it with `python __graft_entry__.py` or "
             "`make -C mpiflow_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    skipped = []
     for name, (res, args) in SIGNATURES.items():
         if os.environ.get("MPIFLOW_HIP_LIB") and not hasattr(lib, name):
+            skipped.append(name)
             continue
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
         fn.restype = res
         fn.argtypes = args
+    if skipped:                          # development hook only: say which calls will fail instead of failing late with an AttributeError
+        import sys
+        sys.stderr.write("mpiflow_amd: MPIFLOW_HIP_LIB=%s lacks %d symbol(s) of include/mpiflow_hip.h: %s\n" % (LIB_PATH, len(skipped), ", ".join(skipped)))
     _lib = lib
     return lib
 

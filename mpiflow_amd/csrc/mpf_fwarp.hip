@@ -25,6 +25,9 @@
 #include "mpf_common.h"
 #include "mpf_math.h"
 
+static int g_fw_prio = 0;       // mpf_tune("chain_prio", 0..3): s_setprio of the sort / resolve / mask kernels (they run underneath a pair launch)
+#define MPF_FW_SETPRIO(p) do { if ((p) == 1) __builtin_amdgcn_s_setprio(1); else if ((p) == 2) __builtin_amdgcn_s_setprio(2); else if ((p) == 3) __builtin_amdgcn_s_setprio(3); } while (0)
+
 #define RADIX_BITS_MAX 11              // digits of 8..11 bits: 20-bit keys (640 x 960 targets) sort in two passes, up to 33 bits in three
 #define RADIX_MAX (1 << RADIX_BITS_MAX)
 #define SORT_THREADS 256
@@ -113,14 +116,13 @@ MPF_DEV void mpf_project_point(const float *P, float X, float Y, float Z, int H,
     z = q[2];
 }
 
-__global__ void __launch_bounds__(256)
-k_moving_object_project(const float *__restrict__ disp, MpfMoProj m, const float *__restrict__ inst, int H, int W,
-                        float *__restrict__ p1, float *__restrict__ z1, int64_t *__restrict__ safe_x, int64_t *__restrict__ safe_y,
-                        float *__restrict__ flow01)
+// One source pixel n of moving_obj.py:29-124, :153: depth from disparity, back-projection, the static or the object projection, pixel
+// units, truncation + clamp, flow.  Shared by the stand-alone kernel and by the chain's fused first sort pass (same IEEE op sequence).
+struct MpfMoOut { float *p1, *z1; int64_t *safe_x, *safe_y; float *flow01; };
+
+MPF_DEV uint32_t mpf_mo_pixel(const float *__restrict__ disp, const MpfMoProj &m, const float *__restrict__ inst, int H, int W, const int64_t n,
+                              const MpfMoOut &o)
 {
-    const int64_t N = (int64_t)H * W;
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
     const float fx = (float)(n % W), fy = (float)(n / W);
     float dep = 1.0f / (disp[n] + 0.005f);                              // moving_obj.py:29-30
     dep = (dep > 100.0f) ? 100.0f : dep;
@@ -131,16 +133,26 @@ k_moving_object_project(const float *__restrict__ disp, MpfMoProj m, const float
     float nx, ny, z;
     if (sel) mpf_project_point(m.Po, cam[0], cam[1], cam[2], H, W, nx, ny, z);
     else     mpf_project_point(m.Ps, cam[0], cam[1], cam[2], H, W, nx, ny, z);
-    z1[n] = z;
+    o.z1[n] = z;
     const float px = (nx + 1.0f) / 2.0f * (float)(W - 1);               // :115-117
     const float py = (ny + 1.0f) / 2.0f * (float)(H - 1);
-    p1[2 * n] = px; p1[2 * n + 1] = py;
+    o.p1[2 * n] = px; o.p1[2 * n + 1] = py;
     int64_t tx = mpf_trunc_like_x86(px), ty = mpf_trunc_like_x86(py);   // :121-122
     tx = tx > W - 1 ? W - 1 : tx; tx = tx < 0 ? 0 : tx;
     ty = ty > H - 1 ? H - 1 : ty; ty = ty < 0 ? 0 : ty;
-    safe_x[n] = tx; safe_y[n] = ty;
-    flow01[2 * n] = px - fx;                                            // :153
-    flow01[2 * n + 1] = py - fy;
+    o.safe_x[n] = tx; o.safe_y[n] = ty;
+    o.flow01[2 * n] = px - fx;                                          // :153
+    o.flow01[2 * n + 1] = py - fy;
+    return (uint32_t)(ty * W + tx);                                     // the forward warp's target (warping.c:15-16)
+}
+
+__global__ void __launch_bounds__(256)
+k_moving_object_project(const float *__restrict__ disp, MpfMoProj m, const float *__restrict__ inst, int H, int W, MpfMoOut o)
+{
+    const int64_t N = (int64_t)H * W;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    (void)mpf_mo_pixel(disp, m, inst, H, W, n, o);
 }
 
 extern "C" int mpf_moving_object_project(const float *d_disp, const float *h_inv_k9, const float *h_P_static12, const float *h_P_obj12,
@@ -154,8 +166,8 @@ extern "C" int mpf_moving_object_project(const float *d_disp, const float *h_inv
     memcpy(m.Ps, h_P_static12, sizeof(m.Ps));
     memcpy(m.Po, h_P_obj12, sizeof(m.Po));
     const int64_t N = (int64_t)H * W;
-    hipLaunchKernelGGL(k_moving_object_project, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_disp, m, d_inst, H, W,
-                       d_p1, d_z1, d_safe_x, d_safe_y, d_flow01);
+    const MpfMoOut o = { d_p1, d_z1, d_safe_x, d_safe_y, d_flow01 };
+    hipLaunchKernelGGL(k_moving_object_project, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_disp, m, d_inst, H, W, o);
     return mpf_launch_status("k_moving_object_project");
 }
 
@@ -239,6 +251,37 @@ k_fw_keys_hist(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy,
     }
 }
 
+// The chain's first pass (mpf_moving_object_chain): the projection of moving_obj.py:29-124 computed HERE, per source pixel, instead of
+// by a kernel of its own whose int64 targets this pass would read back - one launch and 16 N bytes of reads less.
+template <int BITS>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_mo_project_keys_hist(const float *__restrict__ disp, const MpfMoProj m, const float *__restrict__ inst, int h, int w, const MpfMoOut o,
+                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t N, int shift, uint32_t *__restrict__ hist, const int prio)
+{
+    constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS;
+    __shared__ uint32_t hh[RADIX];
+    MPF_FW_SETPRIO(prio);
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) hh[threadIdx.x + k * SORT_THREADS] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t n = base + it * SORT_THREADS + threadIdx.x;
+        if (n < N) {
+            const uint32_t key = mpf_mo_pixel(disp, m, inst, h, w, (int64_t)n, o);
+            keys[n] = key;
+            vals[n] = n;
+            atomicAdd(&hh[(key >> shift) & (RADIX - 1)], 1u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+        const uint32_t d = threadIdx.x + k * SORT_THREADS;
+        hist[(size_t)blockIdx.x * RADIX + d] = hh[d];
+    }
+}
+
 // Offsets of the scatter, two cheap steps instead of one scan over all RADIX*nb counters (which took a single workgroup 34 us
 // per pass - half of the whole forward warp): the exclusive offset of (digit d, tile b) is
 //     base[d] + colprefix[b][d],   base[d] = sum of the totals of the digits below d,   colprefix[b][d] = sum over tiles < b of hist[.][d]
@@ -247,8 +290,9 @@ k_fw_keys_hist(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy,
 // k_radix_scatter: every workgroup rebuilds base[] from the RADIX totals in LDS (256 .. 2048 numbers) and reads its own row of
 //                  colprefix with coalesced loads.
 __global__ void __launch_bounds__(64)
-k_radix_colscan(uint32_t *__restrict__ hist, uint32_t nb, uint32_t radix, uint32_t *__restrict__ totals)
+k_radix_colscan(uint32_t *__restrict__ hist, uint32_t nb, uint32_t radix, uint32_t *__restrict__ totals, const int prio = 0)
 {
+    MPF_FW_SETPRIO(prio);
     uint32_t *col = hist + blockIdx.x;
     const uint32_t lane = threadIdx.x;
     uint32_t carry = 0;
@@ -274,9 +318,10 @@ template <int BITS>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
                 uint32_t *__restrict__ vals_out, uint32_t N, int shift, uint32_t nb, const uint32_t *__restrict__ offsets,
-                const uint32_t *__restrict__ totals)
+                const uint32_t *__restrict__ totals, const int prio = 0)
 {
     constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS, NW = SORT_THREADS / 64;
+    MPF_FW_SETPRIO(prio);
     __shared__ uint32_t running[RADIX];
     __shared__ uint32_t cnt[NW][RADIX];
     __shared__ uint32_t wave_tot[NW];
@@ -345,8 +390,8 @@ static void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
                        uint32_t *hist, uint32_t *totals, hipStream_t st)
 {
     hipLaunchKernelGGL((k_radix_hist<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, N, shift, nb, hist);
-    hipLaunchKernelGGL(k_radix_colscan, dim3(1u << BITS), dim3(64), 0, st, hist, nb, 1u << BITS, totals);
-    hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals);
+    hipLaunchKernelGGL(k_radix_colscan, dim3(1u << BITS), dim3(64), 0, st, hist, nb, 1u << BITS, totals, g_fw_prio);
+    hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals, g_fw_prio);
 }
 
 // ---- buckets: finish the sort inside each high-digit bucket and resolve it, in ONE kernel ------------------------------------
@@ -364,9 +409,11 @@ template <int LB>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_fw_bucket(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
             uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ totals, uint32_t N, const float *__restrict__ z,
-            const uint8_t *__restrict__ src, uint8_t *__restrict__ warped, int zero_fill)
+            const uint8_t *__restrict__ src, uint8_t *__restrict__ warped, int zero_fill, const int prio = 0,
+            const float *__restrict__ src_f = nullptr)
 {
     constexpr int NT = 1 << LB, DPT = NT / SORT_THREADS, NW = SORT_THREADS / 64;
+    MPF_FW_SETPRIO(prio);
     __shared__ uint32_t hcount[NT];            // visitors per target of the bucket (kept for the clears)
     __shared__ uint32_t cursor[NT];            // running insertion point per target, then: winner slot + 1 per target
     __shared__ uint32_t cnt[NW][NT];
@@ -475,8 +522,14 @@ k_fw_bucket(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ v
         uint8_t *o = warped + (size_t)t * 5;
         const uint32_t wj = cursor[t & (NT - 1)];
         if (wj) {                                                               // no visitor passed the z test: the colour bytes keep
-            const uint8_t *sp = src + (size_t)val_at(wj - 1) * 3;               // what they held (warping.c:19-21)
-            o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
+            const uint32_t v = val_at(wj - 1);                                  // what they held (warping.c:19-21)
+            if (src_f) {                                                        // the frame given as float [3,h,w] in 0..1: its uint8 BGR form, utils/utils.py:174-177
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[c] = mpf_to_u8(src_f[(size_t)(2 - c) * N + v]);
+            } else {
+                const uint8_t *sp = src + (size_t)v * 3;
+                o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
+            }
         } else if (zero_fill) {
             o[0] = o[1] = o[2] = 0;
         }
@@ -512,7 +565,8 @@ k_fw_mark(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, 
 
 __global__ void __launch_bounds__(256)
 k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const float *__restrict__ z,
-           const uint8_t *__restrict__ src, uint32_t N, const uint32_t *__restrict__ win, uint8_t *__restrict__ warped)
+           const uint8_t *__restrict__ src, uint32_t N, const uint32_t *__restrict__ win, uint8_t *__restrict__ warped,
+           const float *__restrict__ src_f = nullptr)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N) return;
@@ -523,8 +577,14 @@ k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
     uint8_t *o = warped + (size_t)t * 5;
     const uint32_t wj = win[t];
     if (wj) {                                                         // no visitor ever passed the z test: colour bytes
-        const uint8_t *s = src + (size_t)vals[wj - 1] * 3;            // keep what they held (warping.c:19-21)
-        o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+        const uint32_t v = vals[wj - 1];                              // keep what they held (warping.c:19-21)
+        if (src_f) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = mpf_to_u8(src_f[(size_t)(2 - c) * N + v]);
+        } else {
+            const uint8_t *s = src + (size_t)v * 3;
+            o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+        }
     }
     o[3] = 1;                                                         // warping.c:23
     o[4] = (zprev == 1000.0f) ? 1 : 0;                                // warping.c:24-27
@@ -533,6 +593,9 @@ k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
 static int g_fw_path = 0;       // mpf_tune("fwarp_path", 1): force the general multi-pass path (tests; images above 2^22 pixels take it anyway)
 
 void mpf_fwarp_set_path(int v) { g_fw_path = v; }
+static int g_fw_stop = 0;       // mpf_tune("chain_stop", n): bench-only ablation, the fast path returns after its first n launches (results invalid)
+void mpf_fwarp_set_stop(int v) { g_fw_stop = v; }
+void mpf_fwarp_set_prio(int v) { g_fw_prio = v < 0 ? 0 : (v > 3 ? 3 : v); }
 
 static inline uint32_t fw_blocks(int64_t N) { return (uint32_t)((N + SORT_TILE - 1) / SORT_TILE); }
 
@@ -545,10 +608,14 @@ extern "C" size_t mpf_forward_warp_workspace(int h, int w)
     return 5 * a + hs + 4 * RADIX_MAX;    // keysA, keysB, valsA, valsB, win, hist, digit totals
 }
 
+// proj != nullptr (mpf_moving_object_chain): the targets are not given but computed - d_idx / d_idy / d_z are the projection's own outputs
+struct FwProj { const float *disp; MpfMoProj m; const float *inst; MpfMoOut out; const float *src_f; };
+
 static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_idy, const float *d_z, uint8_t *d_warped, int h,
-                  int w, void *d_workspace, size_t workspace_bytes, void *stream, bool zero_fill)
+                  int w, void *d_workspace, size_t workspace_bytes, void *stream, bool zero_fill, const FwProj *proj = nullptr)
 {
-    MPF_REQUIRE(d_src && d_idx && d_idy && d_z && d_warped && d_workspace && h >= 1 && w >= 1, "mpf_forward_warp: bad argument");
+    const float *src_f = proj ? proj->src_f : nullptr;
+    MPF_REQUIRE((d_src || src_f) && d_idx && d_idy && d_z && d_warped && d_workspace && h >= 1 && w >= 1, "mpf_forward_warp: bad argument");
     const int64_t N64 = (int64_t)h * w;
     MPF_REQUIRE(N64 < ((int64_t)1 << 31), "mpf_forward_warp: image too large");
     MPF_REQUIRE(workspace_bytes >= mpf_forward_warp_workspace(h, w), "mpf_forward_warp: workspace too small");
@@ -574,9 +641,13 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
         const int pb = hb < 8 ? 8 : hb;
         const uint32_t nbuckets = (uint32_t)(((uint64_t)N + ((uint64_t)1 << lb) - 1) >> lb);
 #define MPF_FW_PASS1(PBv)                                                                                                          \
-        hipLaunchKernelGGL((k_fw_keys_hist<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], N, lb, hist);      \
-        hipLaunchKernelGGL(k_radix_colscan, dim3(1u << PBv), dim3(64), 0, st, hist, nb, 1u << PBv, totals);                                  \
-        hipLaunchKernelGGL((k_radix_scatter<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, keys[0], vals[0], keys[1], vals[1], N, lb, nb, hist, totals)
+        if (g_fw_stop == 1) { \
+          if (proj) hipLaunchKernelGGL((k_mo_project_keys_hist<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out, keys[0], vals[0], N, lb, hist, g_fw_prio); \
+          return 0; } \
+        if (proj) hipLaunchKernelGGL((k_mo_project_keys_hist<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out, keys[0], vals[0], N, lb, hist, g_fw_prio); \
+        else hipLaunchKernelGGL((k_fw_keys_hist<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], N, lb, hist);      \
+        hipLaunchKernelGGL(k_radix_colscan, dim3(1u << PBv), dim3(64), 0, st, hist, nb, 1u << PBv, totals, g_fw_prio);                       \
+        hipLaunchKernelGGL((k_radix_scatter<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, keys[0], vals[0], keys[1], vals[1], N, lb, nb, hist, totals, g_fw_prio)
         switch (pb) {
         case 8: MPF_FW_PASS1(8); break;
         case 9: MPF_FW_PASS1(9); break;
@@ -584,8 +655,9 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
         default: MPF_FW_PASS1(11); break;
         }
 #undef MPF_FW_PASS1
+        if (g_fw_stop == 3) return 0;
 #define MPF_FW_BUCKET(LBv) hipLaunchKernelGGL((k_fw_bucket<LBv>), dim3(nbuckets), dim3(SORT_THREADS), 0, st, keys[1], vals[1], keys[0], vals[0], totals, \
-                                              N, d_z, d_src, d_warped, zero_fill ? 1 : 0)
+                                              N, d_z, d_src, d_warped, zero_fill ? 1 : 0, g_fw_prio, src_f)
         switch (lb) {
         case 8: MPF_FW_BUCKET(8); break;
         case 9: MPF_FW_BUCKET(9); break;
@@ -595,6 +667,7 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
 #undef MPF_FW_BUCKET
         return mpf_launch_status("forward_warp kernels");
     }
+    if (proj) hipLaunchKernelGGL(k_moving_object_project, dim3(g256), dim3(256), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out);
     hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], win, zero_fill ? d_warped : (uint8_t *)nullptr);
     // the fewest passes of 8..11-bit digits that cover the key: 640 x 960 (20 bits) -> 2 x 10, 1024 x 1536 (21 bits) -> 2 x 11
     if (bits < 1) bits = 1;
@@ -613,7 +686,7 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_fw_mark, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, N, win);
-    hipLaunchKernelGGL(k_fw_write, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, d_src, N, win, d_warped);
+    hipLaunchKernelGGL(k_fw_write, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, d_src, N, win, d_warped, src_f);
     return mpf_launch_status("forward_warp kernels");
 }
 
@@ -627,8 +700,9 @@ extern "C" int mpf_forward_warp(const uint8_t *d_src, const int64_t *d_idx, cons
 
 __global__ void __launch_bounds__(256)
 k_warp_masks(const uint8_t *__restrict__ warped, int H, int W, uint8_t *__restrict__ Hm, uint8_t *__restrict__ M,
-             uint8_t *__restrict__ Md, uint8_t *__restrict__ P, uint8_t *__restrict__ Hp)
+             uint8_t *__restrict__ Md, uint8_t *__restrict__ P, uint8_t *__restrict__ Hp, const int prio = 0)
 {
+    MPF_FW_SETPRIO(prio);
     const int64_t N = (int64_t)H * W;
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -657,8 +731,31 @@ extern "C" int mpf_warp_masks(const uint8_t *d_warped, int H, int W, uint8_t *d_
     MPF_REQUIRE(d_warped && d_Hm && d_M && d_Md && d_P && d_Hp && H >= 1 && W >= 1, "mpf_warp_masks: bad argument");
     const int64_t N = (int64_t)H * W;
     hipLaunchKernelGGL(k_warp_masks, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_warped, H, W, d_Hm,
-                       d_M, d_Md, d_P, d_Hp);
+                       d_M, d_Md, d_P, d_Hp, g_fw_prio);
     return mpf_launch_status("k_warp_masks");
+}
+
+// ---- moving_obj.py:29-150 as ONE call: projection (fused into the first sort pass), forward splat, masks ------------------------
+
+extern "C" int mpf_moving_object_chain(const float *d_disp, const float *h_inv_k9, const float *h_P_static12, const float *h_P_obj12,
+                                       const float *d_inst, const uint8_t *d_src_u8, const float *d_src_f32_3HW, int H, int W,
+                                       const MpfMovingObjectOut *out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    MPF_REQUIRE(d_disp && h_inv_k9 && h_P_static12 && h_P_obj12 && d_inst && out && H >= 1 && W >= 1, "mpf_moving_object_chain: bad argument");
+    MPF_REQUIRE((d_src_u8 != nullptr) != (d_src_f32_3HW != nullptr), "mpf_moving_object_chain: give the source frame as uint8 [H,W,3] OR as float [3,H,W], not both");
+    MPF_REQUIRE(out->d_p1 && out->d_z1 && out->d_safe_x && out->d_safe_y && out->d_flow01 && out->d_warped, "mpf_moving_object_chain: null output");
+    const bool masks = out->d_Hm || out->d_M || out->d_Md || out->d_P || out->d_Hp;
+    MPF_REQUIRE(!masks || (out->d_Hm && out->d_M && out->d_Md && out->d_P && out->d_Hp), "mpf_moving_object_chain: the five masks go together");
+    FwProj pr;
+    pr.disp = d_disp; pr.inst = d_inst;
+    memcpy(pr.m.ik, h_inv_k9, sizeof(pr.m.ik));
+    memcpy(pr.m.Ps, h_P_static12, sizeof(pr.m.Ps));
+    memcpy(pr.m.Po, h_P_obj12, sizeof(pr.m.Po));
+    pr.out = MpfMoOut{ out->d_p1, out->d_z1, out->d_safe_x, out->d_safe_y, out->d_flow01 };
+    pr.src_f = d_src_f32_3HW;
+    const int rc = fw_run(d_src_u8, out->d_safe_x, out->d_safe_y, out->d_z1, out->d_warped, H, W, d_workspace, workspace_bytes, stream, true, &pr);
+    if (rc || !masks || (g_fw_stop >= 1 && g_fw_stop <= 4)) return rc;
+    return mpf_warp_masks(out->d_warped, H, W, out->d_Hm, out->d_M, out->d_Md, out->d_P, out->d_Hp, stream);
 }
 
 // ---- the reference's FFI symbol (host pointers) -----------------------------------------------------------------

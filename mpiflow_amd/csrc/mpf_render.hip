@@ -562,6 +562,14 @@ k_warp_composite_dbg(const float *__restrict__ rgba, const float *__restrict__ q
 #ifndef MPF_STRIP_TILES
 #define MPF_STRIP_TILES 4
 #endif
+// mpf_xcd_remap for a role that owns only NX of the 8 XCDs (k_pair_overlap with the roles partitioned by XCD): j = k * NX + x is the k-th
+// block of the role's x-th XCD; that XCD gets the x-th contiguous chunk of the logical order.
+MPF_DEV unsigned mpf_xcd_remap_n(unsigned j, unsigned nwg, unsigned NX)
+{
+    const unsigned x = j % NX, k = j / NX, q = nwg / NX, r = nwg % NX;
+    return ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 MPF_DEV unsigned mpf_strip_order(unsigned t, unsigned tiles_x, unsigned tiles_y)
 {
     const unsigned SWd = MPF_STRIP_TILES, nfull = tiles_x / SWd, full = nfull * SWd * tiles_y;
@@ -1546,25 +1554,38 @@ MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const
 template <bool HAS_MASK, int NL, int P, bool ACT, int DEPTH>
 __global__ void __launch_bounds__(256, 5)
 k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsigned V, const MpfSbfArgs ac, const int S, const int H, const int W,
-               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate, const unsigned view_shift)
+               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate, const unsigned view_shift, const unsigned xcd_a)
 {
     constexpr int TW = 32, TH = 8;
     const unsigned xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;          // the k-th workgroup of this XCD
-    const unsigned per = KB + KA;
-    const unsigned a0 = (k * KA) / per, a1 = ((k + 1u) * KA) / per;     // A+C workgroups among the first k / k + 1 of this XCD
-    if (a1 > a0) {
-        const unsigned ja = a0 * 8u + xcd;
+    bool role_a;
+    unsigned ja = 0, jb = 0, l = 0;
+    if (xcd_a) {
+        // roles partitioned by XCD (mpf_tune("ovl_xcd_a", n)): the first n XCDs run Stage A+C workgroups only, the others Stage B only, so
+        // the streaming role's 1.27 GB cannot evict the gather role's texel rows from the L2 they are re-used in
+        role_a = xcd < xcd_a;
+        ja = k * xcd_a + xcd;
+        jb = k * (8u - xcd_a) + (xcd - xcd_a);
+        if (!role_a) l = mpf_xcd_remap_n(jb, nB, 8u - xcd_a);
+    } else {
+        const unsigned per = KB + KA;
+        // 64-bit: k * KA passes 2^32 for shallow stacks of very large frames (S <= 7 with 16 views at ~2^25 px)
+        const unsigned a0 = (unsigned)(((uint64_t)k * KA) / per), a1 = (unsigned)(((uint64_t)(k + 1u) * KA) / per);   // A+C workgroups among the first k / k + 1 of this XCD
+        role_a = a1 > a0;
+        ja = a0 * 8u + xcd;
+        jb = (k - a0) * 8u + xcd;
+        if (!role_a) l = mpf_xcd_remap(jb, nB);
+    }
+    if (role_a) {
         if (ja >= nA || (ablate & 3) == 1) return;                       // ablate (bench only): 1 = Stage B workgroups only, 2 = Stage A+C only
         if (((ablate >> 2) & 3) == 1) __builtin_amdgcn_s_setprio(1);      // bits 2-3: wave priority of the A+C role (tuning experiment)
         else if (((ablate >> 2) & 3) == 2) __builtin_amdgcn_s_setprio(2);
         else if (((ablate >> 2) & 3) == 3) __builtin_amdgcn_s_setprio(3);
         mpf_sbf_stream<MPF_OVL_PX, P, NL, ACT, DEPTH>(ac, S, H, W, (int64_t)ja * 256 + threadIdx.x);
     } else {
-        const unsigned jb = (k - a0) * 8u + xcd;
         if (jb >= nB || (ablate & 3) == 2) return;
         if (((ablate >> 4) & 3) == 1) __builtin_amdgcn_s_setprio(1);      // bits 4-5: wave priority of the Stage B role
         else if (((ablate >> 4) & 3) == 3) __builtin_amdgcn_s_setprio(3);
-        const unsigned l = mpf_xcd_remap(jb, nB);
         const unsigned view = l % V;
         const unsigned tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = tiles_x * tiles_y;
         const unsigned seq = (view & 1u) ? (l / V + view_shift) % ntiles : l / V;        // see k_warp_composite_views
@@ -1577,6 +1598,7 @@ k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsi
 
 static int g_ovl_depth = 4;     // mpf_tune("ovl_depth", 4 | 8): no measurable difference at 64x640x960 (both 492-523 us per launch on one box)
 static int g_ovl_ablate = 0;    // mpf_tune("ovl_ablate", 0 | 1 | 2): bench-only, results invalid when non-zero
+static int g_ovl_xcd_a = 0;     // mpf_tune("ovl_xcd_a", 0..7): 0 = both roles interleaved on every XCD (Bresenham), n = the first n XCDs run Stage A+C only
 
 template <bool HAS_MASK, int NL, int P, bool ACT>
 static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V, const MpfSbfArgs &ac, int S, int H, int W, hipStream_t st)
@@ -1585,11 +1607,17 @@ static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V,
     const unsigned nB = tiles * V;
     const unsigned nA = (unsigned)((ac.T + 255) / 256);              // ac.T = threads of the A+C role (N / MPF_OVL_PX, rounded up)
     const unsigned KB = (nB + 7) / 8, KA = (nA + 7) / 8;
-    dim3 grid(8u * (KB + KA)), block(256);
+    const unsigned xa = (unsigned)g_ovl_xcd_a;
+    unsigned per_xcd = KB + KA;
+    if (xa) {                                                        // roles by XCD: every XCD gets as many workgroups as the busiest one needs (the rest exit at once)
+        const unsigned pa = (nA + xa - 1) / xa, pb = (nB + (8u - xa) - 1) / (8u - xa);
+        per_xcd = pa > pb ? pa : pb;
+    }
+    dim3 grid(8u * per_xcd), block(256);
     if (g_ovl_depth == 4)
-        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles);
+        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa);
     else
-        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 8>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles);
+        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 8>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa);
     return mpf_launch_status("k_pair_overlap");
 }
 
@@ -1649,6 +1677,8 @@ extern "C" int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int
 }
 
 void mpf_fwarp_set_path(int v);      // mpf_fwarp.hip
+void mpf_fwarp_set_prio(int v);
+void mpf_fwarp_set_stop(int v);
 
 extern "C" int mpf_tune(const char *key, int value)
 {
@@ -1658,6 +1688,9 @@ extern "C" int mpf_tune(const char *key, int value)
     if (key && !strcmp(key, "ovl_ablate")) { g_ovl_ablate = value; return 0; }
     if (key && !strcmp(key, "view_shift")) { g_view_shift = value < 0 ? 0 : value; return 0; }
     if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
+    if (key && !strcmp(key, "chain_stop")) { mpf_fwarp_set_stop(value); return 0; }
+    if (key && !strcmp(key, "chain_prio")) { mpf_fwarp_set_prio(value); return 0; }
+    if (key && !strcmp(key, "ovl_xcd_a")) { g_ovl_xcd_a = (value < 0 || value > 7) ? 0 : value; return 0; }
     mpf_set_error("mpf_tune: unknown key");
     return MPF_ERR_BAD_ARGUMENT;
 }

@@ -33,6 +33,39 @@ def object_pose(rng=None):
     return host_math.transformation_from_parameters(ai, tri)
 
 
+def projection_matrices(K, T_obj):
+    """P_static = (K4 . T1)[:3], P_obj = (K4 . Ti)[:3] with the reference's expressions (moving_obj.py:43-52, geometry.py:65)."""
+    K = host_math._cpu32(K).reshape(3, 3)
+    K4 = torch.zeros((1, 4, 4)); K4[0, -1, -1] = 1.0; K4[:, :3, :3] = K          # :49-52
+    T1 = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.zeros(1, 3))   # :43-47
+    Ti = host_math._cpu32(T_obj).reshape(1, 4, 4)
+    return torch.matmul(K4, T1)[:, :3, :][0].contiguous(), torch.matmul(K4, Ti)[:, :3, :][0].contiguous()
+
+
+class MovingObjectChain:
+    """moving_obj.py:29-150 for a STREAM of frames of one size: matrices prepared once per object pose, `n_buffers` preallocated
+    output sets used round-robin (a set is rewritten n_buffers run() calls later), one C call = 5 launches per frame, no
+    allocation.  pipeline.OverlappedPairRenderer runs it on a side stream underneath the pair launches."""
+
+    def __init__(self, H, W, K, inv_K, device, T_obj=None, n_buffers=2):
+        self.H, self.W, self.device = H, W, torch.device(device)
+        self.inv_K = host_math._cpu32(inv_K).reshape(9).contiguous()
+        self.set_object_pose(K, object_pose() if T_obj is None else T_obj)
+        self.bufs = [ops.MovingObjectBuffers(H, W, self.device) for _ in range(n_buffers)]
+        self._next = 0
+
+    def set_object_pose(self, K, T_obj):
+        self.P_static, self.P_obj = projection_matrices(K, T_obj)
+
+    def run(self, disp, inst, src_u8, which=None):
+        """disp [H,W] f32, inst [H,W] f32 (> 0 = the moving instance), src_u8 [H,W,3] - device tensors; launches on the current
+        stream into output set `which` (default: round-robin).  -> ops.MovingObjectBuffers (p1, z1, safe_x, safe_y, flow_01, warped, masks)"""
+        if which is None:
+            which, self._next = self._next, (self._next + 1) % len(self.bufs)
+        b = self.bufs[which]
+        return ops.moving_object_chain(disp, self.inv_K, self.P_static, self.P_obj, inst, src_u8, bufs=b)
+
+
 def moveing_object_with_mask(depth_path, disp, rgb, K, inv_K, instance_mask, i, T_obj=None, write_debug_png=True,
                              inpaint="auto", return_intermediates=False):
     """(sic) reference moving_obj.py:16-168.
@@ -46,21 +79,16 @@ def moveing_object_with_mask(depth_path, disp, rgb, K, inv_K, instance_mask, i, 
     h, w = rgb.shape[:2]
     dev = disp.device if disp.is_cuda else torch.device("cuda")
     disp_d = disp.to(dev, torch.float32).reshape(h, w)
-    K = host_math._cpu32(K).reshape(3, 3)
     inv_K = host_math._cpu32(inv_K).reshape(3, 3)
-    K4 = torch.zeros((1, 4, 4)); K4[0, -1, -1] = 1.0; K4[:, :3, :3] = K          # :49-52
-    T1 = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.zeros(1, 3))   # :43-47
     if T_obj is None:
         T_obj = object_pose()
-    Ti = host_math._cpu32(T_obj).reshape(1, 4, 4)
-    P1 = torch.matmul(K4, T1)[:, :3, :][0]                                       # geometry.py:65
-    Pi = torch.matmul(K4, Ti)[:, :3, :][0]
+    P1, Pi = projection_matrices(K, T_obj)                                       # :43-52, geometry.py:65
     inst = instance_mask.to(dev, torch.float32).reshape(h, w)
-    # :29-30 depth, :63-66 / :101-105 the two projections, :108-124 select + truncate, :153 flow - one fused kernel
-    p1, z1, safe_x, safe_y, flow_01 = ops.moving_object_project(disp_d, inv_K, P1, Pi, inst)
     img = torch.from_numpy(np.ascontiguousarray(rgb)).to(dev).float().reshape(-1).to(torch.uint8)   # :20, :124
-    warped = ops.forward_warp(img, safe_x, safe_y, z1, h, w)                     # :127-129
-    masks = ops.warp_masks(warped)                                               # :133-150
+    # :29-30 depth, :63-66 / :101-105 the two projections, :108-124 select + truncate, :153 flow (fused into the sort's first pass),
+    # :127-129 the forward splat, :133-150 the masks - one C call
+    b = ops.moving_object_chain(disp_d, inv_K, P1, Pi, inst, img.reshape(h, w, 3))
+    p1, z1, safe_x, safe_y, flow_01, warped, masks = b.p1, b.z1, b.safe_x, b.safe_y, b.flow_01, b.warped, b.masks
     im1_raw = warped[:, :, 0:3]
     hole = (1 - masks["H"]).to(torch.uint8)
     from .utils.utils import _inpaint                                            # :162 cv2.inpaint(im1_raw, 1 - H, 3, INPAINT_TELEA)

@@ -623,3 +623,56 @@ def warp_masks(warped_HW5):
     outs = [torch.empty((H, W), dtype=torch.uint8, device=w5.device) for _ in range(5)]
     _lib.check(lib.mpf_warp_masks(_ptr(w5), H, W, *[_ptr(o) for o in outs], _stream()), "mpf_warp_masks")
     return dict(zip(["H", "M", "M'", "P", "H'"], outs))
+
+
+class MovingObjectBuffers:
+    """Preallocated outputs + sort workspace of mpf_moving_object_chain for one (H, W) on one device (28 N bytes of results)."""
+
+    def __init__(self, H, W, device):
+        lib = _lib.load()
+        dev = torch.device(device)
+        u8 = torch.uint8
+        self.H, self.W, self.device = H, W, dev
+        self.p1 = torch.empty((H, W, 2), dtype=_f32, device=dev)
+        self.z1 = torch.empty((H, W), dtype=_f32, device=dev)
+        self.safe_x = torch.empty((H, W), dtype=torch.int64, device=dev)
+        self.safe_y = torch.empty((H, W), dtype=torch.int64, device=dev)
+        self.flow_01 = torch.empty((H, W, 2), dtype=_f32, device=dev)
+        self.warped = torch.empty((H, W, 5), dtype=u8, device=dev)
+        self.masks = {k: torch.empty((H, W), dtype=u8, device=dev) for k in ("H", "M", "M'", "P", "H'")}
+        self.ws_bytes = lib.mpf_forward_warp_workspace(H, W)
+        self._ws = torch.empty(self.ws_bytes + 256, dtype=u8, device=dev)
+        self.ws_ptr = self._ws.data_ptr() + (-self._ws.data_ptr()) % 256
+        m = self.masks
+        self.ready = None        # set by pipeline.OverlappedPairRenderer (unordered chain): torch event recorded behind the launches that fill this set
+        self.consumed = None     # optional, set by the consumer: torch event the side stream waits for before it rewrites this set
+        self.c_out = _lib.MpfMovingObjectOut(self.p1.data_ptr(), self.z1.data_ptr(), self.safe_x.data_ptr(), self.safe_y.data_ptr(),
+                                             self.flow_01.data_ptr(), self.warped.data_ptr(), m["H"].data_ptr(), m["M"].data_ptr(),
+                                             m["M'"].data_ptr(), m["P"].data_ptr(), m["H'"].data_ptr())
+
+    def as_dict(self):
+        return dict(p1=self.p1, z1=self.z1, safe_x=self.safe_x, safe_y=self.safe_y, flow_01=self.flow_01, warped=self.warped, masks=self.masks)
+
+
+@_on_device
+def moving_object_chain(disp_HW, inv_K33, P_static34, P_obj34, inst_HW, src, bufs=None):
+    """moving_obj.py:29-150 in one call (mpf_moving_object_chain): projection fused into the forward warp's first sort pass, splat, masks.
+    src: the frame that is splatted - uint8 [H,W,3], or float32 [3,H,W] in 0..1 (its uint8 BGR form is splatted, converted on the fly).
+    -> MovingObjectBuffers (bufs or a new one)"""
+    lib = _lib.load()
+    disp = _dev(disp_HW, "disp")
+    H, W = disp.shape[-2:]
+    inst = _dev(inst_HW, "instance mask")
+    as_float = src.dtype != torch.uint8
+    src = _dev(src, "src", _f32 if as_float else torch.uint8)
+    assert inst.numel() == H * W and src.numel() == H * W * 3 and (not as_float or tuple(src.shape[-3:]) == (3, H, W))
+    if bufs is None:
+        bufs = MovingObjectBuffers(H, W, disp.device)
+    assert (bufs.H, bufs.W) == (H, W) and bufs.device == disp.device
+    ik = host_math._cpu32(inv_K33).reshape(9).contiguous()
+    Ps = host_math._cpu32(P_static34).reshape(12).contiguous()
+    Po = host_math._cpu32(P_obj34).reshape(12).contiguous()
+    _lib.check(lib.mpf_moving_object_chain(_ptr(disp), ctypes.c_void_p(ik.data_ptr()), ctypes.c_void_p(Ps.data_ptr()), ctypes.c_void_p(Po.data_ptr()),
+                                           _ptr(inst), None if as_float else _ptr(src), _ptr(src) if as_float else None, H, W, ctypes.byref(bufs.c_out), ctypes.c_void_p(bufs.ws_ptr), bufs.ws_bytes,
+                                           _stream()), "mpf_moving_object_chain")
+    return bufs

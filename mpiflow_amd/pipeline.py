@@ -196,7 +196,17 @@ class OverlappedPairRenderer(_PairHostSide):
 
     push(mpi, image, prep, obj_mask, out) enqueues pair i+1 and completes pair i (its `out` = (flow_mix [H,W,2], frame_mix [H,W,3] u8,
     fill_mask [H,W] u8) is written, stream-ordered, by the time push returns); flush() completes the last one.  Two slots of
-    per-pair buffers (blended stack, flows, quads, views) alternate: a slot is rewritten only after its pair has been merged."""
+    per-pair buffers (blended stack, flows, quads, views) alternate: a slot is rewritten only after its pair has been merged.
+
+    LIFETIME of the caller's tensors: `obj_mask` and `out` of pair i (and `moving`'s disparity / instance mask) are read / written by
+    the launches that COMPLETE pair i, i.e. inside the NEXT push() / flush().  They must stay untouched until that call has been issued;
+    a streaming caller alternates two buffers (as the renderer's own slots do).  `mpi` / `image` are consumed by the push they are given to.
+
+    attach_chain(chain): SURVEY 8(d)'s full c3 - the moving-object chain of every pair (moving_obj.MovingObjectChain: depth -> flow
+    projection, forward warp of the pair's uint8 source frame, masks; moving_obj.py:29-150) runs on a SIDE stream.  The chain of pair i
+    needs nothing but the source frame Stage A+C of pair i wrote, so it is issued right behind the launch that carried that role and runs
+    underneath the NEXT launch (Stage B of pair i); the main stream waits for it only when pair i is handed back, a whole pair launch
+    later - no wait ever sits between two pair launches."""
 
     def __init__(self, S, H, W, device, thresh=MASK_THRESH):
         self.S, self.H, self.W, self.device, self.thresh = S, H, W, torch.device(device), thresh
@@ -208,33 +218,97 @@ class OverlappedPairRenderer(_PairHostSide):
                                        rgb_u8=torch.empty((H, W, 3), dtype=torch.uint8, device=dev)) for _ in range(2)])
                       for _ in range(2)]
         self._next, self._pending = 0, None
+        self.chain, self.side = None, None
         self.on_fused = None                                         # optional hook(callable launching) -> used by bench.py to bracket with events
         # the overlapped launch addresses the stack through 32-bit buffer offsets: stacks of 4 GiB and more take the two separate launches
         self.fusable = S * H * W * 16 < (1 << 32)
 
+    def attach_chain(self, chain, high_priority=False, ordered=True):
+        """chain: moving_obj.MovingObjectChain with (at least) two output sets.
+        ordered=True: the chain splats the uint8 source frame the pair's Stage A+C role wrote and its results are stream-ordered on the
+          MAIN stream when the pair is handed back - costs the main stream an event record and an event wait per pair (measured: 12 us per
+          pair at 64 x 640 x 960, the command processor handles both between two pair launches).
+        ordered=False: the chain is an independent side pipeline.  It converts the pair's float image to the same uint8 bytes itself, so it
+          needs no output of the render path and NOTHING is inserted into the main stream: it is issued at the top of push(), each handed-back
+          ops.MovingObjectBuffers carries `.ready` (a torch event to wait for on whatever stream consumes it; `image` / `moving` tensors of
+          that pair must stay untouched until then), a consumer that sets `.consumed` (event) on a set protects it from being rewritten
+          too early, `moving_ready` of push() names the event after which the pair's inputs may be read (None: one is recorded on the main
+          stream), and flush() joins the side stream.
+        high_priority: the side stream gets the device's highest stream priority (no measurable effect at 64 x 640 x 960)."""
+        assert len(chain.bufs) >= 2 and (chain.H, chain.W) == (self.H, self.W)
+        self.chain, self.chain_ordered, self._chain_next = chain, ordered, 0
+        self.side = torch.cuda.Stream(self.device, priority=-1 if high_priority else 0)
+        for k, s in enumerate(self.slots):
+            s["index"], s["ev_src"], s["ev_chain"], s["moving"] = k, torch.cuda.Event(), torch.cuda.Event(), None
+
     def _views(self, slot, prep):
         return [dict(dparams=prep["warp"][v], quads=slot["quads"][v], out=slot["views"][v]) for v in range(2)]
+
+    def _start_chain(self, slot, moving):
+        """ordered chain, right behind the launch whose Stage A+C role wrote slot['src_u8']: the pair's moving-object chain, on the side stream."""
+        if self.chain is None or not self.chain_ordered:
+            return
+        slot["moving"] = None
+        if moving is None:
+            return
+        slot["ev_src"].record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(slot["ev_src"])
+            if os.environ.get("MPF_CHAIN_DEBUG") == "events_only":      # measurement hook (tools/): the event choreography without the chain's kernels
+                slot["moving"] = self.chain.bufs[slot["index"]]
+            else:
+                slot["moving"] = self.chain.run(moving[0], moving[1], slot["src_u8"], which=slot["index"])
+            slot["ev_chain"].record()
+
+    def _start_chain_unordered(self, slot, image, moving, moving_ready):
+        """independent chain, at the top of push(): reads nothing the render path writes."""
+        slot["moving"] = None
+        if moving is None:
+            return
+        which, self._chain_next = self._chain_next, (self._chain_next + 1) % len(self.chain.bufs)
+        b = self.chain.bufs[which]
+        if moving_ready is None:
+            moving_ready = torch.cuda.Event()
+            moving_ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(moving_ready)
+            if b.consumed is not None:
+                self.side.wait_event(b.consumed)
+            self.chain.run(moving[0], moving[1], image, which=which)
+            b.ready = torch.cuda.Event()
+            b.ready.record()
+        slot["moving"] = b
 
     def _finish(self, pend):
         slot, om, out = pend["slot"], pend["om"], pend["out"]
         v = slot["views"]
-        return ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], slot["flows"][0], slot["flows"][1], om, self.thresh, out=out)
+        done = ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], slot["flows"][0], slot["flows"][1], om, self.thresh, out=out)
+        if slot.get("moving") is not None:
+            if self.chain_ordered:
+                torch.cuda.current_stream().wait_event(slot["ev_chain"])      # issued a whole pair launch ago: normally long since complete
+            done = tuple(done) + (slot["moving"],)
+        return done
 
-    def push(self, mpi, image, prep, obj_mask, out=None, cum_mask=None):
+    def push(self, mpi, image, prep, obj_mask, out=None, cum_mask=None, moving=None, moving_ready=None):
         """Enqueue one pair (prep from prepare(K, disparity, [G_cam, G_dyn]); view 0 samples obj_mask, view 1 its complement).
-        Returns the (flow_mix, frame_mix, fill_mask) of the PREVIOUS pair, or None if there was none."""
+        moving = (disp [H,W], instance mask [H,W]) with a chain attached: the pair's moving-object chain runs on the side stream.
+        Returns the (flow_mix, frame_mix, fill_mask[, ops.MovingObjectBuffers]) of the PREVIOUS pair, or None if there was none."""
         assert prep["P"] == 2
         slot = self.slots[self._next]
         self._next ^= 1
         done = None
+        if self.chain is not None and not self.chain_ordered:
+            self._start_chain_unordered(slot, image, moving, moving_ready)
         if self._pending is None:
             ops.src_blend_flow(mpi, image, out_rgba=slot["rgba"], out_flows=slot["flows"], dparams=prep["blend"], P=2, src_u8=slot["src_u8"],
                                obj_mask=obj_mask, quads=slot["quads"][0], quads_complement=slot["quads"][1], cum_mask=cum_mask)
+            self._start_chain(slot, moving)
         elif not self.fusable:
             pend = self._pending
             ops.warp_composite_views(pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), interleaved=2)
             ops.src_blend_flow(mpi, image, out_rgba=slot["rgba"], out_flows=slot["flows"], dparams=prep["blend"], P=2, src_u8=slot["src_u8"],
                                obj_mask=obj_mask, quads=slot["quads"][0], quads_complement=slot["quads"][1], cum_mask=cum_mask)
+            self._start_chain(slot, moving)
             done = self._finish(pend)
         else:
             pend = self._pending
@@ -246,6 +320,7 @@ class OverlappedPairRenderer(_PairHostSide):
                 self.on_fused(launch)
             else:
                 launch()
+            self._start_chain(slot, moving)
             done = self._finish(pend)
         self._pending = dict(slot=slot, prep=prep, om=obj_mask, out=out)
         return done
@@ -256,7 +331,10 @@ class OverlappedPairRenderer(_PairHostSide):
             return None
         pend, self._pending = self._pending, None
         ops.warp_composite_views(pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), interleaved=2)
-        return self._finish(pend)
+        done = self._finish(pend)
+        if self.chain is not None and not self.chain_ordered:
+            torch.cuda.current_stream().wait_stream(self.side)                # the independent chain joins the main stream here
+        return done
 
     @property
     def pending_slot(self):

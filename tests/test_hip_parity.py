@@ -368,6 +368,124 @@ def test_moving_object_chain_vs_reference_golden(dev, oracle, name):
         assert bits_equal(N(masks[k]), om[k]) == 0, k
 
 
+def _fwarp_inputs(g):
+    """Inputs of a forward-warp golden: stored (small case) or regenerated exactly as tests/golden/make_golden.py::gen_fwarp does."""
+    H, W = int(g["H"]), int(g["W"])
+    if "disp" in g:
+        return H, W, g["disp"], g["rgb"], g["inst"]
+    from mpiflow_amd import synth
+    rs = np.random.RandomState(int(g["seed"]))
+    base = synth._upsample(rs.rand(max(H // 16, 2), max(W // 16, 2)), H, W) * 0.3 + 0.05
+    inst = np.zeros((H, W), np.float32)
+    inst[H // 3: 2 * H // 3, W // 3: 2 * W // 3] = 1.0
+    disp = (base + 0.5 * inst).astype(np.float32)
+    rgb = np.floor(rs.rand(H, W, 3) * 256).astype(np.uint8)
+    return H, W, disp, rgb, inst
+
+
+def _check_chain_against_golden(g, b, oracle):
+    """b: ops.MovingObjectBuffers.  Everything the reference handed to / got from its C routine, and the masks vs the oracle."""
+    import hashlib
+    sx, sy, z1, warped, masks = b.safe_x, b.safe_y, b.z1, b.warped, b.masks
+    if "safe_x" in g:
+        assert bits_equal(N(sx), g["safe_x"]) == 0 and bits_equal(N(sy), g["safe_y"]) == 0
+        assert bits_equal(N(z1), g["z1"]) == 0
+        assert bits_equal(N(warped), g["warped"]) == 0
+        assert bits_equal((1 - N(masks["H"])).astype(np.uint8), g["inpaint_mask"].astype(np.uint8)) == 0
+    else:
+        px = g["sample_px"]
+        assert bits_equal(N(sx).ravel()[px], g["safe_x_px"]) == 0 and bits_equal(N(sy).ravel()[px], g["safe_y_px"]) == 0
+        assert bits_equal(N(z1).ravel()[px], g["z1_px"]) == 0
+        assert bits_equal(N(warped).reshape(-1, 5)[px], g["warped_px"]) == 0
+        assert bits_equal(np.packbits(N(warped)[..., 3].ravel()), g["valid_bits"]) == 0
+        assert bits_equal(np.packbits(N(warped)[..., 4].ravel()), g["single_bits"]) == 0
+        assert hashlib.sha256(np.ascontiguousarray(N(sx)).tobytes()).hexdigest() == str(g["sha_idx"])
+        assert hashlib.sha256(np.ascontiguousarray(N(sy)).tobytes()).hexdigest() == str(g["sha_idy"])
+        assert hashlib.sha256(np.ascontiguousarray(N(z1)).tobytes()).hexdigest() == str(g["sha_z"])
+        assert hashlib.sha256(np.ascontiguousarray(N(warped)).tobytes()).hexdigest() == str(g["sha_warped"])
+    om = oracle.warp_masks(N(warped))
+    for k in om:
+        assert bits_equal(N(masks[k]), om[k]) == 0, k
+
+
+@pytest.mark.parametrize("name", ["fwarp_small", "fwarp_c2"])
+def test_one_call_moving_object_chain_vs_reference_golden(dev, oracle, name):
+    """mpf_moving_object_chain (projection fused into the first sort pass, splat, masks: one C call) against what the reference's
+    moveing_object_with_mask handed to / got from its C routine, and bit for bit against the separate kernels."""
+    from mpiflow_amd import moving_obj, ops
+    g = load_golden(name)
+    H, W, disp, rgb, inst = _fwarp_inputs(g)
+    chain = moving_obj.MovingObjectChain(H, W, g["K"], g["inv_K"], dev, T_obj=torch.from_numpy(g["T_obj"])[None])
+    b = chain.run(T(disp, dev), T(inst, dev), T(rgb.astype(np.uint8), dev))
+    _check_chain_against_golden(g, b, oracle)
+    p1, z1, sx, sy, fl = ops.moving_object_project(T(disp, dev), g["inv_K"], chain.P_static, chain.P_obj, T(inst, dev))
+    for a, c in ((b.p1, p1), (b.z1, z1), (b.safe_x, sx), (b.safe_y, sy), (b.flow_01, fl)):
+        assert torch.equal(a, c)
+    assert torch.equal(b.warped, ops.forward_warp(T(rgb.astype(np.uint8), dev), sx, sy, z1, H, W))
+    # the second output set, and a re-run into the first one (stale contents must not leak: every byte is rewritten)
+    b2 = chain.run(T(disp, dev), T(inst, dev), T(rgb.astype(np.uint8), dev))
+    assert b2 is not b and torch.equal(b2.warped, b.warped)
+    b.warped.fill_(77)
+    b3 = chain.run(T(disp, dev), T(inst, dev), T(rgb.astype(np.uint8), dev))
+    assert b3 is b
+    _check_chain_against_golden(g, b3, oracle)
+
+
+def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
+    """SURVEY 8(d)'s full c3 in the throughput form bench.py times: a stream of 64 x 640 x 960 dynamic pairs through
+    pipeline.OverlappedPairRenderer with the moving-object chain attached (side stream, two output sets) - for EVERY pair of the stream
+    the chain's outputs are the bytes the reference produced at this size (fwarp_c2.npz: digests of the full safe_x / safe_y / z / warped
+    arrays, packed validity and collision bits), the splatted frame being the uint8 source frame the pair's Stage A+C role wrote (ordered
+    chain) or the same bytes converted from the pair's float image by the chain itself (the independent chain bench.py times); and the
+    render outputs stay bit-identical to the same stream without the chain."""
+    from mpiflow_amd import host_math, moving_obj, pipeline, synth
+    g = load_golden("fwarp_c2")
+    H, W, disp, rgb, inst = _fwarp_inputs(g)
+    S = 64
+    K, pd = synth.intrinsics(H, W), synth.plane_disparities(S)
+    rng = __import__("random").Random(11)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    stacks = []
+    for k in range(2):
+        mpi = torch.rand((S, 4, H, W), generator=gen, device=dev)
+        mpi[:, 3] = torch.relu(3.0 * torch.randn((S, H, W), generator=gen, device=dev) - 4.0) + 1e-4
+        stacks.append(mpi)
+    # the frame whose uint8 BGR form (what Stage A+C writes as the pair's source frame) is the golden's rgb array
+    img = T(np.ascontiguousarray(rgb[..., ::-1].transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0), dev)
+    om = T(synth.soft_box_mask(H, W), dev)
+    d_disp, d_inst = T(disp, dev), T(inst, dev)
+    poses = [(host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng), host_math.generate_random_pose(0.15, rng=rng)) for _ in range(5)]
+
+    def stream(with_chain, high_priority=False, ordered=True):
+        ovl = pipeline.OverlappedPairRenderer(S, H, W, dev)
+        if with_chain:
+            ovl.attach_chain(moving_obj.MovingObjectChain(H, W, g["K"], g["inv_K"], dev, T_obj=torch.from_numpy(g["T_obj"])[None], n_buffers=2 if ordered else 3),
+                             high_priority=high_priority, ordered=ordered)
+        outs = [tuple(torch.empty(s, dtype=dt, device=dev) for s, dt in (((H, W, 2), torch.float32), ((H, W, 3), torch.uint8), ((H, W), torch.uint8))) for _ in range(2)]
+        res = []
+
+        def take(done):
+            if done is None:
+                return
+            if with_chain:
+                assert len(done) == 4
+                if not ordered:
+                    done[3].ready.synchronize()                          # the independent chain: results come with their own event
+                _check_chain_against_golden(g, done[3], oracle)          # synchronises (reads back): the NEXT push then overwrites nothing in use
+            res.append([N(t).copy() for t in done[:3]])
+        for k, (Gc, Gd) in enumerate(poses):
+            take(ovl.push(stacks[k % 2], img, ovl.prepare(K, pd, [Gc, Gd]), om, out=outs[k % 2], moving=(d_disp, d_inst) if with_chain else None))
+        take(ovl.flush())
+        assert len(res) == len(poses)
+        return res
+    plain = stream(False)
+    for hp, ordered in ((False, True), (True, True), (False, False)):
+        got = stream(True, high_priority=hp, ordered=ordered)
+        for k, (a, b) in enumerate(zip(plain, got)):
+            for x, y in zip(a, b):
+                assert bits_equal(x, y) == 0, "pair %d: render output changed with the chain attached" % k
+
+
 def test_fused_byproducts_equal_standalone_kernels(dev):
     """Stage A+C's fused source-u8 / mask-quad outputs and Stage B's fused u8 frame must equal the stand-alone kernels."""
     from mpiflow_amd import host_math, ops
@@ -631,15 +749,16 @@ def test_overlapped_launch_equals_separate_launches(dev, kernel_exp, S, H, W):
             w_q = [torch.empty((H, W, 4), device=dev) for _ in range(2)]
             ops.src_blend_flow(mk(b["mpi"]), mk(b["image"]), out_rgba=w_rgba, out_flows=w_fl, dparams=dp, P=P, src_u8=w_u8, obj_mask=mk(b["obj_mask"]),
                                quads=w_q[0], quads_complement=w_q[1], cum_mask=cm)
-            for depth in (8, 4):
+            for depth, xcd_a in ((8, 0), (4, 0), (4, 3), (4, 1), (4, 7)):          # xcd_a: the roles partitioned by XCD instead of interleaved
                 _lib.check(_lib.load().mpf_tune(b"ovl_depth", depth))
+                _lib.check(_lib.load().mpf_tune(b"ovl_xcd_a", xcd_a))
                 g_rgba = ops.alloc_rgba_stack(S, H, W, dev)
                 g_fl = torch.full((P, 2, H, W), float("nan"), device=dev) if P else None
                 g_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
                 g_q = [torch.full((H, W, 4), float("nan"), device=dev) for _ in range(2)]
                 got_v = ops.warp_views_and_blend_next(rgba_a, views(), mk(b["mpi"]), mk(b["image"]), dp, P, g_rgba, out_flows_next=g_fl, src_u8_next=g_u8,
                                                       obj_mask_next=mk(b["obj_mask"]), quads_next=g_q[0], quads_complement_next=g_q[1], cum_mask_next=cm)
-                tag = (P, cm is not None, depth)
+                tag = (P, cm is not None, depth, xcd_a)
                 for gv, wv in zip(got_v, want_v):
                     for k in ("rgb", "objmask", "depth", "tgt_mask", "rgb_u8"):
                         if wv.get(k) is not None:
@@ -649,6 +768,7 @@ def test_overlapped_launch_equals_separate_launches(dev, kernel_exp, S, H, W):
                 if P:
                     assert torch.equal(g_fl.view(torch.int32), w_fl.view(torch.int32)), tag
     _lib.check(_lib.load().mpf_tune(b"ovl_depth", 4))
+    _lib.check(_lib.load().mpf_tune(b"ovl_xcd_a", 0))
 
 
 @pytest.mark.parametrize("S,H,W,n", [(8, 32, 48, 5), (20, 23, 37, 3), (16, 64, 96, 1)])

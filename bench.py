@@ -82,6 +82,9 @@ def parse():
     p.add_argument("--no-moving-object", action="store_true",
                    help="c3 without the moving-object chain (depth->flow projection, forward warp, masks): the render-only pair of rounds 1-3")
     p.add_argument("--chain-priority", type=int, default=0, help="tuning: 1 = the chain's side stream gets the highest stream priority")
+    p.add_argument("--chain-cu-stride", type=int, default=0, help="tuning: the chain's side stream may only use every n-th compute unit (0 = all)")
+    p.add_argument("--merge-in-launch", type=int, default=1,
+                   help="1 = Stage D of pair i is a per-pixel prologue of the Stage A+C role of launch i+2 (one launch per pair); 0 = a launch of its own after every pair launch")
     p.add_argument("--chain-ordered", type=int, default=0,
                    help="1 = the chain's results are stream-ordered on the main stream at every pair (event record + wait per pair); 0 = independent side pipeline, joined at the end")
     p.add_argument("--no-generator", action="store_true", help="skip the end-to-end generator record")
@@ -266,18 +269,19 @@ class PipelinedWorkload:
     i+1 in one heterogeneous-grid launch.  finish() flushes the pipeline (the last pair's stand-alone Stage B)."""
     dynamic = True
 
-    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False, chain_priority=False, chain_ordered=False):
+    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False, chain_priority=False, chain_ordered=False, merge_in_launch=True, chain_cu_stride=0):
         self.S, self.H, self.W, self.B, self.N = S, H, W, B, H * W
         K, disp = synth.intrinsics(H, W), synth.plane_disparities(S)
         rng = random.Random(pose_seed)
-        self.r = pipeline.OverlappedPairRenderer(S, H, W, dev)
+        # merge_in_launch: Stage D of pair i rides in launch i+2 (per-pixel prologue of its Stage A+C role): ONE launch per pair, nothing between
+        self.r = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=merge_in_launch)
         # SURVEY 8(d)'s full c3: the moving-object chain of every pair runs on the renderer's SIDE stream, issued right behind the launch whose
         # Stage A+C role wrote the pair's uint8 source frame and handed back with the pair one launch later (OverlappedPairRenderer.attach_chain)
         self.mo, self.mo_disp = make_moving_object_chain(H, W, K, dev, seed0) if moving_object else (None, None)
         if moving_object:
             # the chain as an independent side pipeline (attach_chain(ordered=False)): nothing of it is inserted into the main stream; the
             # inputs are resident since set-up (ready event recorded once), finish() joins the side stream inside the timed region
-            self.r.attach_chain(self.mo, high_priority=chain_priority, ordered=chain_ordered)
+            self.r.attach_chain(self.mo, high_priority=chain_priority, ordered=chain_ordered, cu_stride=chain_cu_stride)
         self.images, self.preps = [], []
         for i in range(B):
             self.images.append(make_image(S, H, W, dev, seed=seed0 + i))
@@ -285,8 +289,10 @@ class PipelinedWorkload:
             G_cam = host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng)  # :208
             self.preps.append(self.r.prepare(K, disp, [G_cam, G_dyn]))
         self.om = torch.from_numpy(synth.soft_box_mask(H, W)).to(dev)
-        self.mix = (torch.empty((H, W, 2), dtype=torch.float32, device=dev), torch.empty((H, W, 3), dtype=torch.uint8, device=dev),
-                    torch.empty((H, W), dtype=torch.uint8, device=dev))
+        # a pair's outputs are written up to two push() calls after it was enqueued: three sets alternate
+        self.mix = [(torch.empty((H, W, 2), dtype=torch.float32, device=dev), torch.empty((H, W, 3), dtype=torch.uint8, device=dev),
+                     torch.empty((H, W), dtype=torch.uint8, device=dev)) for _ in range(3)]
+        self.n_pushed = 0
         self.ev = []
         self.timed = False
         self.inputs_ready = torch.cuda.Event()
@@ -308,7 +314,8 @@ class PipelinedWorkload:
         moving = (self.mo_disp, self.om) if self.mo is not None else None
         for i in idx:
             mpi, img = self.images[i % self.B]
-            self.r.push(mpi, img, self.preps[i % self.B], self.om, out=self.mix, moving=moving, moving_ready=self.inputs_ready if moving else None)
+            self.r.push(mpi, img, self.preps[i % self.B], self.om, out=self.mix[self.n_pushed % 3], moving=moving, moving_ready=self.inputs_ready if moving else None)
+            self.n_pushed += 1
         return len(idx)
 
     def finish(self):
@@ -513,7 +520,7 @@ def main():
         order = list(range(a.pairs_per_step if a.pairs_per_step > 0 else B))
     chain = dynamic and not a.no_moving_object
     if pipelined:
-        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank, moving_object=chain, chain_priority=bool(a.chain_priority), chain_ordered=bool(a.chain_ordered))
+        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank, moving_object=chain, chain_priority=bool(a.chain_priority), chain_ordered=bool(a.chain_ordered), merge_in_launch=bool(a.merge_in_launch), chain_cu_stride=a.chain_cu_stride)
     else:
         wl = Workload(S, H, W, B, dev, dynamic, seed0=rank * 1000, multi_view=not a.single_view_launches, pose_seed=114514 + rank, moving_object=chain)
     torch.cuda.synchronize()
@@ -556,7 +563,9 @@ def main():
         roof["traffic"] = traffic
         if traffic_src:
             roof["traffic_source"] = traffic_src
-        how = ("pipelined: per pair one heterogeneous-grid launch (Stage B of this pair, 2 views + Stage A+C of the next pair) + merge" if pipelined
+        how = (("pipelined: per pair ONE heterogeneous-grid launch (Stage B of this pair, 2 views + Stage A+C of the next pair, which also merges the pair before "
+                "this one as a per-pixel prologue)" if a.merge_in_launch else
+                "pipelined: per pair one heterogeneous-grid launch (Stage B of this pair, 2 views + Stage A+C of the next pair) + merge") if pipelined
                else "one kernel after the other: blend + 2 flows, 2 warped views in one launch, merge")
         mo = (" + the moving-object chain of every pair (depth->flow projection, order-preserving forward warp of the uint8 source frame, masks on "
               "disp = rand(H, W): SURVEY 8(d)'s full c3)" + (" on a side stream underneath the next pair launch" if pipelined else "")) if chain else " (render only, no moving-object chain)"
@@ -567,7 +576,7 @@ def main():
             "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.mode == "batch" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None, "tune": a.tune,
+            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "merge_in_launch": bool(a.merge_in_launch) if pipelined else None, "chain_cu_stride": a.chain_cu_stride, "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None, "tune": a.tune,
                        "pairs_per_step_per_gpu": len(order), "resident_stacks_per_gpu": B, "timed_seconds": dt,
                        "sharding": "independent images per rank (i % world == rank), stats all-reduce only",
                        "device": _lib.device_info(local),

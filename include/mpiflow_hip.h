@@ -50,6 +50,11 @@ int mpf_version(void);
 const char *mpf_last_error(void);
 /* fills CU count, HBM bytes, gfx arch name (e.g. "gfx950"); any pointer may be NULL */
 int mpf_device_info(int device, int *cu_count, size_t *hbm_bytes, char *arch, size_t arch_len);
+/* A stream restricted to every `stride`-th compute unit (starting at `offset`): hipExtStreamCreateWithCUMask.  For latency-sized side work
+ * underneath a chip-filling launch on another stream (pipeline.OverlappedPairRenderer.attach_chain(cu_stride=...)).  The caller owns the
+ * stream (mpf_stream_destroy). */
+int mpf_stream_create_cu_subset(int stride, int offset, void **out_stream);
+int mpf_stream_destroy(void *stream);
 
 /* bench/tuning knobs (never change results): "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2); "stage_b" = Stage B kernel
  * variant; "ovl_depth" = planes of loads a Stage A+C wave keeps in flight inside mpf_warp_views_and_blend_next (4 or 8) */
@@ -143,6 +148,26 @@ int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpView *views,
                                   float flow_clip, float *d_out_rgba_next, float *d_flows_next, uint8_t *d_src_u8_bgr_next,
                                   const float *d_obj_mask_next, float *d_quads_next, float *d_quads_complement_next,
                                   const float *d_cum_mask_next, int S, int H, int W, void *stream);
+
+/* The same launch with Stage D (mpf_merge) of an EARLIER pair folded in: the Stage A+C role runs it as a per-pixel prologue, so a stream
+ * of pairs is ONE launch per pair with nothing between two launches (pipeline.OverlappedPairRenderer(merge_in_launch=True): pair i's
+ * Stage A+C in launch i, its Stage B in launch i+1, its merge in launch i+2).  merge_prev = mpf_merge's arguments (NULL: plain
+ * mpf_warp_views_and_blend_next).  Its d_flow / d_flow_dyn MAY be (parts of) d_flows_next - the thread that merges a pixel is the one that
+ * later writes that pixel's new flows; its frames / masks must not be the views this launch renders. */
+typedef struct MpfMergeArgs {
+    const float *d_frame, *d_frame_dyn;        /* [3,H,W] the two rendered views */
+    const float *d_mask, *d_mask_dyn;          /* [H,W] their rendered object masks */
+    const float *d_flow, *d_flow_dyn;          /* [2,H,W] the two volume-rendered flows */
+    const float *d_obj_mask;                   /* [H,W] source-frame object mask */
+    float thresh;
+    float *d_flow_mix;                         /* [H,W,2] */
+    uint8_t *d_frame_mix, *d_fill_mask;        /* [H,W,3] BGR, [H,W] */
+} MpfMergeArgs;
+int mpf_warp_views_blend_next_merge_prev(const float *d_rgba, const MpfWarpView *views, int n_views,
+                                         const float *d_mpi_next, const float *d_img_next, const float *d_params_next, int P,
+                                         float flow_clip, float *d_out_rgba_next, float *d_flows_next, uint8_t *d_src_u8_bgr_next,
+                                         const float *d_obj_mask_next, float *d_quads_next, float *d_quads_complement_next,
+                                         const float *d_cum_mask_next, int S, int H, int W, const MpfMergeArgs *merge_prev, void *stream);
 
 /* Stage D.  Replaces utils/utils.py:237-283 (uint8 BGR conversion, threshold, layer select, fill mask).
  * frames [3,H,W] RGB float, masks [H,W], flows [2,H,W], obj_mask [H,W] ->

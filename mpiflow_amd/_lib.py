@@ -48,6 +48,12 @@ class MpfMovingObjectOut(ctypes.Structure):
                 ("d_Hm", c_p), ("d_M", c_p), ("d_Md", c_p), ("d_P", c_p), ("d_Hp", c_p)]
 
 
+class MpfMergeArgs(ctypes.Structure):
+    """struct MpfMergeArgs of include/mpiflow_hip.h: mpf_merge's arguments, for the merge folded into a pair launch."""
+    _fields_ = [("d_frame", c_p), ("d_frame_dyn", c_p), ("d_mask", c_p), ("d_mask_dyn", c_p), ("d_flow", c_p), ("d_flow_dyn", c_p),
+                ("d_obj_mask", c_p), ("thresh", c_f), ("d_flow_mix", c_p), ("d_frame_mix", c_p), ("d_fill_mask", c_p)]
+
+
 MAX_VIEWS = 16          # MPF_MAX_VIEWS
 
 # name -> (restype, argtypes); must list every symbol include/mpiflow_hip.h declares (tests/test_capi.py checks)
@@ -55,6 +61,8 @@ SIGNATURES = {
     "mpf_version": (c_i, []),
     "mpf_last_error": (ctypes.c_char_p, []),
     "mpf_device_info": (c_i, [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_sz), ctypes.c_char_p, c_sz]),
+    "mpf_stream_create_cu_subset": (c_i, [c_i, c_i, ctypes.POINTER(c_p)]),
+    "mpf_stream_destroy": (c_i, [c_p]),
     "mpf_src_blend_flow": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpf_build_mask_quads": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "mpf_warp_composite": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
@@ -62,6 +70,8 @@ SIGNATURES = {
     "mpf_src_flow": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "mpf_warp_composite_views": (c_i, [c_p, c_i, ctypes.POINTER(MpfWarpView), c_i, c_i, c_i, c_i, c_p]),
     "mpf_warp_views_and_blend_next": (c_i, [c_p, ctypes.POINTER(MpfWarpView), c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "mpf_warp_views_blend_next_merge_prev": (c_i, [c_p, ctypes.POINTER(MpfWarpView), c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i,
+                                                  ctypes.POINTER(MpfMergeArgs), c_p]),
     "mpf_merge": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),
     "mpf_merge_depth_ordered": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p]),
     "mpf_fill_holes_workspace": (c_sz, [c_i, c_i]),

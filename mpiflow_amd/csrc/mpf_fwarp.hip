@@ -226,28 +226,31 @@ k_fw_keys_hist(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy,
 {
     constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS;
     __shared__ uint32_t hh[RADIX];
+    const uint32_t nb = (N + SORT_TILE - 1) / SORT_TILE;
+    for (uint32_t tile = blockIdx.x; tile < nb; tile += gridDim.x) {      // a workgroup walks several tiles when the grid is capped (mpf_tune("chain_grid"))
 #pragma unroll
-    for (int k = 0; k < DPT; ++k) hh[threadIdx.x + k * SORT_THREADS] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * SORT_TILE;
+        for (int k = 0; k < DPT; ++k) hh[threadIdx.x + k * SORT_THREADS] = 0;
+        __syncthreads();
+        const uint32_t base = tile * SORT_TILE;
 #pragma unroll
-    for (int it = 0; it < SORT_ITEMS; ++it) {
-        const uint32_t n = base + it * SORT_THREADS + threadIdx.x;
-        if (n < N) {
-            int64_t x = idx[n], y = idy[n];
-            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);              // as k_fw_keys: clamp instead of scribbling
-            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-            const uint32_t key = (uint32_t)(y * w + x);
-            keys[n] = key;
-            vals[n] = n;
-            atomicAdd(&hh[(key >> shift) & (RADIX - 1)], 1u);
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t n = base + it * SORT_THREADS + threadIdx.x;
+            if (n < N) {
+                int64_t x = idx[n], y = idy[n];
+                x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);              // as k_fw_keys: clamp instead of scribbling
+                y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+                const uint32_t key = (uint32_t)(y * w + x);
+                keys[n] = key;
+                vals[n] = n;
+                atomicAdd(&hh[(key >> shift) & (RADIX - 1)], 1u);
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < DPT; ++k) {
-        const uint32_t d = threadIdx.x + k * SORT_THREADS;
-        hist[(size_t)blockIdx.x * RADIX + d] = hh[d];
+        for (int k = 0; k < DPT; ++k) {
+            const uint32_t d = threadIdx.x + k * SORT_THREADS;
+            hist[(size_t)tile * RADIX + d] = hh[d];
+        }
     }
 }
 
@@ -261,24 +264,27 @@ k_mo_project_keys_hist(const float *__restrict__ disp, const MpfMoProj m, const 
     constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS;
     __shared__ uint32_t hh[RADIX];
     MPF_FW_SETPRIO(prio);
+    const uint32_t nb = (N + SORT_TILE - 1) / SORT_TILE;
+    for (uint32_t tile = blockIdx.x; tile < nb; tile += gridDim.x) {
 #pragma unroll
-    for (int k = 0; k < DPT; ++k) hh[threadIdx.x + k * SORT_THREADS] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * SORT_TILE;
-    for (int it = 0; it < SORT_ITEMS; ++it) {
-        const uint32_t n = base + it * SORT_THREADS + threadIdx.x;
-        if (n < N) {
-            const uint32_t key = mpf_mo_pixel(disp, m, inst, h, w, (int64_t)n, o);
-            keys[n] = key;
-            vals[n] = n;
-            atomicAdd(&hh[(key >> shift) & (RADIX - 1)], 1u);
+        for (int k = 0; k < DPT; ++k) hh[threadIdx.x + k * SORT_THREADS] = 0;
+        __syncthreads();
+        const uint32_t base = tile * SORT_TILE;
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t n = base + it * SORT_THREADS + threadIdx.x;
+            if (n < N) {
+                const uint32_t key = mpf_mo_pixel(disp, m, inst, h, w, (int64_t)n, o);
+                keys[n] = key;
+                vals[n] = n;
+                atomicAdd(&hh[(key >> shift) & (RADIX - 1)], 1u);
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < DPT; ++k) {
-        const uint32_t d = threadIdx.x + k * SORT_THREADS;
-        hist[(size_t)blockIdx.x * RADIX + d] = hh[d];
+        for (int k = 0; k < DPT; ++k) {
+            const uint32_t d = threadIdx.x + k * SORT_THREADS;
+            hist[(size_t)tile * RADIX + d] = hh[d];
+        }
     }
 }
 
@@ -289,26 +295,28 @@ k_mo_project_keys_hist(const float *__restrict__ disp, const MpfMoProj m, const 
 //                  colprefix in place and writes the digit's total;
 // k_radix_scatter: every workgroup rebuilds base[] from the RADIX totals in LDS (256 .. 2048 numbers) and reads its own row of
 //                  colprefix with coalesced loads.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_radix_colscan(uint32_t *__restrict__ hist, uint32_t nb, uint32_t radix, uint32_t *__restrict__ totals, const int prio = 0)
 {
     MPF_FW_SETPRIO(prio);
-    uint32_t *col = hist + blockIdx.x;
-    const uint32_t lane = threadIdx.x;
-    uint32_t carry = 0;
-    for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
-        const uint32_t i = b0 + lane;
-        const uint32_t v = i < nb ? col[(size_t)i * radix] : 0u;
-        uint32_t inc = v;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    for (uint32_t c = blockIdx.x * wpb + wave; c < radix; c += gridDim.x * wpb) {       // one wave per column
+        uint32_t *col = hist + c;
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            const uint32_t v = i < nb ? col[(size_t)i * radix] : 0u;
+            uint32_t inc = v;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(inc, off);
-            if (lane >= (uint32_t)off) inc += o;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off);
+                if (lane >= (uint32_t)off) inc += o;
+            }
+            if (i < nb) col[(size_t)i * radix] = carry + inc - v;
+            carry += __shfl(inc, 63);
         }
-        if (i < nb) col[(size_t)i * radix] = carry + inc - v;
-        carry += __shfl(inc, 63);
+        if (lane == 0) totals[c] = carry;
     }
-    if (lane == 0) totals[blockIdx.x] = carry;
 }
 
 // Stable scatter of one tile.  Keys are visited in index order: iteration `it` covers 256 consecutive keys, wave k of
@@ -326,6 +334,7 @@ k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict
     __shared__ uint32_t cnt[NW][RADIX];
     __shared__ uint32_t wave_tot[NW];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t dbase[DPT];
     {   // base[d] = exclusive scan of the digit totals; thread t owns the DPT consecutive digits t*DPT ..
         uint32_t v[DPT], sum = 0;
 #pragma unroll
@@ -341,47 +350,50 @@ k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict
         uint32_t base = inc - sum;
         for (uint32_t k = 0; k < wave; ++k) base += wave_tot[k];
 #pragma unroll
+        for (int k = 0; k < DPT; ++k) { dbase[k] = base; base += v[k]; }
+    }
+    for (uint32_t tile = blockIdx.x; tile < nb; tile += gridDim.x) {       // a workgroup walks several tiles when the grid is capped
+#pragma unroll
         for (int k = 0; k < DPT; ++k) {
             const uint32_t d = tid * DPT + k;
-            running[d] = base + offsets[(size_t)blockIdx.x * RADIX + d];
-            base += v[k];
+            running[d] = dbase[k] + offsets[(size_t)tile * RADIX + d];
         }
-    }
-    const uint32_t base = blockIdx.x * SORT_TILE;
-    for (int it = 0; it < SORT_ITEMS; ++it) {
-        const uint32_t i = base + it * SORT_THREADS + tid;
-        const bool valid = i < N;
-        const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
-        const uint32_t val = valid ? vals_in[i] : 0u;
-        const uint32_t digit = (key >> shift) & (RADIX - 1);
+        const uint32_t base = tile * SORT_TILE;
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t i = base + it * SORT_THREADS + tid;
+            const bool valid = i < N;
+            const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
+            const uint32_t val = valid ? vals_in[i] : 0u;
+            const uint32_t digit = (key >> shift) & (RADIX - 1);
 #pragma unroll
-        for (int k = 0; k < RADIX / 64; ++k) cnt[wave][lane + 64 * k] = 0;
-        unsigned long long mask = __ballot(valid);
+            for (int k = 0; k < RADIX / 64; ++k) cnt[wave][lane + 64 * k] = 0;
+            unsigned long long mask = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < BITS; ++b) {
-            const bool bit = (digit >> b) & 1;
-            const unsigned long long bal = __ballot(bit);
-            mask &= bit ? bal : ~bal;
+            for (int b = 0; b < BITS; ++b) {
+                const bool bit = (digit >> b) & 1;
+                const unsigned long long bal = __ballot(bit);
+                mask &= bit ? bal : ~bal;
+            }
+            const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+            if (valid && rank == 0) cnt[wave][digit] = __popcll(mask);
+            __syncthreads();
+            if (valid) {
+                uint32_t pos = running[digit] + rank;
+                for (uint32_t k = 0; k < wave; ++k) pos += cnt[k][digit];
+                keys_out[pos] = key;
+                vals_out[pos] = val;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < DPT; ++k) {
+                const uint32_t d = tid + k * SORT_THREADS;
+                uint32_t add = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) add += cnt[w][d];
+                running[d] += add;
+            }
+            __syncthreads();
         }
-        const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-        if (valid && rank == 0) cnt[wave][digit] = __popcll(mask);
-        __syncthreads();
-        if (valid) {
-            uint32_t pos = running[digit] + rank;
-            for (uint32_t k = 0; k < wave; ++k) pos += cnt[k][digit];
-            keys_out[pos] = key;
-            vals_out[pos] = val;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < DPT; ++k) {
-            const uint32_t d = tid + k * SORT_THREADS;
-            uint32_t add = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) add += cnt[w][d];
-            running[d] += add;
-        }
-        __syncthreads();
     }
 }
 
@@ -390,7 +402,7 @@ static void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
                        uint32_t *hist, uint32_t *totals, hipStream_t st)
 {
     hipLaunchKernelGGL((k_radix_hist<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, N, shift, nb, hist);
-    hipLaunchKernelGGL(k_radix_colscan, dim3(1u << BITS), dim3(64), 0, st, hist, nb, 1u << BITS, totals, g_fw_prio);
+    hipLaunchKernelGGL(k_radix_colscan, dim3((1u << BITS) / 4u), dim3(256), 0, st, hist, nb, 1u << BITS, totals, g_fw_prio);
     hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals, g_fw_prio);
 }
 
@@ -421,7 +433,9 @@ k_fw_bucket(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ v
     __shared__ uint32_t skey[FW_BUCKET_CAP];   // the bucket's visitors sorted by (target, raster index): target, source index, z
     __shared__ uint32_t sval[FW_BUCKET_CAP];
     __shared__ float sz[FW_BUCKET_CAP];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t nbuckets = (uint32_t)(((uint64_t)N + NT - 1) >> LB);
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {              // a workgroup walks several buckets when the grid is capped
     // this bucket's slice [start, start + n) of the sorted-by-high-digit arrays: start = sum of the totals of the buckets below
     uint32_t part = 0;
     for (uint32_t k = tid; k < b; k += SORT_THREADS) part += totals[k];
@@ -547,6 +561,8 @@ k_fw_bucket(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ v
             }
         }
     }
+    __syncthreads();                                                           // the LDS tables are re-used by the next bucket
+    }
 }
 
 // ---- resolve (the general path: images above 2^22 pixels) ------------------------------------------------------------------
@@ -593,6 +609,10 @@ k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
 static int g_fw_path = 0;       // mpf_tune("fwarp_path", 1): force the general multi-pass path (tests; images above 2^22 pixels take it anyway)
 
 void mpf_fwarp_set_path(int v) { g_fw_path = v; }
+static int g_fw_grid = 0;       // mpf_tune("chain_grid", g): cap the workgroup count of every sort / resolve / mask launch at g (0 = one per tile);
+                                // fewer, longer-lived workgroups for runs underneath a chip-filling launch of another stream
+void mpf_fwarp_set_grid(int v) { g_fw_grid = v < 0 ? 0 : v; }
+static inline uint32_t fw_cap(uint32_t n) { return (g_fw_grid > 0 && n > (uint32_t)g_fw_grid) ? (uint32_t)g_fw_grid : n; }
 static int g_fw_stop = 0;       // mpf_tune("chain_stop", n): bench-only ablation, the fast path returns after its first n launches (results invalid)
 void mpf_fwarp_set_stop(int v) { g_fw_stop = v; }
 void mpf_fwarp_set_prio(int v) { g_fw_prio = v < 0 ? 0 : (v > 3 ? 3 : v); }
@@ -642,12 +662,12 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
         const uint32_t nbuckets = (uint32_t)(((uint64_t)N + ((uint64_t)1 << lb) - 1) >> lb);
 #define MPF_FW_PASS1(PBv)                                                                                                          \
         if (g_fw_stop == 1) { \
-          if (proj) hipLaunchKernelGGL((k_mo_project_keys_hist<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out, keys[0], vals[0], N, lb, hist, g_fw_prio); \
+          if (proj) hipLaunchKernelGGL((k_mo_project_keys_hist<PBv>), dim3(fw_cap(nb)), dim3(SORT_THREADS), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out, keys[0], vals[0], N, lb, hist, g_fw_prio); \
           return 0; } \
-        if (proj) hipLaunchKernelGGL((k_mo_project_keys_hist<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out, keys[0], vals[0], N, lb, hist, g_fw_prio); \
-        else hipLaunchKernelGGL((k_fw_keys_hist<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], N, lb, hist);      \
-        hipLaunchKernelGGL(k_radix_colscan, dim3(1u << PBv), dim3(64), 0, st, hist, nb, 1u << PBv, totals, g_fw_prio);                       \
-        hipLaunchKernelGGL((k_radix_scatter<PBv>), dim3(nb), dim3(SORT_THREADS), 0, st, keys[0], vals[0], keys[1], vals[1], N, lb, nb, hist, totals, g_fw_prio)
+        if (proj) hipLaunchKernelGGL((k_mo_project_keys_hist<PBv>), dim3(fw_cap(nb)), dim3(SORT_THREADS), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out, keys[0], vals[0], N, lb, hist, g_fw_prio); \
+        else hipLaunchKernelGGL((k_fw_keys_hist<PBv>), dim3(fw_cap(nb)), dim3(SORT_THREADS), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], N, lb, hist);      \
+        hipLaunchKernelGGL(k_radix_colscan, dim3(fw_cap((1u << PBv) / 4u)), dim3(256), 0, st, hist, nb, 1u << PBv, totals, g_fw_prio);                       \
+        hipLaunchKernelGGL((k_radix_scatter<PBv>), dim3(fw_cap(nb)), dim3(SORT_THREADS), 0, st, keys[0], vals[0], keys[1], vals[1], N, lb, nb, hist, totals, g_fw_prio)
         switch (pb) {
         case 8: MPF_FW_PASS1(8); break;
         case 9: MPF_FW_PASS1(9); break;
@@ -656,7 +676,7 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
         }
 #undef MPF_FW_PASS1
         if (g_fw_stop == 3) return 0;
-#define MPF_FW_BUCKET(LBv) hipLaunchKernelGGL((k_fw_bucket<LBv>), dim3(nbuckets), dim3(SORT_THREADS), 0, st, keys[1], vals[1], keys[0], vals[0], totals, \
+#define MPF_FW_BUCKET(LBv) hipLaunchKernelGGL((k_fw_bucket<LBv>), dim3(fw_cap(nbuckets)), dim3(SORT_THREADS), 0, st, keys[1], vals[1], keys[0], vals[0], totals, \
                                               N, d_z, d_src, d_warped, zero_fill ? 1 : 0, g_fw_prio, src_f)
         switch (lb) {
         case 8: MPF_FW_BUCKET(8); break;
@@ -704,8 +724,7 @@ k_warp_masks(const uint8_t *__restrict__ warped, int H, int W, uint8_t *__restri
 {
     MPF_FW_SETPRIO(prio);
     const int64_t N = (int64_t)H * W;
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
     const int x = (int)(n % W), y = (int)(n / W);
     const uint8_t hv = warped[n * 5 + 3];
     const uint8_t m = (uint8_t)(1 - (warped[n * 5 + 4] == hv));       // M = 1 - (collision == valid)
@@ -723,6 +742,7 @@ k_warp_masks(const uint8_t *__restrict__ warped, int H, int W, uint8_t *__restri
     const uint8_t p = (uint8_t)(md == m);
     P[n] = p;
     Hp[n] = (uint8_t)(hv * p);
+    }
 }
 
 extern "C" int mpf_warp_masks(const uint8_t *d_warped, int H, int W, uint8_t *d_Hm, uint8_t *d_M, uint8_t *d_Md, uint8_t *d_P,
@@ -730,7 +750,7 @@ extern "C" int mpf_warp_masks(const uint8_t *d_warped, int H, int W, uint8_t *d_
 {
     MPF_REQUIRE(d_warped && d_Hm && d_M && d_Md && d_P && d_Hp && H >= 1 && W >= 1, "mpf_warp_masks: bad argument");
     const int64_t N = (int64_t)H * W;
-    hipLaunchKernelGGL(k_warp_masks, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_warped, H, W, d_Hm,
+    hipLaunchKernelGGL(k_warp_masks, dim3(fw_cap((unsigned)((N + 255) / 256))), dim3(256), 0, (hipStream_t)stream, d_warped, H, W, d_Hm,
                        d_M, d_Md, d_P, d_Hp, g_fw_prio);
     return mpf_launch_status("k_warp_masks");
 }

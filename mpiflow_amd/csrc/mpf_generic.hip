@@ -25,6 +25,36 @@ void mpf_set_error(const char *fmt, ...)
 extern "C" const char *mpf_last_error(void) { return g_err; }
 extern "C" int mpf_version(void) { return MPF_VERSION; }
 
+// A HIP stream whose kernels may only be placed on a SUBSET of the compute units (hipExtStreamCreateWithCUMask): every `stride`-th CU of the
+// device.  For latency-sized side work that runs underneath a chip-filling launch on another stream (the moving-object chain beside the pair
+// launch): its workgroups then compete for slots on few CUs instead of taking a slot here and there on all of them.
+extern "C" int mpf_stream_create_cu_subset(int stride, int offset, void **out_stream)
+{
+    MPF_REQUIRE(out_stream && stride >= 1 && offset >= 0 && offset < stride, "mpf_stream_create_cu_subset: bad argument");
+    int dev = 0;
+    MPF_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    MPF_HIP(hipGetDeviceProperties(&p, dev));
+    const int ncu = p.multiProcessorCount;
+    uint32_t mask[32];
+    memset(mask, 0, sizeof(mask));
+    MPF_REQUIRE(ncu <= 1024, "mpf_stream_create_cu_subset: more compute units than the mask holds");
+    int n = 0;
+    for (int c = offset; c < ncu; c += stride) { mask[c >> 5] |= 1u << (c & 31); ++n; }
+    MPF_REQUIRE(n >= 1, "mpf_stream_create_cu_subset: empty CU set");
+    hipStream_t st = nullptr;
+    MPF_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask));
+    *out_stream = (void *)st;
+    return 0;
+}
+
+extern "C" int mpf_stream_destroy(void *stream)
+{
+    MPF_REQUIRE(stream, "mpf_stream_destroy: null stream");
+    MPF_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int mpf_device_info(int device, int *cu_count, size_t *hbm_bytes, char *arch, size_t arch_len)
 {
     hipDeviceProp_t p;

@@ -701,11 +701,17 @@ MPF_DEV float mpf_geom_l(MpfConstParams params, int s, const MpfConsts &c, MpfGe
     return valid;
 }
 
-template <bool HAS_MASK, int NL, bool KS, bool AUX>
+// PLANAR: the stack is channel-planar as the reference holds it ([S,4,H,W], or rgb [S,3,H,W] + sigma [S,1,H,W]: planar_src).  The footprint
+// box is fetched with coalesced DWORD loads from the four channel planes (same box raster, one texel per lane and pass) and interleaved
+// on the way into LDS, so the tap reads are the same four ds_read_b128 - what costs the planar gather kernel 8 + 1 uncoalesced gathers per
+// plane and pixel (TA-bound, 0.32-0.35 of the HBM roofline) becomes <= 12 coalesced 4-byte loads per lane and plane: 248 -> 236 us with a mask,
+// 226 -> 214 without at 64 x 640 x 960 (profiles/r4/stage_b_planar_lds.log).  Tried on top and dropped: the mask's footprint through LDS as
+// well (97 VGPRs + 52 spilled SGPRs, four unaligned ds_read_b32 per pixel: 289 us) and 5 workgroups per CU (223 us without a mask).
+template <bool HAS_MASK, int NL, bool KS, bool AUX, bool PLANAR = false>
 MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
                           int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
                           float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out,
-                          const unsigned tile, float4 *s_tex, uint2 *s_box)
+                          const unsigned tile, float4 *s_tex, uint2 *s_box, const MpfPlanarSrc *planar_src = nullptr)
 {
     constexpr int TW = 32, TH = 8;
     const int64_t N = (int64_t)H * W;
@@ -761,7 +767,8 @@ MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restric
     // a plane whose footprint does not fit the LDS tile (extreme pose), or a denominator near 0 on the tile: the whole
     // workgroup takes the gather path for this tile (uniform; the barrier doubles as the one publishing s_box)
     if (__syncthreads_or(unfit | ((H >= 65536) | (W >= 65536)))) {
-        mpf_wc2_body<HAS_MASK, NL, TW, TH, KS, true, 0, AUX>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile);
+        if (PLANAR) mpf_wc2_body<HAS_MASK, NL, TW, TH, KS, false, 0, AUX, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, planar_src);
+        else mpf_wc2_body<HAS_MASK, NL, TW, TH, KS, true, 0, AUX>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile);
         return;
     }
 
@@ -784,7 +791,28 @@ MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restric
     // one descriptor per plane: [plane base, +(N + W + 1) texels) - row H / column W of the last plane are the tail padding
     const unsigned span = (unsigned)(N + W + 1) * 16u;
     mpf_v4u L[MPF_LT_PASSES];
+    const unsigned chan_bytes = (unsigned)N * 4u;
     auto issue = [&](int s, const MpfBox &b) {
+        if (PLANAR) {
+            // one descriptor per plane and tensor; it ends where the TENSOR ends for the last plane (reads past it return 0, their weight is 0),
+            // earlier planes spill into the next channel / plane, i.e. into valid memory (same argument as mpf_fetch_planar)
+            const bool last = s + 1 == S;
+            __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(planar_src->rgb + (size_t)s * planar_src->rgb_stride), 0,
+                                                                           last ? planar_src->rgb_last : 0xFFFFFFFCu, 0x00020000);
+            __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(planar_src->sigma + (size_t)s * planar_src->sigma_stride), 0,
+                                                                           last ? planar_src->sigma_last : 0xFFFFFFFCu, 0x00020000);
+            const unsigned g4 = b.goff >> 2;                  // (ymin * W + xmin) * 4: byte offset of the box origin inside one channel plane
+#pragma unroll
+            for (int k = 0; k < MPF_LT_PASSES; ++k)
+                if ((unsigned)(TW * TH) * k + 64u * wave < MPF_LT_PITCH * b.h) {
+                    const unsigned v = gconst[k] >> 2;
+                    L[k].x = __builtin_amdgcn_raw_buffer_load_b32(rc, v, g4, 0);
+                    L[k].y = __builtin_amdgcn_raw_buffer_load_b32(rc, v, g4 + chan_bytes, 0);
+                    L[k].z = __builtin_amdgcn_raw_buffer_load_b32(rc, v, g4 + 2u * chan_bytes, 0);
+                    L[k].w = __builtin_amdgcn_raw_buffer_load_b32(rg, v, g4, 0);
+                }
+            return;
+        }
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(pbase + (size_t)s * plane_bytes), 0, span, 0x00020000);
 #pragma unroll
         for (int k = 0; k < MPF_LT_PASSES; ++k)
@@ -879,6 +907,30 @@ k_warp_composite_lds(const float *__restrict__ rgba, const MpfViewSet vs, const 
         mpf_wcl_body<HAS_MASK, NL, false, true>(rgba, w.d_mask_quads, params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask, w.d_rgb_u8_bgr, tile, s_tex, s_box);
 }
 
+template <bool HAS_MASK, int NL>
+__global__ void __launch_bounds__(256, 4)
+k_warp_composite_planar_lds(const MpfPlanarSrc src, const float *__restrict__ quads, const float *__restrict__ params,
+                            int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                            float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
+{
+    constexpr int TW = 32, TH = 8;
+    const unsigned tile = mpf_strip_order(mpf_xcd_remap(blockIdx.x, gridDim.x), (W + TW - 1) / TW, (H + TH - 1) / TH);
+    const MpfConstParams cp = (MpfConstParams)params;
+    const bool pinhole = (cp[1] == 0.0f) & (cp[3] == 0.0f) & (cp[6] == 0.0f) & (cp[7] == 0.0f) & (cp[8] == 1.0f);
+    const bool aux = (depth_out != nullptr) | (tgt_mask_out != nullptr);
+    const float *rgba = reinterpret_cast<const float *>(src.rgb);
+    __shared__ float4 s_tex[2 * MPF_LT_TEXELS];
+    __shared__ uint2 s_box[MPF_LT_MAXS];
+    if (pinhole && !aux)
+        mpf_wcl_body<HAS_MASK, NL, true, false, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, s_tex, s_box, &src);
+    else if (pinhole)
+        mpf_wcl_body<HAS_MASK, NL, true, true, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, s_tex, s_box, &src);
+    else
+        mpf_wcl_body<HAS_MASK, NL, false, true, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, s_tex, s_box, &src);
+}
+
+static int g_planar_lds = 1;        // mpf_tune("planar_lds", 0 | 1): Stage B on the reference's channel-planar tensors through LDS-staged footprints (1) or gathers (0)
+
 static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = gather shapes, 20 = LDS-staged footprints
 
 template <bool HAS_MASK>
@@ -945,6 +997,11 @@ static int launch_planar(const MpfPlanarSrc &src, const float *quads, const floa
                          float *tm, uint8_t *u8, hipStream_t st)
 {
     const unsigned tiles = ((W + 31) / 32) * ((H + 7) / 8);
+    if (g_planar_lds && S <= MPF_LT_MAXS && S < 256) {
+        if (quads) hipLaunchKernelGGL((k_warp_composite_planar_lds<true, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
+        else hipLaunchKernelGGL((k_warp_composite_planar_lds<false, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
+        return mpf_launch_status("k_warp_composite_planar_lds");
+    }
 #define MPF_WCP(HM, NLv) hipLaunchKernelGGL((k_warp_composite_planar<HM, NLv>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8)
     if (S < 256) { if (quads) MPF_WCP(true, 2); else MPF_WCP(false, 2); }
     else         { if (quads) MPF_WCP(true, 3); else MPF_WCP(false, 3); }
@@ -1364,6 +1421,35 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
 #undef MPF_SBF
 }
 
+// Stage D for one pixel (utils/utils.py:237-283): thresholds, layer select, uint8 BGR frame, fill mask, merged flow.  Shared by k_merge and
+// by the pair launch's Stage A+C role, which can run it as a per-pixel prologue for an EARLIER pair (k_pair_overlap, `mg`).
+MPF_DEV void mpf_merge_pixel(const MpfMergeArgs &a, const int64_t n, const int64_t N)
+{
+    const float th = a.thresh;
+    // every input first, unconditionally (all addresses are valid): written as `cond ? a[n] : b[n]` hipcc branches around the loads and
+    // the wave sits out six dependent round trips in a kernel that is nothing but latency
+    const float om = a.d_obj_mask[n], m = a.d_mask[n], md = a.d_mask_dyn[n];
+    const float fx = a.d_flow[n], fy = a.d_flow[N + n], gx = a.d_flow_dyn[n], gy = a.d_flow_dyn[N + n];
+    float fr[3], fd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        fr[c] = a.d_frame[c * N + n];
+        fd[c] = a.d_frame_dyn[c * N + n];
+    }
+    const bool obj = om >= th;                          // source-frame mask   utils/utils.py:270-271, :277-278
+    a.d_flow_mix[2 * n] = obj ? fx : gx;
+    a.d_flow_mix[2 * n + 1] = obj ? fy : gy;
+    const bool sel = m >= th;                           // target-frame masks  :273-276
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                       // BGR order           :240-242
+        const uint8_t x = (m < th) ? (uint8_t)255 : mpf_to_u8(fr[2 - c]);
+        const uint8_t y = (md < th) ? (uint8_t)255 : mpf_to_u8(fd[2 - c]);
+        a.d_frame_mix[3 * n + c] = sel ? x : y;
+    }
+    const float f = sel ? 1.0f : md;                    // :280-283
+    a.d_fill_mask[n] = (f < th) ? 1 : 0;
+}
+
 // Stage A+C as the overlapped launch runs it (k_pair_overlap): the arithmetic of mpf_sbf_body<.., BLEND = true> - same IEEE operation
 // sequence per plane and pixel, bit-identical outputs (tests/test_hip_parity.py) - restated for a role that gets ~1 workgroup per CU
 // inside Stage B's register budget:
@@ -1374,7 +1460,7 @@ extern "C" int mpf_src_blend_flow(const float *d_mpi, const float *d_img, const 
 //     stores the same texels again: no exec-mask branch around the stores either.  Needs 16*S*N < 4 GiB (checked by the launcher).
 //   * DEPTH planes of loads in flight per wave (ring of register sets, loop unrolled DEPTH times)
 template <int PX, int P, int NL, bool ACT, int DEPTH>
-MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const int W, const int64_t t)
+MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const int W, const int64_t t, const MpfMergeArgs &mg)
 {
     const MpfConstParams params = (MpfConstParams)a.params;
     const int64_t N = (int64_t)H * W;
@@ -1418,6 +1504,9 @@ MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const
 #pragma unroll
             for (int c = 0; c < 3; ++c) a.src_u8[3 * n[i] + c] = mpf_to_u8(im[i][2 - c]);          // utils/utils.py:174-177
         }
+        // Stage D of an EARLIER pair, for this pixel.  Its flows may live in the very buffer this thread writes its own flows to at the end
+        // (the renderer's two slots alternate): same thread, same addresses, read before written - no other thread touches them.
+        if (live[i] && mg.d_flow_mix) mpf_merge_pixel(mg, n[i], N);
         if (live[i] && a.obj_mask) {
             const int x = (int)(n[i] % W), y = (int)(n[i] / W);
             const bool e = (x + 1) < W, so = (y + 1) < H;
@@ -1554,7 +1643,8 @@ MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const
 template <bool HAS_MASK, int NL, int P, bool ACT, int DEPTH>
 __global__ void __launch_bounds__(256, 5)
 k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsigned V, const MpfSbfArgs ac, const int S, const int H, const int W,
-               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate, const unsigned view_shift, const unsigned xcd_a)
+               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate, const unsigned view_shift, const unsigned xcd_a,
+               const MpfMergeArgs mg)
 {
     constexpr int TW = 32, TH = 8;
     const unsigned xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;          // the k-th workgroup of this XCD
@@ -1581,7 +1671,7 @@ k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsi
         if (((ablate >> 2) & 3) == 1) __builtin_amdgcn_s_setprio(1);      // bits 2-3: wave priority of the A+C role (tuning experiment)
         else if (((ablate >> 2) & 3) == 2) __builtin_amdgcn_s_setprio(2);
         else if (((ablate >> 2) & 3) == 3) __builtin_amdgcn_s_setprio(3);
-        mpf_sbf_stream<MPF_OVL_PX, P, NL, ACT, DEPTH>(ac, S, H, W, (int64_t)ja * 256 + threadIdx.x);
+        mpf_sbf_stream<MPF_OVL_PX, P, NL, ACT, DEPTH>(ac, S, H, W, (int64_t)ja * 256 + threadIdx.x, mg);
     } else {
         if (jb >= nB || (ablate & 3) == 2) return;
         if (((ablate >> 4) & 3) == 1) __builtin_amdgcn_s_setprio(1);      // bits 4-5: wave priority of the Stage B role
@@ -1601,7 +1691,7 @@ static int g_ovl_ablate = 0;    // mpf_tune("ovl_ablate", 0 | 1 | 2): bench-only
 static int g_ovl_xcd_a = 0;     // mpf_tune("ovl_xcd_a", 0..7): 0 = both roles interleaved on every XCD (Bresenham), n = the first n XCDs run Stage A+C only
 
 template <bool HAS_MASK, int NL, int P, bool ACT>
-static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V, const MpfSbfArgs &ac, int S, int H, int W, hipStream_t st)
+static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V, const MpfSbfArgs &ac, int S, int H, int W, hipStream_t st, const MpfMergeArgs &mg)
 {
     const unsigned tiles = ((W + 31) / 32) * ((H + 7) / 8);
     const unsigned nB = tiles * V;
@@ -1615,9 +1705,9 @@ static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V,
     }
     dim3 grid(8u * per_xcd), block(256);
     if (g_ovl_depth == 4)
-        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa);
+        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa, mg);
     else
-        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 8>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa);
+        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 8>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa, mg);
     return mpf_launch_status("k_pair_overlap");
 }
 
@@ -1627,6 +1717,26 @@ extern "C" int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpV
                                              const float *d_obj_mask_next, float *d_quads_next, float *d_quads_complement_next,
                                              const float *d_cum_mask_next, int S, int H, int W, void *stream)
 {
+    return mpf_warp_views_blend_next_merge_prev(d_rgba, views, n_views, d_mpi_next, d_img_next, d_params_next, P, flow_clip, d_out_rgba_next, d_flows_next,
+                                                d_src_u8_bgr_next, d_obj_mask_next, d_quads_next, d_quads_complement_next, d_cum_mask_next, S, H, W, nullptr, stream);
+}
+
+extern "C" int mpf_warp_views_blend_next_merge_prev(const float *d_rgba, const MpfWarpView *views, int n_views,
+                                                    const float *d_mpi_next, const float *d_img_next, const float *d_params_next, int P,
+                                                    float flow_clip, float *d_out_rgba_next, float *d_flows_next, uint8_t *d_src_u8_bgr_next,
+                                                    const float *d_obj_mask_next, float *d_quads_next, float *d_quads_complement_next,
+                                                    const float *d_cum_mask_next, int S, int H, int W, const MpfMergeArgs *merge_prev, void *stream)
+{
+    MpfMergeArgs mg;
+    memset(&mg, 0, sizeof(mg));
+    if (merge_prev) {
+        mg = *merge_prev;
+        MPF_REQUIRE(mg.d_frame && mg.d_frame_dyn && mg.d_mask && mg.d_mask_dyn && mg.d_flow && mg.d_flow_dyn && mg.d_obj_mask && mg.d_flow_mix && mg.d_frame_mix &&
+                        mg.d_fill_mask, "mpf_warp_views_blend_next_merge_prev: merge_prev has a null pointer");
+        for (int v = 0; v < n_views && views; ++v)
+            MPF_REQUIRE(views[v].d_rgb != mg.d_frame && views[v].d_rgb != mg.d_frame_dyn && views[v].d_objmask != mg.d_mask && views[v].d_objmask != mg.d_mask_dyn,
+                        "mpf_warp_views_blend_next_merge_prev: the merged pair's views must not be the views this launch renders");
+    }
     MPF_REQUIRE(d_rgba && views && d_mpi_next && d_img_next && d_params_next && d_out_rgba_next, "mpf_warp_views_and_blend_next: null pointer");
     MPF_REQUIRE(d_out_rgba_next != d_rgba, "mpf_warp_views_and_blend_next: the stack being rendered and the stack being written must be different buffers");
     MPF_REQUIRE(n_views >= 1 && n_views <= MPF_MAX_VIEWS, "mpf_warp_views_and_blend_next: n_views must be 1..%d (got %d)", MPF_MAX_VIEWS, n_views);
@@ -1655,9 +1765,9 @@ extern "C" int mpf_warp_views_and_blend_next(const float *d_rgba, const MpfWarpV
     hipStream_t st = (hipStream_t)stream;
 #define MPF_OVL(HM, NLv)                                                                                                        \
     switch (P) {                                                                                                                \
-    case 0: return d_cum_mask_next ? launch_overlap<HM, NLv, 0, true>(d_rgba, vs, n_views, ac, S, H, W, st) : launch_overlap<HM, NLv, 0, false>(d_rgba, vs, n_views, ac, S, H, W, st); \
-    case 1: return d_cum_mask_next ? launch_overlap<HM, NLv, 1, true>(d_rgba, vs, n_views, ac, S, H, W, st) : launch_overlap<HM, NLv, 1, false>(d_rgba, vs, n_views, ac, S, H, W, st); \
-    default: return d_cum_mask_next ? launch_overlap<HM, NLv, 2, true>(d_rgba, vs, n_views, ac, S, H, W, st) : launch_overlap<HM, NLv, 2, false>(d_rgba, vs, n_views, ac, S, H, W, st); \
+    case 0: return d_cum_mask_next ? launch_overlap<HM, NLv, 0, true>(d_rgba, vs, n_views, ac, S, H, W, st, mg) : launch_overlap<HM, NLv, 0, false>(d_rgba, vs, n_views, ac, S, H, W, st, mg); \
+    case 1: return d_cum_mask_next ? launch_overlap<HM, NLv, 1, true>(d_rgba, vs, n_views, ac, S, H, W, st, mg) : launch_overlap<HM, NLv, 1, false>(d_rgba, vs, n_views, ac, S, H, W, st, mg); \
+    default: return d_cum_mask_next ? launch_overlap<HM, NLv, 2, true>(d_rgba, vs, n_views, ac, S, H, W, st, mg) : launch_overlap<HM, NLv, 2, false>(d_rgba, vs, n_views, ac, S, H, W, st, mg); \
     }
     if (S < 256) { if (has_mask) { MPF_OVL(true, 2) } else { MPF_OVL(false, 2) } }
     else         { if (has_mask) { MPF_OVL(true, 3) } else { MPF_OVL(false, 3) } }
@@ -1679,15 +1789,18 @@ extern "C" int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int
 void mpf_fwarp_set_path(int v);      // mpf_fwarp.hip
 void mpf_fwarp_set_prio(int v);
 void mpf_fwarp_set_stop(int v);
+void mpf_fwarp_set_grid(int v);
 
 extern "C" int mpf_tune(const char *key, int value)
 {
     if (key && !strcmp(key, "sbf_px")) { g_sbf_px = value; return 0; }
     if (key && !strcmp(key, "stage_b")) { g_stage_b_variant = value; return 0; }
+    if (key && !strcmp(key, "planar_lds")) { g_planar_lds = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "ovl_depth")) { g_ovl_depth = (value == 8) ? 8 : 4; return 0; }
     if (key && !strcmp(key, "ovl_ablate")) { g_ovl_ablate = value; return 0; }
     if (key && !strcmp(key, "view_shift")) { g_view_shift = value < 0 ? 0 : value; return 0; }
     if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
+    if (key && !strcmp(key, "chain_grid")) { mpf_fwarp_set_grid(value); return 0; }
     if (key && !strcmp(key, "chain_stop")) { mpf_fwarp_set_stop(value); return 0; }
     if (key && !strcmp(key, "chain_prio")) { mpf_fwarp_set_prio(value); return 0; }
     if (key && !strcmp(key, "ovl_xcd_a")) { g_ovl_xcd_a = (value < 0 || value > 7) ? 0 : value; return 0; }
@@ -1700,35 +1813,11 @@ extern "C" int mpf_tune(const char *key, int value)
 // ---------------------------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256)
-k_merge(const float *__restrict__ frame, const float *__restrict__ frame_dyn, const float *__restrict__ mask,
-        const float *__restrict__ mask_dyn, const float *__restrict__ flow, const float *__restrict__ flow_dyn,
-        const float *__restrict__ obj_mask, float th, int64_t N, float *__restrict__ flow_mix,
-        uint8_t *__restrict__ frame_mix, uint8_t *__restrict__ fill_mask)
+k_merge(const MpfMergeArgs m, int64_t N)
 {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    // every input first, unconditionally (all addresses are valid): written as `cond ? a[n] : b[n]` hipcc branches around the loads and
-    // the wave sits out six dependent round trips in a kernel that is nothing but latency
-    const float om = obj_mask[n], m = mask[n], md = mask_dyn[n];
-    const float fx = flow[n], fy = flow[N + n], gx = flow_dyn[n], gy = flow_dyn[N + n];
-    float fr[3], fd[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        fr[c] = frame[c * N + n];
-        fd[c] = frame_dyn[c * N + n];
-    }
-    const bool obj = om >= th;                          // source-frame mask   utils/utils.py:270-271, :277-278
-    flow_mix[2 * n] = obj ? fx : gx;
-    flow_mix[2 * n + 1] = obj ? fy : gy;
-    const bool sel = m >= th;                           // target-frame masks  :273-276
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {                       // BGR order           :240-242
-        const uint8_t a = (m < th) ? (uint8_t)255 : mpf_to_u8(fr[2 - c]);
-        const uint8_t b = (md < th) ? (uint8_t)255 : mpf_to_u8(fd[2 - c]);
-        frame_mix[3 * n + c] = sel ? a : b;
-    }
-    const float f = sel ? 1.0f : md;                    // :280-283
-    fill_mask[n] = (f < th) ? 1 : 0;
+    mpf_merge_pixel(m, n, N);
 }
 
 extern "C" int mpf_merge(const float *d_frame, const float *d_frame_dyn, const float *d_mask, const float *d_mask_dyn,
@@ -1738,8 +1827,8 @@ extern "C" int mpf_merge(const float *d_frame, const float *d_frame_dyn, const f
     MPF_REQUIRE(d_frame && d_frame_dyn && d_mask && d_mask_dyn && d_flow && d_flow_dyn && d_obj_mask && d_flow_mix &&
                     d_frame_mix && d_fill_mask && H >= 1 && W >= 1, "mpf_merge: bad argument");
     const int64_t N = (int64_t)H * W;
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_frame, d_frame_dyn,
-                       d_mask, d_mask_dyn, d_flow, d_flow_dyn, d_obj_mask, thresh, N, d_flow_mix, d_frame_mix, d_fill_mask);
+    const MpfMergeArgs m = { d_frame, d_frame_dyn, d_mask, d_mask_dyn, d_flow, d_flow_dyn, d_obj_mask, thresh, d_flow_mix, d_frame_mix, d_fill_mask };
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m, N);
     return mpf_launch_status("k_merge");
 }
 

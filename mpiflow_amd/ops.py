@@ -234,11 +234,13 @@ def _view_array(views, device):
 
 @_on_device
 def warp_views_and_blend_next(rgba, views, mpi_next, img_next, dparams_next, P, out_rgba_next, out_flows_next=None, flow_clip=200.0,
-                              src_u8_next=None, obj_mask_next=None, quads_next=None, quads_complement_next=None, cum_mask_next=None):
+                              src_u8_next=None, obj_mask_next=None, quads_next=None, quads_complement_next=None, cum_mask_next=None,
+                              merge_prev=None):
     """Stage B of one image (all `views` of the tail-padded stack `rgba`, as warp_composite_views) and Stage A+C of the NEXT image
     (as src_blend_flow with preallocated outputs) in ONE launch whose grid interleaves the two kinds of workgroups
     (mpf_warp_views_and_blend_next).  Bit-identical to the two separate calls; every *_next buffer must be distinct from what the
-    views read or write."""
+    views read or write.  merge_prev: merge_args(...) of an EARLIER pair, merged by the Stage A+C role as a per-pixel prologue
+    (mpf_warp_views_blend_next_merge_prev); its flows may be `out_flows_next` itself."""
     lib = _lib.load()
     a = _dev(rgba, "rgba")
     S, H, W, C = a.shape
@@ -251,10 +253,22 @@ def warp_views_and_blend_next(rgba, views, mpi_next, img_next, dparams_next, P, 
     arr = _view_array(views, a.device)
     om = _dev(obj_mask_next, "obj_mask_next").reshape(H, W) if obj_mask_next is not None else None
     cm = _dev(cum_mask_next, "cum_mask_next") if cum_mask_next is not None else None
-    _lib.check(lib.mpf_warp_views_and_blend_next(_ptr(a), arr, len(views), _ptr(mpi), _ptr(img), _ptr(dparams_next), int(P), float(flow_clip),
-                                                 _ptr(out_rgba_next), _ptr(out_flows_next), _ptr(src_u8_next), _ptr(om), _ptr(quads_next),
-                                                 _ptr(quads_complement_next), _ptr(cm), S, H, W, _stream()), "mpf_warp_views_and_blend_next")
+    _lib.check(lib.mpf_warp_views_blend_next_merge_prev(_ptr(a), arr, len(views), _ptr(mpi), _ptr(img), _ptr(dparams_next), int(P), float(flow_clip),
+                                                        _ptr(out_rgba_next), _ptr(out_flows_next), _ptr(src_u8_next), _ptr(om), _ptr(quads_next),
+                                                        _ptr(quads_complement_next), _ptr(cm), S, H, W,
+                                                        ctypes.byref(merge_prev) if merge_prev is not None else None, _stream()),
+               "mpf_warp_views_blend_next_merge_prev")
     return [v["out"] for v in views]
+
+
+def merge_args(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh, out):
+    """mpf_merge's arguments as the struct a pair launch takes (warp_views_and_blend_next(merge_prev=...)).  All tensors fp32 contiguous on the
+    device, out = (flow_mix [H,W,2] f32, frame_mix [H,W,3] u8, fill_mask [H,W] u8); the caller keeps them alive until the launch was issued."""
+    import numpy as np
+    for t in (frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask):
+        assert t.is_cuda and t.dtype == _f32 and t.is_contiguous()
+    return _lib.MpfMergeArgs(frame.data_ptr(), frame_dyn.data_ptr(), mask.data_ptr(), mask_dyn.data_ptr(), flow.data_ptr(), flow_dyn.data_ptr(),
+                             obj_mask.data_ptr(), float(np.float32(thresh)), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
 
 
 @_on_device

@@ -206,10 +206,18 @@ class OverlappedPairRenderer(_PairHostSide):
     projection, forward warp of the pair's uint8 source frame, masks; moving_obj.py:29-150) runs on a SIDE stream.  The chain of pair i
     needs nothing but the source frame Stage A+C of pair i wrote, so it is issued right behind the launch that carried that role and runs
     underneath the NEXT launch (Stage B of pair i); the main stream waits for it only when pair i is handed back, a whole pair launch
-    later - no wait ever sits between two pair launches."""
+    later - no wait ever sits between two pair launches.
 
-    def __init__(self, S, H, W, device, thresh=MASK_THRESH):
+    merge_in_launch=True: Stage D of a pair rides in a LATER pair launch instead of being a launch of its own between two of them (it is
+    8 us of kernel plus two launch boundaries on the critical path): the Stage A+C role of launch i+2 merges pair i as a per-pixel prologue
+    (mpf_warp_views_blend_next_merge_prev) - the thread that merges a pixel is the one that later overwrites that pixel's flows in the
+    slot the two pairs share, so no further buffering is needed.  The stream is then ONE launch per pair and nothing else; push() hands back
+    the pair enqueued TWO calls earlier, `obj_mask` / `out` of a pair must stay untouched for two further push() calls (three alternating
+    buffers), and flush() returns a list (the last two pairs)."""
+
+    def __init__(self, S, H, W, device, thresh=MASK_THRESH, merge_in_launch=False):
         self.S, self.H, self.W, self.device, self.thresh = S, H, W, torch.device(device), thresh
+        self.merge_in_launch, self._merging, self.chain_ordered = merge_in_launch, None, True
         f32, dev = torch.float32, self.device
         self.slots = [dict(rgba=ops.alloc_rgba_stack(S, H, W, dev), flows=torch.empty((2, 2, H, W), dtype=f32, device=dev),
                            quads=[torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)],
@@ -223,7 +231,7 @@ class OverlappedPairRenderer(_PairHostSide):
         # the overlapped launch addresses the stack through 32-bit buffer offsets: stacks of 4 GiB and more take the two separate launches
         self.fusable = S * H * W * 16 < (1 << 32)
 
-    def attach_chain(self, chain, high_priority=False, ordered=True):
+    def attach_chain(self, chain, high_priority=False, ordered=True, cu_stride=0):
         """chain: moving_obj.MovingObjectChain with (at least) two output sets.
         ordered=True: the chain splats the uint8 source frame the pair's Stage A+C role wrote and its results are stream-ordered on the
           MAIN stream when the pair is handed back - costs the main stream an event record and an event wait per pair (measured: 12 us per
@@ -237,7 +245,18 @@ class OverlappedPairRenderer(_PairHostSide):
         high_priority: the side stream gets the device's highest stream priority (no measurable effect at 64 x 640 x 960)."""
         assert len(chain.bufs) >= 2 and (chain.H, chain.W) == (self.H, self.W)
         self.chain, self.chain_ordered, self._chain_next = chain, ordered, 0
-        self.side = torch.cuda.Stream(self.device, priority=-1 if high_priority else 0)
+        if cu_stride and cu_stride > 1:
+            # the side stream may only use every cu_stride-th compute unit: the chain's latency-sized workgroups then sit on few CUs instead of
+            # taking a slot here and there on all of them, underneath a launch that fills the whole chip
+            import ctypes
+            from . import _lib
+            h = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().mpf_stream_create_cu_subset(int(cu_stride), 0, ctypes.byref(h)), "mpf_stream_create_cu_subset")
+            self._side_handle = h                                     # owned for the renderer's lifetime
+            self.side = torch.cuda.ExternalStream(h.value, device=self.device)
+        else:
+            self.side = torch.cuda.Stream(self.device, priority=-1 if high_priority else 0)
         for k, s in enumerate(self.slots):
             s["index"], s["ev_src"], s["ev_chain"], s["moving"] = k, torch.cuda.Event(), torch.cuda.Event(), None
 
@@ -245,26 +264,25 @@ class OverlappedPairRenderer(_PairHostSide):
         return [dict(dparams=prep["warp"][v], quads=slot["quads"][v], out=slot["views"][v]) for v in range(2)]
 
     def _start_chain(self, slot, moving):
-        """ordered chain, right behind the launch whose Stage A+C role wrote slot['src_u8']: the pair's moving-object chain, on the side stream."""
-        if self.chain is None or not self.chain_ordered:
-            return
-        slot["moving"] = None
-        if moving is None:
-            return
+        """ordered chain, right behind the launch whose Stage A+C role wrote slot['src_u8']: the pair's moving-object chain, on the side
+        stream.  -> the output set, or None"""
+        if self.chain is None or not self.chain_ordered or moving is None:
+            return None
         slot["ev_src"].record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(slot["ev_src"])
             if os.environ.get("MPF_CHAIN_DEBUG") == "events_only":      # measurement hook (tools/): the event choreography without the chain's kernels
-                slot["moving"] = self.chain.bufs[slot["index"]]
+                b = self.chain.bufs[slot["index"]]
             else:
-                slot["moving"] = self.chain.run(moving[0], moving[1], slot["src_u8"], which=slot["index"])
+                b = self.chain.run(moving[0], moving[1], slot["src_u8"], which=slot["index"])
             slot["ev_chain"].record()
+        slot["chain_busy"] = True
+        return b
 
-    def _start_chain_unordered(self, slot, image, moving, moving_ready):
-        """independent chain, at the top of push(): reads nothing the render path writes."""
-        slot["moving"] = None
-        if moving is None:
-            return
+    def _start_chain_unordered(self, image, moving, moving_ready):
+        """independent chain, at the top of push(): reads nothing the render path writes.  -> the output set, or None"""
+        if self.chain is None or self.chain_ordered or moving is None:
+            return None
         which, self._chain_next = self._chain_next, (self._chain_next + 1) % len(self.chain.bufs)
         b = self.chain.bufs[which]
         if moving_ready is None:
@@ -277,64 +295,102 @@ class OverlappedPairRenderer(_PairHostSide):
             self.chain.run(moving[0], moving[1], image, which=which)
             b.ready = torch.cuda.Event()
             b.ready.record()
-        slot["moving"] = b
+        return b
+
+    def _wait_chain_of(self, slot):
+        """main stream: the ordered chain that reads this slot's source frame has finished (issued at least a whole pair launch ago)."""
+        if slot.get("chain_busy"):
+            torch.cuda.current_stream().wait_event(slot["ev_chain"])
+            slot["chain_busy"] = False
+
+    def _out_of(self, pend):
+        if pend["out"] is None:
+            f32, dev, H, W = torch.float32, self.device, self.H, self.W
+            pend["out"] = (torch.empty((H, W, 2), dtype=f32, device=dev), torch.empty((H, W, 3), dtype=torch.uint8, device=dev),
+                           torch.empty((H, W), dtype=torch.uint8, device=dev))
+        return pend["out"]
+
+    def _merge_operands(self, pend):
+        slot = pend["slot"]
+        v = slot["views"]
+        return (v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], slot["flows"][0], slot["flows"][1], pend["om"])
+
+    def _handed_back(self, pend):
+        done = tuple(pend["out"])
+        if pend["moving"] is not None:
+            if self.chain_ordered:
+                self._wait_chain_of(pend["slot"])
+            done = done + (pend["moving"],)
+        return done
 
     def _finish(self, pend):
-        slot, om, out = pend["slot"], pend["om"], pend["out"]
-        v = slot["views"]
-        done = ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], slot["flows"][0], slot["flows"][1], om, self.thresh, out=out)
-        if slot.get("moving") is not None:
-            if self.chain_ordered:
-                torch.cuda.current_stream().wait_event(slot["ev_chain"])      # issued a whole pair launch ago: normally long since complete
-            done = tuple(done) + (slot["moving"],)
-        return done
+        """Stage D as a launch of its own, then the pair is handed back."""
+        ops.merge(*self._merge_operands(pend), self.thresh, out=self._out_of(pend))
+        return self._handed_back(pend)
+
+    def _blend_alone(self, slot, mpi, image, prep, obj_mask, cum_mask):
+        ops.src_blend_flow(mpi, image, out_rgba=slot["rgba"], out_flows=slot["flows"], dparams=prep["blend"], P=2, src_u8=slot["src_u8"],
+                           obj_mask=obj_mask, quads=slot["quads"][0], quads_complement=slot["quads"][1], cum_mask=cum_mask)
 
     def push(self, mpi, image, prep, obj_mask, out=None, cum_mask=None, moving=None, moving_ready=None):
         """Enqueue one pair (prep from prepare(K, disparity, [G_cam, G_dyn]); view 0 samples obj_mask, view 1 its complement).
         moving = (disp [H,W], instance mask [H,W]) with a chain attached: the pair's moving-object chain runs on the side stream.
-        Returns the (flow_mix, frame_mix, fill_mask[, ops.MovingObjectBuffers]) of the PREVIOUS pair, or None if there was none."""
+        Returns the (flow_mix, frame_mix, fill_mask[, ops.MovingObjectBuffers]) of the pair this call completed - the PREVIOUS one, or with
+        merge_in_launch the one before that - or None if there was none."""
         assert prep["P"] == 2
         slot = self.slots[self._next]
         self._next ^= 1
         done = None
-        if self.chain is not None and not self.chain_ordered:
-            self._start_chain_unordered(slot, image, moving, moving_ready)
-        if self._pending is None:
-            ops.src_blend_flow(mpi, image, out_rgba=slot["rgba"], out_flows=slot["flows"], dparams=prep["blend"], P=2, src_u8=slot["src_u8"],
-                               obj_mask=obj_mask, quads=slot["quads"][0], quads_complement=slot["quads"][1], cum_mask=cum_mask)
-            self._start_chain(slot, moving)
+        obj_mask = obj_mask.reshape(self.H, self.W)
+        if obj_mask.dtype != torch.float32 or not obj_mask.is_contiguous():
+            obj_mask = obj_mask.to(torch.float32).contiguous()
+        new = dict(slot=slot, prep=prep, om=obj_mask, out=out, moving=self._start_chain_unordered(image, moving, moving_ready))
+        self._wait_chain_of(slot)                                    # this slot's source frame is about to be rewritten
+        pend = self._pending
+        if pend is None:
+            self._blend_alone(slot, mpi, image, prep, obj_mask, cum_mask)
         elif not self.fusable:
-            pend = self._pending
             ops.warp_composite_views(pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), interleaved=2)
-            ops.src_blend_flow(mpi, image, out_rgba=slot["rgba"], out_flows=slot["flows"], dparams=prep["blend"], P=2, src_u8=slot["src_u8"],
-                               obj_mask=obj_mask, quads=slot["quads"][0], quads_complement=slot["quads"][1], cum_mask=cum_mask)
-            self._start_chain(slot, moving)
-            done = self._finish(pend)
+            self._blend_alone(slot, mpi, image, prep, obj_mask, cum_mask)
         else:
-            pend = self._pending
+            mg, self._merging = self._merging, None
+            mp = ops.merge_args(*self._merge_operands(mg), self.thresh, self._out_of(mg)) if mg is not None else None
             launch = lambda: ops.warp_views_and_blend_next(                                                   # noqa: E731
                 pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), mpi, image, prep["blend"], 2, slot["rgba"],
                 out_flows_next=slot["flows"], src_u8_next=slot["src_u8"], obj_mask_next=obj_mask, quads_next=slot["quads"][0],
-                quads_complement_next=slot["quads"][1], cum_mask_next=cum_mask)
+                quads_complement_next=slot["quads"][1], cum_mask_next=cum_mask, merge_prev=mp)
             if self.on_fused is not None:
                 self.on_fused(launch)
             else:
                 launch()
-            self._start_chain(slot, moving)
-            done = self._finish(pend)
-        self._pending = dict(slot=slot, prep=prep, om=obj_mask, out=out)
+            if mg is not None:
+                done = self._handed_back(mg)
+        if new["moving"] is None:
+            new["moving"] = self._start_chain(slot, moving)
+        if pend is not None:
+            if self.merge_in_launch and self.fusable:
+                self._merging = pend                                 # its Stage B is in flight; its merge rides in the next launch
+            else:
+                done = self._finish(pend)
+        self._pending = new
         return done
 
     def flush(self):
-        """Complete the last enqueued pair with a stand-alone Stage B launch; returns its (flow_mix, frame_mix, fill_mask) or None."""
-        if self._pending is None:
-            return None
-        pend, self._pending = self._pending, None
-        ops.warp_composite_views(pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), interleaved=2)
-        done = self._finish(pend)
+        """Complete what is in flight: the last pair's stand-alone Stage B launch and the outstanding merges.  Returns the last pair's
+        (flow_mix, frame_mix, fill_mask[, chain buffers]) or None; with merge_in_launch a LIST of the (up to two) pairs completed here, oldest first."""
+        pend, mg = self._pending, self._merging
+        self._pending = self._merging = None
+        res = []
+        if pend is not None:
+            ops.warp_composite_views(pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), interleaved=2)
+        for p in (mg, pend):
+            if p is not None:
+                res.append(self._finish(p))
         if self.chain is not None and not self.chain_ordered:
             torch.cuda.current_stream().wait_stream(self.side)                # the independent chain joins the main stream here
-        return done
+        if self.merge_in_launch:
+            return res
+        return res[-1] if res else None
 
     @property
     def pending_slot(self):

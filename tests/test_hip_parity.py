@@ -429,6 +429,21 @@ def test_one_call_moving_object_chain_vs_reference_golden(dev, oracle, name):
     b3 = chain.run(T(disp, dev), T(inst, dev), T(rgb.astype(np.uint8), dev))
     assert b3 is b
     _check_chain_against_golden(g, b3, oracle)
+    # capped grids (mpf_tune("chain_grid")): every sort / resolve / mask workgroup walks several tiles - same bytes; and the frame given as
+    # float [3,H,W] (its uint8 BGR form is what gets splatted)
+    from mpiflow_amd import _lib
+    img = T(np.ascontiguousarray(rgb[..., ::-1].transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0), dev)
+    try:
+        for grid in (7, 64):
+            _lib.check(_lib.load().mpf_tune(b"chain_grid", grid))
+            for src in (T(rgb.astype(np.uint8), dev), img):
+                for t in (b.warped, b.safe_x, b.z1, b.masks["H'"]):
+                    t.fill_(1)
+                _check_chain_against_golden(g, chain.run(T(disp, dev), T(inst, dev), src, which=0), oracle)
+            sx, sy, z1 = b.safe_x.clone(), b.safe_y.clone(), b.z1.clone()
+            assert torch.equal(ops.forward_warp(T(rgb.astype(np.uint8), dev), sx, sy, z1, H, W), b.warped)
+    finally:
+        _lib.check(_lib.load().mpf_tune(b"chain_grid", 0))
 
 
 def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
@@ -456,12 +471,12 @@ def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
     d_disp, d_inst = T(disp, dev), T(inst, dev)
     poses = [(host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng), host_math.generate_random_pose(0.15, rng=rng)) for _ in range(5)]
 
-    def stream(with_chain, high_priority=False, ordered=True):
-        ovl = pipeline.OverlappedPairRenderer(S, H, W, dev)
+    def stream(with_chain, high_priority=False, ordered=True, merge_in_launch=False):
+        ovl = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=merge_in_launch)
         if with_chain:
             ovl.attach_chain(moving_obj.MovingObjectChain(H, W, g["K"], g["inv_K"], dev, T_obj=torch.from_numpy(g["T_obj"])[None], n_buffers=2 if ordered else 3),
                              high_priority=high_priority, ordered=ordered)
-        outs = [tuple(torch.empty(s, dtype=dt, device=dev) for s, dt in (((H, W, 2), torch.float32), ((H, W, 3), torch.uint8), ((H, W), torch.uint8))) for _ in range(2)]
+        outs = [tuple(torch.empty(s, dtype=dt, device=dev) for s, dt in (((H, W, 2), torch.float32), ((H, W, 3), torch.uint8), ((H, W), torch.uint8))) for _ in range(3)]
         res = []
 
         def take(done):
@@ -474,13 +489,15 @@ def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
                 _check_chain_against_golden(g, done[3], oracle)          # synchronises (reads back): the NEXT push then overwrites nothing in use
             res.append([N(t).copy() for t in done[:3]])
         for k, (Gc, Gd) in enumerate(poses):
-            take(ovl.push(stacks[k % 2], img, ovl.prepare(K, pd, [Gc, Gd]), om, out=outs[k % 2], moving=(d_disp, d_inst) if with_chain else None))
-        take(ovl.flush())
+            take(ovl.push(stacks[k % 2], img, ovl.prepare(K, pd, [Gc, Gd]), om, out=outs[k % 3], moving=(d_disp, d_inst) if with_chain else None))
+        last = ovl.flush()
+        for d in (last if merge_in_launch else [last]):
+            take(d)
         assert len(res) == len(poses)
         return res
     plain = stream(False)
-    for hp, ordered in ((False, True), (True, True), (False, False)):
-        got = stream(True, high_priority=hp, ordered=ordered)
+    for hp, ordered, mil in ((False, True, False), (True, True, False), (False, False, False), (False, False, True), (False, True, True)):
+        got = stream(True, high_priority=hp, ordered=ordered, merge_in_launch=mil)
         for k, (a, b) in enumerate(zip(plain, got)):
             for x, y in zip(a, b):
                 assert bits_equal(x, y) == 0, "pair %d: render output changed with the chain attached" % k
@@ -805,6 +822,25 @@ def test_overlapped_pair_renderer_equals_render_pair(dev, kernel_exp, S, H, W, n
     outs2.append(sep.flush())
     for a, b in zip(outs, outs2):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # merge_in_launch: Stage D of pair i rides in launch i+2 (the Stage A+C role's per-pixel prologue) - push() hands back the pair enqueued
+    # two calls earlier, flush() the last two; same bytes.  Without `out` the renderer allocates the outputs itself.
+    for with_out in (True, False):
+        mil = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=True)
+        outs3, given = [], []
+        for i, (inp, G_cam, G_dyn) in enumerate(items):
+            out = tuple(torch.full_like(t, 3) for t in outs[0]) if with_out else None
+            given.append(out)
+            done = mil.push(T(inp["mpi"], dev), T(inp["image"], dev), mil.prepare(inp["K"], inp["disparity"], [G_cam, G_dyn]), T(inp["obj_mask"], dev), out=out)
+            assert (done is None) == (i < 2)
+            if done is not None:
+                assert not with_out or done[0] is given[i - 2][0]
+                outs3.append(done)
+        rest = mil.flush()
+        assert isinstance(rest, list) and len(rest) == min(n, 2) and mil.flush() == []
+        outs3 += rest
+        assert len(outs3) == n
+        for a, b in zip(outs, outs3):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
     for (inp, G_cam, G_dyn), out in zip(items, outs):
         ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
         for k, t in zip(("flow_mix", "frame_mix", "fill_mask"), out):
@@ -832,14 +868,20 @@ def test_planar_and_split_stage_b_equal_the_interleaved_kernel(dev, kernel_exp, 
         m = (1.0 - inp["obj_mask"]) if comp else inp["obj_mask"]
         want = o.warp_composite(N(inter), m, Hst, k_inv, G, d)
         q = ops.mask_quads(T(inp["obj_mask"], dev), complement=comp)
-        for quads in (q, None):
-            a = ops.warp_composite(stack, quads, Hst, k_inv, G, d, interleaved=False)
-            b = ops.warp_composite_split(rgb3, sig1, quads, Hst, k_inv, G, d)
-            for got in (a, b):
-                for k in ("rgb", "depth", "tgt_mask") + (("objmask",) if quads is not None else ()):
-                    assert bits_equal(N(got[k]), want[k]) == 0, (k, comp, quads is not None)
-        lean = ops.warp_composite_split(rgb3, sig1, q, Hst, k_inv, G, d, want_depth=False, want_tgt_mask=False)
-        assert bits_equal(N(lean["rgb"]), want["rgb"]) == 0 and bits_equal(N(lean["objmask"]), want["objmask"]) == 0
+        from mpiflow_amd import _lib
+        try:
+            for planar_lds in (1, 0):          # LDS-staged footprints (coalesced dword loads, the default) / 8-byte tap-pair gathers
+                _lib.check(_lib.load().mpf_tune(b"planar_lds", planar_lds))
+                for quads in (q, None):
+                    a = ops.warp_composite(stack, quads, Hst, k_inv, G, d, interleaved=False)
+                    b = ops.warp_composite_split(rgb3, sig1, quads, Hst, k_inv, G, d)
+                    for got in (a, b):
+                        for k in ("rgb", "depth", "tgt_mask") + (("objmask",) if quads is not None else ()):
+                            assert bits_equal(N(got[k]), want[k]) == 0, (k, comp, quads is not None, planar_lds)
+                lean = ops.warp_composite_split(rgb3, sig1, q, Hst, k_inv, G, d, want_depth=False, want_tgt_mask=False)
+                assert bits_equal(N(lean["rgb"]), want["rgb"]) == 0 and bits_equal(N(lean["objmask"]), want["objmask"]) == 0
+        finally:
+            _lib.check(_lib.load().mpf_tune(b"planar_lds", 1))
     ref = o.src_blend_flow(inp["mpi"], inp["image"], k_inv, d, np.stack([Hts_c, Hts_d]))
     assert bits_equal(N(ops.src_flow(sig1, k_inv, d, np.stack([Hts_c, Hts_d]))), ref["flows"]) == 0
     assert bits_equal(N(ops.src_flow(sig1.reshape(S, H, W), k_inv, d, Hts_d[None]))[0], ref["flows"][1]) == 0

@@ -28,9 +28,12 @@ p.add_argument("--aux", type=int, default=1, help="0 = no depth / tgt_mask outpu
 p.add_argument("--layout", type=int, default=1, help="1 = interleaved, 2 = interleaved + tail padding, 0 = the reference's channel-planar [S,4,H,W] "
                "(variant 0 = round-1 planar kernel, any other variant = k_warp_composite_planar), 3 = separate rgb [S,3,H,W] / sigma [S,1,H,W] "
                "tensors as render_novel_view_dynamic receives them (mpf_warp_composite_split; variant 0 = torch.cat + round-1 planar kernel)")
+p.add_argument("--planar-lds", type=int, default=-1, help="layouts 0 / 3: 1 = LDS-staged footprints (k_warp_composite_planar_lds), 0 = gathers (k_warp_composite_planar), -1 = library default")
 a = p.parse_args()
 
 lib = _lib.load()
+if a.planar_lds >= 0:
+    _lib.check(lib.mpf_tune(b"planar_lds", a.planar_lds))
 dev = torch.device("cuda:0")
 S, H, W = a.planes, a.height, a.width
 g = torch.Generator(device=dev).manual_seed(0)

@@ -17,6 +17,27 @@ from .homography_sampler import HomographySample
 from .rendering_utils import transform_G_xyz  # noqa: F401  (re-exported like the reference module does)
 
 
+# ---- provenance tags: which tensors are "the standard ones" ---------------------------------------------------------------------------
+# render_tgt_rgb_depth receives xyz_src / xyz_tgt as materialised tensors.  When they are what get_src_xyz_from_plane_disparity /
+# get_tgt_xyz_from_plane_disparity of THIS module returned for the same (K_src_inv, disparities, G_tgt_src) - the reference's only call site
+# builds them exactly so (utils/utils.py:303-310) - the fused kernels, which evaluate those affine fields in registers, apply.  The tag is a
+# Python attribute on the returned tensor: (what, bytes of the small host matrices it was built from, tensor version at tagging time).  A
+# tensor that was modified in place, sliced, copied or built any other way carries no valid tag and takes the generic kernels.
+
+def _key(*small):
+    return tuple(host_math._cpu32(t).contiguous().numpy().tobytes() for t in small)
+
+
+def _tag(t, what, key):
+    t._mpf_std = (what, key, t._version)
+    return t
+
+
+def _tagged(t, what):
+    tag = getattr(t, "_mpf_std", None)
+    return tag[1] if tag is not None and tag[0] == what and tag[2] == t._version else None
+
+
 def _flat(t):                      # [B,S,C,H,W] -> per-batch [S,C,H*W] views
     B, S, C, H, W = t.shape
     return t.reshape(B, S, C, H * W)
@@ -125,21 +146,79 @@ def get_src_xyz_from_plane_disparity(meshgrid_src_homo, mpi_disparity_src, K_src
     H, W = meshgrid_src_homo.size(1), meshgrid_src_homo.size(2)
     dev = mpi_disparity_src.device if mpi_disparity_src.is_cuda else meshgrid_src_homo.device
     out = [ops.src_xyz(K_src_inv[b], host_math.plane_depths(mpi_disparity_src[b]), H, W, dev) for b in range(B)]
-    return torch.stack(out)
+    return _tag(torch.stack(out), "src", _key(K_src_inv, mpi_disparity_src))
 
 
 def get_tgt_xyz_from_plane_disparity(xyz_src_BS3HW, G_tgt_src):
     """xyz_tgt = G . [xyz_src; 1]   (reference :242-256) -> BxSx3xHxW"""
     B, S, _, H, W = xyz_src_BS3HW.size()
     out = [ops.transform_xyz(G_tgt_src[b], xyz_src_BS3HW[b].reshape(S, 3, H * W)).reshape(S, 3, H, W) for b in range(B)]
-    return torch.stack(out)
+    res, src_key = torch.stack(out), _tagged(xyz_src_BS3HW, "src")
+    return _tag(res, "tgt", src_key + _key(G_tgt_src)) if src_key is not None else res
+
+
+def _same_mask_on_every_plane(obj_mask_BS1HW):
+    """The reference hands over S copies of ONE mask (utils/utils.py:323: obj_mask.unsqueeze(1).repeat(B, S, 1, 1, 1)); the fused kernel takes
+    the mask once.  An expanded view is recognised by its stride, a materialised repeat by comparing the planes (one pass over the tensor)."""
+    if obj_mask_BS1HW.size(1) == 1 or obj_mask_BS1HW.stride(1) == 0:
+        return True
+    return bool((obj_mask_BS1HW[:, 1:] == obj_mask_BS1HW[:, :1]).all())
+
+
+def fused_render_applies(mpi_disparity_src, xyz_tgt_BS3HW, xyz_src_BS3HW, G_tgt_src, K_src_inv, K_tgt, use_alpha=False, is_bg_depth_inf=False,
+                         hard_flow=False, obj_mask=None):
+    """True when render_tgt_rgb_depth may dispatch to the fused kernels: default options, xyz tensors that carry this module's tag for exactly
+    these (K_src_inv, disparities, G_tgt_src), and one mask on every plane.  (K_tgt is free: it only enters the homographies.)"""
+    if use_alpha or is_bg_depth_inf or hard_flow:
+        return False
+    src_key, tgt_key = _tagged(xyz_src_BS3HW, "src"), _tagged(xyz_tgt_BS3HW, "tgt")
+    if src_key is None or tgt_key is None:
+        return False
+    want_src = _key(K_src_inv, mpi_disparity_src)
+    if src_key != want_src or tgt_key != want_src + _key(G_tgt_src):
+        return False
+    return obj_mask is None or _same_mask_on_every_plane(obj_mask)
+
+
+def _render_tgt_fused(mpi_rgb_src, mpi_sigma_src, mpi_disparity_src, G_tgt_src, K_src_inv, K_tgt, obj_mask):
+    """The fused form of render_tgt_rgb_depth: Stage B on the two channel-planar tensors in place (mpf_warp_composite_split: homography warp,
+    analytic xyz_tgt, front-to-back composite, depth, validity count, rendered mask) + the source-frame flow of the sigma tensor
+    (mpf_src_flow) - two launches per batch item instead of the reference-shaped chain (8-channel concatenation, generic sampling of every
+    channel, S-deep intermediates)."""
+    B, S, _, H, W = mpi_rgb_src.size()
+    dev = mpi_rgb_src.device
+    rgbs, depths, tms, flows, oms = [], [], [], [], []
+    for b in range(B):
+        d = host_math.plane_depths(mpi_disparity_src[b])
+        H_ts, H_st = host_math.homographies(G_tgt_src[b], K_src_inv[b], K_tgt[b], d)
+        quads = ops.mask_quads(obj_mask[b, 0, 0].to(dev, torch.float32).contiguous(), False) if obj_mask is not None else None
+        v = ops.warp_composite_split(mpi_rgb_src[b].to(torch.float32), mpi_sigma_src[b].to(torch.float32), quads, H_st, K_src_inv[b], G_tgt_src[b], d)
+        rgbs.append(v["rgb"]); depths.append(v["depth"].reshape(1, H, W)); tms.append(v["tgt_mask"].reshape(1, H, W))
+        flows.append(ops.src_flow(mpi_sigma_src[b].to(torch.float32), K_src_inv[b], d, H_ts.unsqueeze(0), flow_clip=0.0)[0])
+        if obj_mask is not None:
+            oms.append(v["objmask"].reshape(1, H, W))
+    return torch.stack(rgbs), torch.stack(depths), torch.stack(tms), torch.stack(flows), (torch.stack(oms) if oms else None)
 
 
 def render_tgt_rgb_depth(H_sampler: HomographySample, mpi_rgb_src, mpi_sigma_src, mpi_disparity_src, xyz_tgt_BS3HW,
                          xyz_src_BS3HW, G_tgt_src, K_src_inv, K_tgt, mpi_flow_src=None, use_alpha=False,
-                         is_bg_depth_inf=False, hard_flow=False, obj_mask=None):
+                         is_bg_depth_inf=False, hard_flow=False, obj_mask=None, fused=None):
     """reference :259-349 -> (tgt_rgb_syn Bx3xHxW, tgt_depth_syn Bx1xHxW, tgt_mask Bx1xHxW, flowA2B Bx2xHxW,
-    tgt_obj_mask_sync Bx1xHxW).  `mpi_flow_src` is accepted and ignored exactly as in the reference (:267)."""
+    tgt_obj_mask_sync Bx1xHxW).  `mpi_flow_src` is accepted and ignored exactly as in the reference (:267).
+
+    fused (not a reference argument): None = dispatch to the fused kernels when fused_render_applies(...) - the standard call of
+    utils/utils.py:291-349 -, else the generic kernels that work on the materialised tensors; False = always generic; True = fused, raising
+    if it does not apply.  The two forms differ by fp32 rounding only (the generic one interpolates the xyz_tgt channels bilinearly, the fused
+    one evaluates the same affine field at the interpolated coordinate): both sit inside the parity bars against the reference's outputs
+    (tests/test_dropin_api.py), tgt_mask is identical."""
+    if fused is None or fused:
+        ok = fused_render_applies(mpi_disparity_src, xyz_tgt_BS3HW, xyz_src_BS3HW, G_tgt_src, K_src_inv, K_tgt, use_alpha, is_bg_depth_inf,
+                                  hard_flow, obj_mask)
+        if fused and not ok:
+            raise ValueError("render_tgt_rgb_depth(fused=True): the fused kernels need default options, one mask on every plane and xyz tensors built by "
+                             "this module's get_src_xyz_from_plane_disparity / get_tgt_xyz_from_plane_disparity for the same K, disparities and pose")
+        if ok:
+            return _render_tgt_fused(mpi_rgb_src, mpi_sigma_src, mpi_disparity_src, G_tgt_src, K_src_inv, K_tgt, obj_mask)
     B, S, _, H, W = mpi_rgb_src.size()
     mpi_depth_src = torch.reciprocal(mpi_disparity_src.detach().to("cpu", torch.float32))          # :284
     mpi_xyz_src = torch.cat((mpi_rgb_src.to(torch.float32), mpi_sigma_src.to(torch.float32), xyz_tgt_BS3HW.to(torch.float32)), dim=2)

@@ -95,6 +95,41 @@ def test_render_and_render_tgt_rgb_depth(dev, name):
     assert max_abs(N(r_depth[0, 0]), g["rtd_depth"]) < 2e-5 * max(1.0, float(np.abs(g["rtd_depth"]).max()))
     with pytest.raises(UnboundLocalError):        # what the reference's own use_alpha branch does (mpi_rendering.py:33-39)
         mpi_rendering.render(rgb, sig, xyz_src, use_alpha=True)
+    # xyz tensors loaded from a file carry no provenance tag: that call took the GENERIC kernels
+    assert not mpi_rendering.fused_render_applies(T(g["disparity"], dev)[None], xyz_tgt, xyz_src, T(g["G_cam"], dev)[None], T(g["k_inv"], dev)[None],
+                                                  T(g["K"], dev)[None], obj_mask=om_in)
+    with pytest.raises(ValueError):
+        mpi_rendering.render_tgt_rgb_depth(hs, rgb_b, sig, T(g["disparity"], dev)[None], xyz_tgt, xyz_src, T(g["G_cam"], dev)[None],
+                                           T(g["k_inv"], dev)[None], T(g["K"], dev)[None], None, obj_mask=om_in, fused=True)
+    # the reference's own call sequence (utils/utils.py:303-349): xyz tensors from this module's two functions -> the FUSED kernels
+    # (mpf_warp_composite_split + mpf_src_flow).  Same bars against the reference's outputs; tgt_mask identical; against the generic form the
+    # difference is fp32 rounding of the xyz channels (interpolated there, evaluated at the interpolated coordinate here)
+    disp, G, Ki, K = T(g["disparity"], dev)[None], T(g["G_cam"], dev)[None], T(g["k_inv"], dev)[None], T(g["K"], dev)[None]
+    xs = mpi_rendering.get_src_xyz_from_plane_disparity(hs.meshgrid, disp, Ki)
+    xt = mpi_rendering.get_tgt_xyz_from_plane_disparity(xs.to(K.dtype), G.to(K.dtype))
+    assert bits_equal(N(xs[0]), g["xyz_src"]) == 0 and bits_equal(N(xt[0]), g["xyz_tgt_cam"]) == 0
+    assert mpi_rendering.fused_render_applies(disp, xt, xs, G, Ki, K, obj_mask=om_in)
+    f_rgb, f_depth, f_tmask, f_flow, f_om = mpi_rendering.render_tgt_rgb_depth(hs, rgb_b, sig, disp, xt, xs, G, Ki, K, None, obj_mask=om_in)
+    assert tuple(f_rgb.shape) == (1, 3, H, W) and tuple(f_depth.shape) == (1, 1, H, W) and tuple(f_tmask.shape) == (1, 1, H, W)
+    assert tuple(f_flow.shape) == (1, 2, H, W) and tuple(f_om.shape) == (1, 1, H, W)
+    assert max_abs(N(f_rgb[0]), g["rtd_rgb"]) < 2e-6 and max_abs(N(f_om[0, 0]), g["rtd_objmask"]) < 2e-6
+    assert bits_equal(N(f_tmask[0, 0]), g["rtd_tgt_mask"]) == 0 and torch.equal(f_tmask, r_tmask)
+    assert max_abs(N(f_flow[0]), g["rtd_flow_unclipped"]) < 5e-5
+    assert max_abs(N(f_depth[0, 0]), g["rtd_depth"]) < 2e-5 * max(1.0, float(np.abs(g["rtd_depth"]).max()))
+    assert max_abs(N(f_rgb), N(r_rgb)) < 1e-6 and max_abs(N(f_flow), N(r_flow)) < 1e-5
+    gen = mpi_rendering.render_tgt_rgb_depth(hs, rgb_b, sig, disp, xt, xs, G, Ki, K, None, obj_mask=om_in, fused=False)
+    assert all(torch.equal(a, b) for a, b in zip(gen, out))                      # fused=False: the generic kernels, whatever the tags say
+    # what must NOT dispatch: another pose than the one the tensor was built for, a tensor modified in place, per-plane masks, non-default options
+    assert not mpi_rendering.fused_render_applies(disp, xt, xs, T(g["G_dyn"], dev)[None], Ki, K)
+    assert not mpi_rendering.fused_render_applies(disp, xt, xs, G, Ki, K, hard_flow=True)
+    om_diff = om_in.clone()
+    om_diff[0, 1] += 0.5
+    assert not mpi_rendering.fused_render_applies(disp, xt, xs, G, Ki, K, obj_mask=om_diff)
+    assert mpi_rendering.fused_render_applies(disp, xt, xs, G, Ki, K, obj_mask=T(g["obj_mask"], dev)[None, None, None].expand(1, S, 1, H, W))
+    xt.mul_(1.0)
+    assert not mpi_rendering.fused_render_applies(disp, xt, xs, G, Ki, K)
+    no_mask = mpi_rendering.render_tgt_rgb_depth(hs, rgb_b, sig, disp, mpi_rendering.get_tgt_xyz_from_plane_disparity(xs, G), xs, G, Ki, K)
+    assert no_mask[4] is None and max_abs(N(no_mask[0][0]), g["rtd_rgb"]) < 2e-6
 
 
 @pytest.mark.parametrize("name", ["tiny_white", "odd_s20", "s1"])

@@ -497,6 +497,43 @@ def generator_record(n_images=64, repeat=5, timeout=600):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+MFMA_F16_PEAK = 2.5e15   # dense fp16 MFMA, flop/s (MI355X_MICROARCH.md; AMD's headline figure includes 2:1 sparsity and is not used)
+
+
+def n1_record(dev, S=64, H=384, W=1280, iters=10):
+    """SURVEY 8(f) N1 - the AdaMPI producer on the HIP engine (mpiflow_amd.model.engine.HipPredictor, random weights of the reference's
+    architecture, the generator's 64 x 384 x 1280): one image = 20 mpf_conv3x3_f16 launches + mpf_plane_masks (+ the batch-1 torch encoder on a
+    side stream), replayed from one hipGraph.  Algorithmic flops = the reference's own convolutions on the real channel counts; algorithmic
+    bytes = every layer's sources read once and its output written once in the engine's storage types (HipPredictor.accounting).  Both
+    roofline fractions are of the whole forward: it is bound by neither alone."""
+    from mpiflow_amd.model import MPIPredictor
+    from mpiflow_amd.model.engine import HipPredictor
+    m = MPIPredictor(W, H, S).randomize_(0).eval().to(dev)
+    hp = HipPredictor(m, encoder_dtype=None, graph=True)
+    g = torch.Generator(device=dev).manual_seed(5)
+    img, dsp = torch.rand((1, 3, H, W), generator=g, device=dev), torch.rand((1, 1, H, W), generator=g, device=dev)
+    for _ in range(2):
+        hp(img, dsp)                                                            # capture (every layer records the shapes of its launch) + one replay
+    torch.cuda.synchronize()
+    rows, tot = hp.accounting()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        hp(img, dsp)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    rec = {"workload": "AdaMPI producer (N1) on the HIP engine: %d planes x %d x %d, fp16 storage / fp32 accumulate, one hipGraph replay per image" % (S, H, W),
+           "ms_per_image": t * 1e3, "images_per_s": 1.0 / t, "launches": len(rows),
+           "algorithmic_flops_per_image": tot["flops"], "algorithmic_bytes_per_image": tot["bytes"],
+           "hbm": {"bound": "hbm", "achieved": tot["bytes"] / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": tot["bytes"] / t / HBM_PEAK},
+           "mfma": {"bound": "mfma", "achieved": tot["flops"] / t / 1e12, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": tot["flops"] / t / MFMA_F16_PEAK},
+           "layers": [{"name": r["name"], "GB": r["bytes"] / 1e9, "GFLOP": r["flops"] / 1e9} for r in rows]}
+    del hp, m
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     a = parse()
     rank, world, local, backend, rank_devices = init_dist(a)
@@ -618,6 +655,10 @@ def main():
         if world == 1 and not a.no_sub:
             out["hbm_reference"] = hbm_reference(dev)
         if world == 1 and not a.no_sub and not a.no_generator and a.mode == "resident":
+            try:
+                out["roofline_n1"] = n1_record(dev)
+            except Exception as e:                                   # noqa: BLE001
+                out["roofline_n1"] = {"error": repr(e)}
             try:
                 out["generator"] = generator_record()
             except Exception as e:                                   # noqa: BLE001 - a side record must never cost the headline line

@@ -95,6 +95,8 @@ class ConvLayer:
         self.loader, self.epi, self.stride, self.pad_mode, self.ct = loader, epi, stride, pad_mode, ct
         self.nchunk = vmap.numel() // ct
         self.nblk, self.ncg, self.Cst, self.CA, self.CB = nblk, ncg, Cst, CA, CB
+        self.vmap_real = vmap
+        self.rows_real = int((rows_w.reshape(rows_w.shape[0], -1).abs().sum(1) > 0).sum())     # output rows that are not padding
         self.wpack = pack_weights(rows_w, vmap, ct).to(device)
         self.ep = ep.float().contiguous().to(device)
         assert self.ep.shape == (3, nblk * 16)
@@ -181,6 +183,7 @@ class ConvLayer:
         a.ct, a.nchunk, a.nblk, a.ncg, a.Cst = self.ct, self.nchunk, self.nblk, self.ncg, self.Cst
         a.loader, a.epi, a.stride, a.pad_mode = self.loader, self.epi, self.stride, self.pad_mode
         a.wlds = int(_wlds(self.name, self.wlds_default))
+        self.last_call = dict(S=S, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, HA=a.HA, WA=a.WA)
         if self.loader == LD_BILINEAR_CAT:
             a.fparams[0] = (a.HA - 1) / (Hin - 1) if Hin > 1 else 0.0
             a.fparams[1] = (a.WA - 1) / (Win - 1) if Win > 1 else 0.0
@@ -188,6 +191,33 @@ class ConvLayer:
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(_lib.load().mpf_conv3x3_f16(ctypes.byref(a), stream), "mpf_conv3x3_f16")
         return out
+
+
+def layer_accounting(layer):
+    """Algorithmic work of ONE launch of `layer` (shapes of its last call): flops of the convolution on the REAL channels (the reference's
+    own count: 2 * S * Hout * Wout * Cout * Cin * 9, gated layers have two such convolutions), and the bytes that have to cross HBM once -
+    every source tensor read once (fp16 activations; the shared skip features and fp32 masks of the per-plane loader once per image, not per
+    plane), the output written once, the packed weights once."""
+    c = layer.last_call
+    S, Hin, Win, Hout, Wout = c["S"], c["Hin"], c["Win"], c["Hout"], c["Wout"]
+    cin_real = int((layer.vmap_real >= 0).sum())
+    rows_real = layer.rows_real
+    flops = 2.0 * S * Hout * Wout * rows_real * cin_real * 9
+    if layer.loader == LD_FMN_INPUT:
+        rd = Hin * Win * (3 + 1) * 4                                    # image + disparity, fp32, shared by the S planes
+    elif layer.loader == LD_DIRECT:
+        rd = S * Hin * Win * layer.CA * 2
+    elif layer.loader == LD_BILINEAR_CAT:
+        rd = S * c["HA"] * c["WA"] * layer.CA * 2 + S * Hin * Win * layer.CB * 2
+    else:                                                               # nearest-upsampled planes + shared skip features + the two fp32 masks
+        rd = S * c["HA"] * c["WA"] * layer.CA * 2 + (Hin * Win * (layer.CB - 8) * 2 + 2 * S * Hin * Win * 4 if layer.CB else 0)
+    if layer.epi == EP_AFFINE_RELU_F32:
+        wr = S * Hout * Wout * 4
+    elif layer.epi == EP_GATED_PLANAR_F32:
+        wr = S * layer.Cst * Hout * Wout * 4
+    else:
+        wr = S * Hout * Wout * layer.Cst * 2
+    return dict(name=layer.name, flops=flops, bytes=float(rd + wr + layer.wpack.numel() * 2), read_bytes=float(rd), write_bytes=float(wr))
 
 
 def _nhwc16(t_1CHW):
@@ -369,6 +399,25 @@ class HipPredictor:
             t.record_stream(main)
         raw, cum = self.dec(feats, masks, shared=shared)
         return raw, cum, disp
+
+    def layers(self):
+        f, d = self.fmn, self.dec
+        out = [f.l1, f.l2, f.l3, f.l4, f.l5, f.l6, f.l7, f.l8, f.l9, d.up0[4]]
+        for i in range(4, -1, -1):
+            if i < 4:
+                out.append(d.up0[i])
+            out.append(d.up1[i])
+        return out + [d.disp0]
+
+    def accounting(self):
+        """Per-layer and total algorithmic flops / HBM bytes of the 20 convolution launches of the last forward (layer_accounting), plus
+        the plane-mask pass (logits read twice, cumulative mask + pyramid written)."""
+        rows = [layer_accounting(L) for L in self.layers() if getattr(L, "last_call", None)]
+        c = self.fmn.l9.last_call
+        n = c["S"] * c["Hout"] * c["Wout"] * 4
+        rows.append(dict(name="plane_masks", flops=0.0, bytes=float(2 * n + n + 2 * n * (1 / 4 + 1 / 16 + 1 / 64 + 1 / 256 + 1 / 1024)), read_bytes=float(2 * n),
+                         write_bytes=float(n + 2 * n * (1 / 4 + 1 / 16 + 1 / 64 + 1 / 256 + 1 / 1024))))
+        return rows, dict(flops=sum(r["flops"] for r in rows), bytes=sum(r["bytes"] for r in rows))
 
     @torch.no_grad()
     def __call__(self, src_imgs, src_depths):

@@ -216,13 +216,21 @@ def test_plane_masks_match_torch():
         assert float((got["fm"][i] - F.adaptive_avg_pool2d(fm[None], (H // k, W // k))[0]).abs().max()) < 4e-6
 
 
+# Absolute bars of the engine's error against the fp32 model, per case: (mean, 99.9th percentile) of |sigmoid(rgb)| and |sigma| differences.
+# Set at ~2x what tools/engine_error.py measures on MI355X (profiles/r4/engine_error.txt: case 1 rgb 2.8e-3 / 6.9e-2, sigma 1.1e-3 / 5.4e-2;
+# case 2 rgb 9.4e-4 / 1.9e-2, sigma 6.6e-4 / 2.4e-2; torch's own fp16 autocast sits at 4-6x those).  Random weights amplify rounding through
+# 25 layers - with a trained checkpoint (none available offline) the same arithmetic would sit far below these - so the bars are what a
+# regression of the engine's arithmetic (a lost fp32 accumulation, a wrong epilogue row) cannot pass, not a statement about image quality.
+ENGINE_BARS = {(8, 128, 256, 5): dict(rgb=(6e-3, 0.14), sigma=(2.5e-3, 0.11)),
+               (3, 256, 128, 6): dict(rgb=(2e-3, 4e-2), sigma=(1.5e-3, 5e-2))}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("S,H,W,seed", [(8, 128, 256, 5), (3, 256, 128, 6)])
 def test_predictor_engine_matches_fp32_model(S, H, W, seed):
-    """Whole producer on the engine vs the fp32 torch model (same random parameters).  A randomly initialised 25-layer
-    network amplifies rounding, so the yardstick is the precision the reference itself runs at on a GPU - torch fp16
-    (`.half()`, gen_3dphoto_dynamic_v2.py:46,59,82-84): the engine (fp16 storage, fp32 accumulate and epilogue) must be at
-    least as close to fp32 as torch's fp16 autocast is, in the mean and at the 99.9th percentile, on rgb and sigma."""
+    """Whole producer on the engine vs the fp32 torch model (same random parameters): ABSOLUTE bars on the mean and the 99.9th percentile of
+    the error of sigmoid(rgb) and sigma (ENGINE_BARS), and - the relative yardstick - at least as close to fp32 as the precision the
+    reference itself runs at on a GPU, torch fp16 (`.half()`, gen_3dphoto_dynamic_v2.py:46,59,82-84)."""
     from mpiflow_amd.model.engine import HipPredictor
     dev = _gpu()
     m = _model(S, H, W, seed=seed)
@@ -245,10 +253,11 @@ def test_predictor_engine_matches_fp32_model(S, H, W, seed):
         d = (x - ref).abs().flatten()
         return float(d.mean()), float(d.kthvalue(int(d.numel() * 0.999)).values)
 
-    for got, half, ref in zip(act(raw, cum), act(h_raw[0], h_cum[0]), act(ref_raw[0], ref_cum[0])):
+    bars = ENGINE_BARS[(S, H, W, seed)]
+    for name, got, half, ref in zip(("rgb", "sigma"), act(raw, cum), act(h_raw[0], h_cum[0]), act(ref_raw[0], ref_cum[0])):
         (e_mean, e_tail), (h_mean, h_tail) = err(got, ref), err(half, ref)
+        assert e_mean <= bars[name][0] and e_tail <= bars[name][1], (name, e_mean, e_tail, bars[name])
         assert e_mean <= h_mean and e_tail <= h_tail, (e_mean, h_mean, e_tail, h_tail)
-        assert e_mean < 5e-3
 
 
 @pytest.mark.gpu
@@ -261,8 +270,14 @@ def test_engine_at_the_generator_size():
     m = _model(S, H, W, seed=1)
     g = torch.Generator().manual_seed(3)
     img, dsp = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 1, H, W, generator=g).to(dev)
-    raw, cum, disp = HipPredictor(m, encoder_dtype=None)(img, dsp)       # fp32 encoder: the comparison isolates the engine's own rounding
+    hp = HipPredictor(m, encoder_dtype=None)                              # fp32 encoder: the comparison isolates the engine's own rounding
+    raw, cum, disp = hp(img, dsp)
     assert tuple(raw.shape) == (S, 4, H, W) and bool(torch.isfinite(raw).all())
+    # the work bench.py's roofline_n1 is quoted on: 20 convolution launches + the plane masks; ~4.1 TFLOP (the reference's convolutions on the
+    # real channel counts) and ~12 GB (every layer's sources read once, its output written once) per image at this size
+    rows, tot = hp.accounting()
+    assert len(rows) == 21 and [r["name"] for r in rows][:3] == ["l1", "l2", "l3"] and rows[-1]["name"] == "plane_masks"
+    assert 3.5e12 < tot["flops"] < 4.6e12 and 9e9 < tot["bytes"] < 15e9, tot
     assert float((cum[-1] - 1).abs().max()) < 1e-5 and float(cum.min()) >= 0 and bool((cum[1:] >= cum[:-1] - 1e-6).all())
     with torch.no_grad():
         ref = m(img, dsp, raw=True)[0][0]
@@ -270,7 +285,9 @@ def test_engine_at_the_generator_size():
             half = m(img, dsp, raw=True)[0][0].float()
     e_engine = float((torch.sigmoid(raw[:, :3]) - torch.sigmoid(ref[:, :3])).abs().mean())
     e_half = float((torch.sigmoid(half[:, :3]) - torch.sigmoid(ref[:, :3])).abs().mean())
-    assert e_engine <= e_half and e_engine < 2e-2, (e_engine, e_half)          # random 25-layer network: both ~1e-2 at 64 planes
+    # absolute bar at ~2x the measured 3.2e-3 (profiles/r4/engine_error.txt; torch fp16 autocast: 1.2e-2), and the relative yardstick
+    assert e_engine <= e_half and e_engine < 6.5e-3, (e_engine, e_half)
+
 
 
 @pytest.mark.gpu

@@ -107,17 +107,15 @@ def self_launch(a):
     torch.distributed.run (the form the driver uses itself), LOCAL_RANK = device index, rendezvous on 127.0.0.1 - and pass their
     output and exit status through.  The reference's model is the same: one process per GPU (scripts/gen_train_kitti15_v2.sh:1-4,
     gen_3dphoto_dynamic_v2.py:78).  Fails loudly when the box has fewer devices than ranks asked for."""
-    import socket
     import subprocess
     forced = "MPIFLOW_FORCE_DEVICE" in os.environ            # test hook: all ranks on one device over gloo
     have = torch.cuda.device_count()
     if have < a.gpus and not forced:
         raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible on this box" % (a.gpus, have))
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d store picks a free port and keeps it (no bind-then-close race with other jobs of the box);
+    # --local-addr: the container's host name may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MPIFLOW_SELF_LAUNCHED="1")
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
@@ -593,6 +591,32 @@ def main():
     else:
         total_pairs = my_pairs
 
+    # BASELINE configs[3] beside the weak-scaling `value`, on every run: a FIXED batch of --batch images (512) sharded i % world over the ranks,
+    # each rank renders its share (cycling through its resident stacks); pairs/s = batch / slowest rank, per-rank seconds reported
+    batch_rec = None
+    if a.mode == "resident" and a.batch > 0 and dynamic:
+        mine_b = pipeline.shard_indices(a.batch, rank, world)
+        order_b = list(range(len(mine_b)))
+        wl.step(False, order_b[:8])
+        wl.finish()
+        torch.cuda.synchronize()
+        barrier()
+        tb0 = time.perf_counter()
+        nb = wl.step(False, order_b)
+        wl.finish()
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb0
+        per_rank = [(tb, nb)]
+        if world > 1:
+            import torch.distributed as dist
+            box = [None] * world
+            dist.all_gather_object(box, (tb, nb), group=pipeline.host_side_group())
+            per_rank = box
+        batch_rec = {"workload": "BASELINE configs[3]: a fixed batch of %d images (64 planes, 640x960, full dynamic pipeline) sharded i %% world over %d rank(s), "
+                                 "one pass; strong scaling" % (a.batch, world),
+                     "batch_images": a.batch, "pairs_per_s": sum(n for _, n in per_rank) / max(t for t, _ in per_rank), "scaling": "strong",
+                     "per_rank_seconds": [t for t, _ in per_rank], "per_rank_pairs": [n for _, n in per_rank]}
+
     if rank == 0:
         roofs = wl.rooflines()
         traffic, traffic_src = measured_traffic("pair" if pipelined else "stage_b")
@@ -623,6 +647,13 @@ def main():
                        "ranks": rank_devices},
             "roofline": roof,
         }
+        if batch_rec is not None:
+            out["batch512"] = batch_rec
+        if world > 1 and backend == "nccl":
+            try:
+                out["config"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                                        # noqa: BLE001
+                out["config"]["rccl_version"] = None
         if not pipelined:
             out["roofline_stage_ac"] = roofs["stage_ac"]
         if a.mode == "batch":

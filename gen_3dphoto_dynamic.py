@@ -119,16 +119,13 @@ def default_writers(local_world):
 
 def self_launch(opt, argv):
     """--gpus N > 1 without a launcher: start one process per GPU under torch.distributed.run and pass the exit status through."""
-    import socket
     import subprocess
     have = torch.cuda.device_count()
     if have < opt.gpus and "MPIFLOW_FORCE_DEVICE" not in os.environ:
         raise SystemExit("gen_3dphoto_dynamic: --gpus %d but only %d GPU(s) are visible on this box" % (opt.gpus, have))
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(opt.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    # --standalone: the launcher's own store picks and keeps a free port (no bind-then-close race); --local-addr: the host name may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(opt.gpus),
+           os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
     raise SystemExit(subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode)
 
 
@@ -267,10 +264,10 @@ def main(argv=None):
             nm, n_new, hand_off = pending.pop(0)
             try:
                 hand_off()
-                done += n_new
             except Exception as e:                                         # noqa: BLE001
                 torch.cuda.synchronize()
-                skipped.append((nm, "hand-off: %r" % (e,)))
+                skipped.append((nm, "hand-off after %d of %d pairs: %r" % (hand_off.submitted[0], n_new, e)))
+            done += hand_off.submitted[0]                                  # what reached the writers (and the statistics) is counted, whatever came after
         return done
     n_pairs, t_first, n_first, n_owned = 0, None, 0, 0
     for i, img in enumerate(names):
@@ -399,6 +396,8 @@ def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, m
         ready = torch.cuda.Event()
         ready.record()
 
+    submitted = [0]                                                        # pairs whose statistics were added AND whose files were handed to the writers
+
     def hand_off():
         with torch.cuda.stream(tail_stream):
             tail_stream.wait_event(ready)
@@ -407,12 +406,14 @@ def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, m
                     tns.record_stream(tail_stream)
                 flo_path, png_path = os.path.join(out, "flows", f"{name}_{r}.flo"), os.path.join(out, "dst_images", f"{name}_{r}.png")   # :120-121
                 with lap("hole fill / PNG scanlines + hand-off to the writers"):
-                    dstats.add(res["flow_mix"], res["fill_mask"])
                     if fill_mode in ("cv2", "builtin"):                    # :284-286 on the host, on a writer thread
                         ring.submit_pair_fill(res["flow_mix"], res["frame_mix"], res["fill_mask"], flo_path, png_path)
                     else:
                         frame = ops.fill_holes(res["frame_mix"], res["fill_mask"], workspace=fill_ws) if fill_mode == "peel" else res["frame_mix"]
                         ring.submit_pair(res["flow_mix"], ops.png_scanlines(frame), flo_path, png_path)
+                    dstats.add(res["flow_mix"], res["fill_mask"])          # statistics only for pairs that went out: n_pairs and the sums stay consistent
+                    submitted[0] += 1
+    hand_off.submitted = submitted
     return opt.repeat, hand_off
 
 

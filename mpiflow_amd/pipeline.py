@@ -516,21 +516,26 @@ def device_description(local_index):
         return "cuda:%d (%s)" % (int(local_index), type(e).__name__)
 
 
-_side_group = None
+_side_groups = {}
 
 
 def host_side_group(group=None):
-    """A gloo (CPU, TCP) process group over the same ranks, for the small host-side exchanges that must not touch RCCL: under the
-    "nccl" backend a collective between two ranks that share one GPU stalls or aborts deep inside RCCL, which is exactly the
-    misconfiguration assert_distinct_devices() exists to report.  Public API only (dist.new_group); created once, collectively."""
+    """A gloo (CPU, TCP) process group over the SAME ranks as `group` (default: the world), for the small host-side exchanges that must not
+    touch RCCL: under the "nccl" backend a collective between two ranks that share one GPU stalls or aborts deep inside RCCL, which is
+    exactly the misconfiguration assert_distinct_devices() exists to report.  Public API only (dist.new_group); created once per group,
+    collectively (new_group is a collective over the WORLD: every rank of the job must reach this call, in the same order, for a given
+    `group` - also the ranks that are not members, which get the non-member handle back)."""
     import torch.distributed as dist
-    global _side_group
     if dist.get_backend(group) == "gloo":
         return group
     world = dist.group.WORLD                                  # a side group belongs to ONE default group: never reuse it after a re-init
-    if _side_group is None or _side_group[0] is not world:
-        _side_group = (world, dist.new_group(backend="gloo"))
-    return _side_group[1]
+    key = (id(world), None if group is None or group is world else id(group))
+    hit = _side_groups.get(key)
+    if hit is None or hit[0] is not world:
+        ranks = None if key[1] is None else dist.get_process_group_ranks(group)
+        hit = (world, dist.new_group(ranks=ranks, backend="gloo"), group)      # keep `group` alive so that its id cannot be recycled
+        _side_groups[key] = hit
+    return hit[1]
 
 
 def exchange_device_records(local_index, group=None):

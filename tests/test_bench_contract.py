@@ -69,6 +69,30 @@ def test_gpus_flag_launches_the_ranks_itself():
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
 
 
+def test_eight_ranks_self_launched_with_the_strong_scaling_record():
+    """`python bench.py --gpus 8` (the driver's command on an 8-GPU node) with no launcher around it: eight ranks over gloo on the one device
+    of this box - rendezvous through the launcher's own store (no fixed port), the one-process-per-GPU record exchange over the gloo side
+    group, barrier, the statistics all-reduce, max-over-ranks timing, ONE line from rank 0 carrying the weak-scaling `value` AND the
+    configs[3] strong-scaling sub-record (a fixed batch sharded i % 8, per-rank seconds and pair counts)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0")
+    tiny = ["--planes", "8", "--height", "32", "--width", "64", "--images", "2", "--pairs-per-step", "0", "--steps", "2", "--warmup", "1", "--no-generator",
+            "--batch", "21"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + tiny, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["world_size"] == 8 and len(d["config"]["ranks"]) == 8 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    b = d["batch512"]
+    assert b["scaling"] == "strong" and b["batch_images"] == 21 and len(b["per_rank_seconds"]) == 8
+    assert b["per_rank_pairs"] == [3, 3, 3, 3, 3, 2, 2, 2] and sum(b["per_rank_pairs"]) == 21           # image i belongs to rank i % 8
+    assert abs(b["pairs_per_s"] - 21 / max(b["per_rank_seconds"])) / b["pairs_per_s"] < 1e-9
+
+
 def test_gpus_flag_fails_loudly_without_enough_devices():
     """No test hook: --gpus beyond the visible device count must exit non-zero with a message, not measure fewer GPUs silently."""
     if not torch.cuda.is_available():

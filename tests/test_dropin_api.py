@@ -321,6 +321,32 @@ def _run_cli(root, args, env=None, nproc=1, port=29551):
     return subprocess.run(cmd + [os.path.join(root, "gen_3dphoto_dynamic.py")] + args, capture_output=True, text=True, timeout=900, env=env)
 
 
+def test_cli_eight_ranks_write_the_files_of_one_rank(dev, tmp_path):
+    """`--gpus 8` from a bare python (what a user of an 8-GPU node types): the CLI starts eight ranks itself (gloo + the one device of this
+    box), images are sharded i % 8 (some ranks own two images, some one, the listing has a corrupt picture and a mask without instances),
+    rank 0 broadcasts the mask-maximum table, the skip lists are gathered, the statistics all-reduced - and every file equals the 1-rank run's."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ["im%02d" % i for i in range(11)]
+    base = tmp_path / "data"
+    _toy_dataset(base, names, empty_mask=("im03",), corrupt=("im06",))
+    common = ["--base", str(base), "--width", "64", "--height", "48", "--repeat", "2", "--planes", "16", "--inpaint", "none", "--mpi-from", "disparity"]
+    one, eight = tmp_path / "one", tmp_path / "eight"
+    r1 = _run_cli(root, ["--out", str(one)] + common)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MPIFLOW_DIST_BACKEND="gloo", MPIFLOW_FORCE_DEVICE="0")
+    r8 = _run_cli(root, ["--out", str(eight), "--gpus", "8"] + common, env=env)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    assert "pairs 18 " in r8.stdout and "(8 ranks)" in r8.stdout and "pairs 18 " in r1.stdout
+    assert open(one / "skipped.txt").read() == open(eight / "skipped.txt").read() and "im03" in open(eight / "skipped.txt").read()
+    for sub in ("flows", "dst_images", "src_images"):
+        files = sorted(os.listdir(one / sub))
+        assert len(files) == 18 and files == sorted(os.listdir(eight / sub))
+        for f in files:
+            assert open(one / sub / f, "rb").read() == open(eight / sub / f, "rb").read(), "%s/%s differs between 1 and 8 ranks" % (sub, f)
+
+
 def test_cli_skips_bad_images_without_disturbing_the_others(dev, tmp_path):
     """Failure isolation (the reference dies on a mask without instances, gen_3dphoto_dynamic_v2.py:101): an image whose mask holds no
     instance consumes NO draws, a corrupt picture is skipped after its draws - either way every other image gets the files it would

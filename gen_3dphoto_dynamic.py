@@ -32,9 +32,15 @@ import random
 import sys
 import time
 
+_T_PROCESS = time.perf_counter()                  # start-up is reported from here: it includes `import torch`
+
 # dmabuf IPC (the only mode this node pool's driver supports) for RCCL's peer-memory exchange between the per-GPU processes;
 # already exported by the launch environment, set here for a bare `torchrun gen_3dphoto_dynamic.py`
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# MIOpen (the batch-1 torch encoder / bottleneck of the producer network) in its immediate mode: on a box whose MIOpen user cache is empty the
+# default find mode spends 2.9-3.3 s searching / compiling in the FIRST forward, the immediate mode 0.3 s (tools/miopen_cold_start.py,
+# profiles/r4/generator_startup.txt); the encoder runs hidden underneath the feature-mask network either way.  Set it yourself to override.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import numpy as np
 import torch
@@ -130,6 +136,7 @@ def self_launch(opt, argv):
 
 
 def main(argv=None):
+    t_main = time.perf_counter()
     opt = parse(argv)
     if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(opt, argv)
@@ -319,6 +326,10 @@ def main(argv=None):
         pending.append((name, n_new, hand_off))
         if t_first is None and n_owned >= len(lanes):
             t_first, n_first = time.perf_counter(), n_pairs + sum(q[1] for q in pending)       # start-up (graph capture, first MIOpen calls) ends once every lane has run
+            if rank == 0:
+                print("start-up: %.2f s from process start until the first image was submitted (imports %.2f s, set-up + model + weight packing "
+                      "%.2f s, first image incl. MIOpen's first calls and the graph capture %.2f s)" % (
+                          t_first - _T_PROCESS, t_main - _T_PROCESS, t_start - t_main, t_first - t_start))
     n_pairs += finish_pending()
     with lap("drain writers"):
         torch.cuda.synchronize()

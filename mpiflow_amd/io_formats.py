@@ -172,16 +172,34 @@ class OutputRing:
         import queue
         import torch
         self.H, self.W, self.level, self._host_fill = H, W, png_level, host_fill
+        # slots are page-locked on demand, up to `slots` of them: pinning all 64 up front cost 0.4-0.7 s of start-up (7 MB each), and a run
+        # whose writers keep up never needs more than a handful
         self._free = queue.Queue()
-        for _ in range(slots):
-            slot = dict(flow=torch.empty((H, W, 2), dtype=torch.float32).pin_memory(),
-                        scan=torch.empty((H, 3 * W + 1), dtype=torch.uint8).pin_memory())
-            if host_fill is not None:
-                slot.update(frame=torch.empty((H, W, 3), dtype=torch.uint8).pin_memory(), hole=torch.empty((H, W), dtype=torch.uint8).pin_memory())
-            self._free.put(slot)
+        self._max_slots, self._n_slots, self._slot_lock = slots, 0, __import__("threading").Lock()
         self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=threads)
         self._futures = []
         self._torch = torch
+
+    def _new_slot(self):
+        torch, H, W = self._torch, self.H, self.W
+        slot = dict(flow=torch.empty((H, W, 2), dtype=torch.float32).pin_memory(),
+                    scan=torch.empty((H, 3 * W + 1), dtype=torch.uint8).pin_memory())
+        if self._host_fill is not None:
+            slot.update(frame=torch.empty((H, W, 3), dtype=torch.uint8).pin_memory(), hole=torch.empty((H, W), dtype=torch.uint8).pin_memory())
+        return slot
+
+    def _get_slot(self):
+        """A free slot; a new one while fewer than the maximum exist; else wait for a writer to hand one back (back-pressure)."""
+        import queue
+        try:
+            return self._free.get_nowait()
+        except queue.Empty:
+            pass
+        with self._slot_lock:
+            grow = self._n_slots < self._max_slots
+            if grow:
+                self._n_slots += 1
+        return self._new_slot() if grow else self._free.get()
 
     def _finish(self, slot, event, flo_path, png_paths, fill=False):
         try:
@@ -204,7 +222,7 @@ class OutputRing:
         """Like submit_pair, but the frame leaves the GPU unfilled together with its hole mask and the writer thread runs
         `host_fill` on it before encoding."""
         assert self._host_fill is not None
-        slot = self._free.get()
+        slot = self._get_slot()
         slot["flow"].copy_(flow_HW2_dev, non_blocking=True)
         slot["frame"].copy_(frame_bgr_dev, non_blocking=True)
         slot["hole"].copy_(hole_dev, non_blocking=True)
@@ -221,7 +239,7 @@ class OutputRing:
             self._futures = [f for f in self._futures if not f.done()]
 
     def _submit(self, flow_dev, scan_dev, flo_path, png_paths):
-        slot = self._free.get()
+        slot = self._get_slot()
         if flow_dev is not None:
             slot["flow"].copy_(flow_dev, non_blocking=True)
         slot["scan"].copy_(scan_dev, non_blocking=True)

@@ -55,7 +55,7 @@ def ksteps(ct):
     return (9 * ct + 31) // 32
 
 
-def pack_weights(w_rows, vmap, ct):
+def pack_weights(w_rows, vmap, ct, device=None):
     """Weights in MFMA A-fragment order for mpf_conv3x3_f16.
 
     w_rows [R, Cin, 3, 3] fp32 (R = 16 * nblk rows in packed order, zero rows for padding);  vmap: LongTensor [Cv], virtual
@@ -67,14 +67,18 @@ def pack_weights(w_rows, vmap, ct):
     R = w_rows.shape[0]
     assert R % 16 == 0 and vmap.numel() % ct == 0
     nblk, nchunk, KS, vpp, tps = R // 16, vmap.numel() // ct, ksteps(ct), ct // 8, 32 // ct
-    wv = torch.zeros(R, vmap.numel(), 10, dtype=torch.float32)          # tap 9 = the all-zero tap
+    # pure data movement (gathers of fp32 values, one rounding to fp16 at the end): done on `device` when given - the 20 layers of the network
+    # take 0.6 s of host time on the CPU, a few milliseconds on the GPU, same bytes
+    dev = torch.device(device) if device is not None else w_rows.device
+    w_rows, vmap = w_rows.to(dev), vmap.to(dev)
+    wv = torch.zeros(R, vmap.numel(), 10, dtype=torch.float32, device=dev)          # tap 9 = the all-zero tap
     valid = vmap >= 0
     wv[:, valid, :9] = w_rows.float().reshape(R, w_rows.shape[1], 9)[:, vmap[valid], :]
     q = torch.arange(4)
     ks = torch.arange(KS)
     slot = (ks[:, None] * tps + (q[None, :] // vpp)).clamp(max=9)       # [KS, 4]
-    ch = ((q % vpp) * 8)[:, None] + torch.arange(8)[None, :]             # [4, 8] channel inside the chunk
-    out = torch.empty(nchunk, KS, nblk, 4, 16, 8, dtype=torch.float32)
+    ch = (((q % vpp) * 8)[:, None] + torch.arange(8)[None, :]).to(dev)   # [4, 8] channel inside the chunk
+    out = torch.empty(nchunk, KS, nblk, 4, 16, 8, dtype=torch.float32, device=dev)
     wv = wv.reshape(nblk, 16, nchunk, ct, 10)
     for k in range(KS):
         for qq in range(4):
@@ -97,7 +101,7 @@ class ConvLayer:
         self.nblk, self.ncg, self.Cst, self.CA, self.CB = nblk, ncg, Cst, CA, CB
         self.vmap_real = vmap
         self.rows_real = int((rows_w.reshape(rows_w.shape[0], -1).abs().sum(1) > 0).sum())     # output rows that are not padding
-        self.wpack = pack_weights(rows_w, vmap, ct).to(device)
+        self.wpack = pack_weights(rows_w, vmap, ct, device=device).to(device)
         self.ep = ep.float().contiguous().to(device)
         assert self.ep.shape == (3, nblk * 16)
 

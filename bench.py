@@ -82,6 +82,9 @@ def parse():
     p.add_argument("--no-moving-object", action="store_true",
                    help="c3 without the moving-object chain (depth->flow projection, forward warp, masks): the render-only pair of rounds 1-3")
     p.add_argument("--chain-priority", type=int, default=0, help="tuning: 1 = the chain's side stream gets the highest stream priority")
+    p.add_argument("--main-priority", type=int, default=-1,
+                   help="tuning: run the timed workload on a stream of this priority (-1 = the device's highest) instead of the default stream, so that "
+                        "the chain's normal-priority side stream is only dispatched where the pair launches leave room")
     p.add_argument("--chain-cu-stride", type=int, default=0, help="tuning: the chain's side stream may only use every n-th compute unit (0 = all)")
     p.add_argument("--merge-in-launch", type=int, default=1,
                    help="1 = Stage D of pair i is a per-pixel prologue of the Stage A+C role of launch i+2 (one launch per pair); 0 = a launch of its own after every pair launch")
@@ -560,6 +563,10 @@ def main():
         B = a.images
         order = list(range(a.pairs_per_step if a.pairs_per_step > 0 else B))
     chain = dynamic and not a.no_moving_object
+    main_stream = torch.cuda.Stream(dev, priority=a.main_priority) if a.main_priority else None
+    if main_stream is not None:
+        main_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main_stream)
     if pipelined:
         wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank, moving_object=chain, chain_priority=bool(a.chain_priority), chain_ordered=bool(a.chain_ordered), merge_in_launch=bool(a.merge_in_launch), chain_cu_stride=a.chain_cu_stride)
     else:
@@ -643,7 +650,7 @@ def main():
             "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.mode == "batch" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "merge_in_launch": bool(a.merge_in_launch) if pipelined else None, "chain_cu_stride": a.chain_cu_stride, "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None, "tune": a.tune,
+            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "merge_in_launch": bool(a.merge_in_launch) if pipelined else None, "chain_cu_stride": a.chain_cu_stride, "main_stream_priority": a.main_priority, "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None, "tune": a.tune,
                        "pairs_per_step_per_gpu": len(order), "resident_stacks_per_gpu": B, "timed_seconds": dt,
                        "sharding": "independent images per rank (i % world == rank), stats all-reduce only",
                        "device": _lib.device_info(local),

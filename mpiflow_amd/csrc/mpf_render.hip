@@ -706,7 +706,9 @@ MPF_DEV float mpf_geom_l(MpfConstParams params, int s, const MpfConsts &c, MpfGe
 // on the way into LDS, so the tap reads are the same four ds_read_b128 - what costs the planar gather kernel 8 + 1 uncoalesced gathers per
 // plane and pixel (TA-bound, 0.32-0.35 of the HBM roofline) becomes <= 12 coalesced 4-byte loads per lane and plane: 248 -> 236 us with a mask,
 // 226 -> 214 without at 64 x 640 x 960 (profiles/r4/stage_b_planar_lds.log).  Tried on top and dropped: the mask's footprint through LDS as
-// well (97 VGPRs + 52 spilled SGPRs, four unaligned ds_read_b32 per pixel: 289 us) and 5 workgroups per CU (223 us without a mask).
+// well (97 VGPRs + 52 spilled SGPRs, four unaligned ds_read_b32 per pixel: 289 us), 5 workgroups per CU (223 us without a mask), and the box rows as
+// 16-byte loads of one channel into a channel-planar LDS tile (3 instead of 12 loads per lane and plane, taps = 8 ds_read2_b32: 244 / 215 us) -
+// the LDS forms are bound by the per-plane barrier and the LDS round trip, not by the global loads.
 template <bool HAS_MASK, int NL, bool KS, bool AUX, bool PLANAR = false>
 MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
                           int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,

@@ -60,6 +60,12 @@ def make_inputs(S, H, W, seed=0, kind="white"):
 
     Drawn plane by plane with numpy's PCG64 Generator straight into float32 (a 64x640x960 stack takes seconds and no
     multi-GB temporaries); goldens record SHA-256 digests of the arrays so a changed stream is detected, not trusted."""
+    # "<kind>_opaque": the same draws with the LAST plane made opaque (sigma + 0.05 there: its thickness is 1e3, utils/mpi/mpi_rendering.py:73-78),
+    # so the composited weights sum to 1 wherever a ray ends inside the stack and the rendered object masks cluster at 0 / 1 instead of
+    # spreading over (0, 1) - and a small object, see below: with a suitable seed NO pixel lies within 1e-5 of the 0.99 threshold (SURVEY section 7, hard part 2) and the
+    # thresholded masks compare bit for bit without exclusions (tests/golden/make_golden.py: the *_opaque goldens)
+    opaque = kind.endswith("_opaque")
+    kind = kind[:-len("_opaque")] if opaque else kind
     g = np.random.Generator(np.random.PCG64(1000 + seed))
     mpi = np.empty((S, 4, H, W), np.float32)
     if kind == "white":
@@ -78,7 +84,13 @@ def make_inputs(S, H, W, seed=0, kind="white"):
         img = _upsample(g.random((3, h, w)), H, W).astype(np.float32)
     else:
         raise ValueError(kind)
-    return dict(mpi=mpi, disparity=plane_disparities(S), image=img, obj_mask=soft_box_mask(H, W), K=intrinsics(H, W))
+    om = soft_box_mask(H, W)
+    if opaque:
+        mpi[-1, 3] += np.float32(0.05)
+        # ... and a SMALL object (H/16 x W/16 at the centre): around the object's outline the rendered mask takes every value between 0 and 1
+        # over a band as wide as the planes' parallax, so the number of pixels near 0.99 scales with the outline's length
+        om = soft_box_mask(H, W, y0=H / 2.0 - H / 32.0, y1=H / 2.0 + H / 32.0, x0=W / 2.0 - W / 32.0, x1=W / 2.0 + W / 32.0)
+    return dict(mpi=mpi, disparity=plane_disparities(S), image=img, obj_mask=om, K=intrinsics(H, W))
 
 
 def bench_pose():

@@ -127,7 +127,7 @@ def _render_run_pairs(dev, oracle, inp, G_cam, G_dyn, S, H, W, R=5):
     return got
 
 
-def _full_frame(dev, oracle, tag, S, H, W, seed, kind, pose_seed, golden=None, multi_view=True, mode="pair"):
+def _full_frame(dev, oracle, tag, S, H, W, seed, kind, pose_seed, golden=None, multi_view=True, mode="pair", no_margin=False):
     from mpiflow_amd import synth
     inp = synth.make_inputs(S, H, W, seed=seed, kind=kind)
     rng = random.Random(pose_seed)
@@ -184,10 +184,17 @@ def _full_frame(dev, oracle, tag, S, H, W, seed, kind, pose_seed, golden=None, m
     rec["fill_mask_flipped_px"] = int(fd.sum())
     rec["fill_mask_px"] = int(r0["fill_mask"].sum())
     assert flips <= max(8, int(2e-5 * H * W)), "too many threshold flips: %d" % flips
+    if no_margin:
+        # goldens recorded on inputs whose margin band is EMPTY (hard part 2): nothing was excluded above, so the
+        # thresholded masks and the fill mask were compared on every pixel - unconditional bit-exactness, against oracle and reference
+        assert int(margin.sum()) == 0 and flips == 0 and rec["fill_mask_flipped_px"] == 0
+        assert golden is not None and len(golden["margin_px_cam"]) == 0 and len(golden["margin_px_dyn"]) == 0 and len(golden["margin_px_obj"]) == 0
     ok = ~margin
     dfr = np.abs(got["frame_mix"].reshape(-1, 3)[ok].astype(np.int32) - r0["frame_mix"].reshape(-1, 3)[ok].astype(np.int32))
     rec["frame_mix_lsb_px"] = int((dfr.max(axis=1) > 0).sum())
-    assert dfr.max() <= 1 and rec["frame_mix_lsb_px"] < 2e-3 * H * W
+    # uint8 frames: a value whose x 255 lands within 1e-5 of a rounding boundary may round the other way under the two exp
+    # implementations - +-1 LSB on a COUNTED handful of pixels (0-10 per frame observed at every config shape), nothing larger
+    assert dfr.max() <= 1 and rec["frame_mix_lsb_px"] <= 16, rec["frame_mix_lsb_px"]
     assert bits_equal(got["src_np"], r0["src_np"]) == 0
     # 3. the reference's own golden where one was recorded
     if golden is not None:
@@ -207,6 +214,11 @@ def _full_frame(dev, oracle, tag, S, H, W, seed, kind, pose_seed, golden=None, m
         assert (fill & ~gm).sum() == 0
         rec["golden_fill_mask_flipped_px"] = int(fill.sum())
         rec["golden_margin_px"] = int(gm.sum())
+        if no_margin:
+            assert rec["golden_margin_px"] == 0 and rec["golden_fill_mask_flipped_px"] == 0 and rec["golden_cam_mask_flipped_px"] == 0 and rec["golden_dyn_mask_flipped_px"] == 0
+            # ... and the uint8 frame against the reference's own bytes on the sampled pixels: +-1 LSB on at most a handful
+            dg = np.abs(got["frame_mix"].reshape(-1, 3)[px].astype(np.int32) - golden["frame_mix_px"].astype(np.int32))
+            assert dg.max() <= 1 and int((dg.max(axis=1) > 0).sum()) <= 4
     _report(tag, rec)
 
 
@@ -240,6 +252,18 @@ def test_every_pixel_generator_shape(dev, oracle, name, mode):
     g = load_golden(name)
     _full_frame(dev, oracle, "%s_%s" % (name, mode), int(g["S"]), int(g["H"]), int(g["W"]), int(g["seed"]), str(g["kind"]), int(g["pose_seed"]),
                 golden=g, mode=mode)
+
+
+@pytest.mark.parametrize("name,mode", [("c1_opaque", "pair"), ("kitti_opaque", "run_pairs"), ("kitti_opaque", "overlapped"), ("c2_opaque", "pair"),
+                                       ("c2_opaque", "overlapped")])
+def test_every_pixel_masks_bit_exact_without_margin_band(dev, oracle, name, mode):
+    """Goldens recorded from the reference on inputs whose margin band is empty (no rendered-mask value within 1e-5 of the 0.99 threshold:
+    an opaque last plane and a small object, synth.make_inputs(kind='*_opaque'), seeds found with the oracle): the thresholded occlusion
+    masks and the fill mask are compared on EVERY pixel with NO exclusion - bit-exact against the pinned oracle and against the reference's
+    own packed masks - at the c1, the generator's and the c2 shape, stand-alone and through the pipelined launch forms."""
+    g = load_golden(name)
+    _full_frame(dev, oracle, "%s_%s_no_margin" % (name, mode), int(g["S"]), int(g["H"]), int(g["W"]), int(g["seed"]), str(g["kind"]), int(g["pose_seed"]),
+                golden=g, mode=mode, no_margin=True)
 
 
 def test_every_pixel_c1(dev, oracle):

@@ -197,7 +197,7 @@ def test_render_pair_small(oracle, name):
     assert bits_equal(out["src_np"], g["src_np"]) == 0
 
 
-@pytest.mark.parametrize("name,tol_flow", [("c1_white", 1e-4)])
+@pytest.mark.parametrize("name,tol_flow", [("c1_white", 1e-4), ("c1_opaque", 1e-4)])
 def test_render_pair_config_shape(oracle, name, tol_flow):
     """BASELINE config 1 shape (32 x 384 x 512): inputs regenerated from the seed, outputs checked at the recorded
     pixel sample and through packed full-frame masks."""
@@ -215,6 +215,11 @@ def test_render_pair_config_shape(oracle, name, tol_flow):
         diff = np.unpackbits(m ^ g[tag + "_mask_bits"])[: H * W]
         diff[g["margin_px_" + tag]] = 0
         assert diff.sum() == 0
+        if name.endswith("_opaque"):          # recorded on inputs whose margin band is empty: the comparison above excluded nothing
+            assert len(g["margin_px_" + tag]) == 0
+    if name.endswith("_opaque"):
+        fill = np.unpackbits(np.packbits(out["fill_mask"].ravel()) ^ g["fill_mask_bits"])[: H * W]
+        assert fill.sum() == 0 and int(out["fill_mask"].sum()) == int(g["fill_mask_count"])
     assert max_abs(out["flows"][0].reshape(2, -1)[:, px], g["cam_flow_px"]) < tol_flow
     assert max_abs(out["flows"][1].reshape(2, -1)[:, px], g["dyn_flow_px"]) < tol_flow
 

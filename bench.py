@@ -371,17 +371,23 @@ def hbm_reference(dev, nbytes=1 << 30, reps=10):
     return rec
 
 
-def cpu_baseline(S, H, W, pairs, budget_s=12.0):
-    """Time the oracle (checker, used here only as the reported CPU baseline) on full dynamic pairs: a bounded sample - pairs are
-    rendered until `budget_s` seconds of CPU work have been spent (at least 2, at most `pairs`)."""
+def cpu_baseline(S, H, W, pairs, budget_s=12.0, chain=True):
+    """Time the oracle (checker, used here only as the reported CPU baseline) on the workload of `value`: full dynamic pairs + the
+    moving-object chain of every pair (SURVEY 8(d)'s c3) - a bounded sample: pairs are rendered until `budget_s` seconds of CPU work have
+    been spent (at least 2, at most `pairs`)."""
     from oracle import mpi_oracle as orc
     inp = synth.make_inputs(S, H, W, seed=77, kind="white")
     rng = random.Random(114514)
     G_dyn = orc.random_pose(rng, 0.15)
     G_cam = orc.random_pose(rng, 0.15, base_motions=(0, 0, 0))
+    disp = np.random.RandomState(4242).rand(H, W).astype(np.float32)
+    inv_K = np.linalg.inv(np.asarray(inp["K"], np.float64)).astype(np.float32)
+    T_obj = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.tensor([[0.07, -0.06, 0.08]]))[0].numpy()
 
     def one():
-        orc.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
+        r = orc.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
+        if chain:
+            orc.moving_object(disp, r["src_np"], inp["K"], inv_K, inp["obj_mask"], T_obj)
 
     one()
     t0 = time.perf_counter()
@@ -391,8 +397,8 @@ def cpu_baseline(S, H, W, pairs, budget_s=12.0):
         n += 1
     dt = time.perf_counter() - t0
     return dict(value=n / dt, unit="pairs/s", cores=os.cpu_count(), kind="port",
-                sample="%d full dynamic pairs (blend + 2 flows, 2 warped views, merge) at %dx%dx%d by the plain-C oracle (OpenMP, %d threads), %.1f s" %
-                       (n, S, H, W, os.cpu_count(), dt))
+                sample="%d full dynamic pairs (blend + 2 flows, 2 warped views, merge%s) at %dx%dx%d by the plain-C oracle (OpenMP, %d threads), %.1f s" %
+                       (n, " + the moving-object chain: depth->flow projection, serial forward warp, masks" if chain else "", S, H, W, os.cpu_count(), dt))
 
 
 def sub_record(name, S, H, W, B, dev, dynamic, steps, multi_view=True, pipelined=False, moving_object=False):
@@ -708,7 +714,7 @@ def main():
             except Exception as e:                                   # noqa: BLE001 - a side record must never cost the headline line
                 out["generator"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, H, W, a.cpu_pairs)
+            out["cpu_baseline"] = cpu_baseline(S, H, W, a.cpu_pairs, chain=chain)
             out["cpu_baseline"]["reference_measured_in_build_container"] = \
                 "reference render_3dphoto_dynamic (the same full dynamic pair) 64x640x960: 104.8 s on 8 threads (tests/golden/make_golden.py)"
         print(json.dumps(out))

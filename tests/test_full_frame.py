@@ -70,7 +70,7 @@ def _render_pair(dev, inp, G_cam, G_dyn, S, H, W, multi_view):
 
 
 def _render_overlapped(dev, inp, G_cam, G_dyn, S, H, W):
-    """The pair as the bench / batch driver render it: inside an OverlappedPairRenderer stream, between two other images - its Stage A+C
+    """The pair as bench.py renders it: inside an OverlappedPairRenderer stream, between two other images - its Stage A+C
     shares a launch with the previous image's Stage B, its Stage B with the next image's Stage A+C."""
     from mpiflow_amd import pipeline, synth
     ovl = pipeline.OverlappedPairRenderer(S, H, W, dev)

@@ -790,7 +790,7 @@ def test_overlapped_launch_equals_separate_launches(dev, kernel_exp, S, H, W):
 
 @pytest.mark.parametrize("S,H,W,n", [(8, 32, 48, 5), (20, 23, 37, 3), (16, 64, 96, 1)])
 def test_overlapped_pair_renderer_equals_render_pair(dev, kernel_exp, S, H, W, n):
-    """pipeline.OverlappedPairRenderer (the bench's and the batch driver's throughput form: Stage B of pair i beside Stage A+C of pair
+    """pipeline.OverlappedPairRenderer (the throughput form of bench.py's streams of single pairs: Stage B of pair i beside Stage A+C of pair
     i+1) returns, for every pair of a stream of n images, exactly what pipeline.render_pair returns - and that is the oracle's answer."""
     from mpiflow_amd import pipeline
     o = kernel_exp

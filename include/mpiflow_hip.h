@@ -324,9 +324,13 @@ int mpf_moving_object_chain(const float *d_disp, const float *h_inv_k9, const fl
 #define MPF_CONV_LD_BILINEAR_CAT  2   /* x2 bilinear (align_corners) of srcA f16 [S,HA,WA,CA]  ++  srcB f16 [S,Hin,Win,CB]; fparams = {(HA-1)/(Hin-1), (WA-1)/(Win-1)} */
 #define MPF_CONV_LD_NEAREST_PLANE 3   /* x2 nearest (or same size) of srcA f16 [S,HA,WA,CA] (CA may be 0)  ++  per-plane skip: srcB f16 [Hin,Win,CB-8] shared
                                          features * cm[s], then (cm[s], fm[s], 0 x6); cm, fm f32 [S,Hin,Win]; CB == 0: no skip */
+#define MPF_CONV_LD_FMN_SYNTH      4   /* the feature-mask network's first layer never materialised: channels = relu(A' + plane_vals[s] * B'), srcA = A', srcB = B',
+                                         both f32 [Hin,Win,16] (A' = its pre-activation output for plane value 0, B' = the plane channel's share) */
+#define MPF_CONV_LD_BILINEAR_SYNTH 5   /* LD_BILINEAR_CAT whose skip source is synthesised the same way: srcB = A', cm = B' f32 [Hin,Win,16], CB = 16 */
 #define MPF_CONV_EP_AFFINE_RELU      0   /* out f16 [S,Hout,Wout,Cst] = relu(acc * ep[0][row] + ep[1][row]) */
 #define MPF_CONV_EP_AFFINE_RELU_F32  1   /* same, output channel 0 only, out f32 [S,Hout,Wout] */
 #define MPF_CONV_EP_GATED_ELU        2   /* g = (accF + ep[0][rowF]) * sigmoid(accM + ep[0][rowM]); out f16 NHWC = elu(g * ep[1][rowF] + ep[2][rowF]) */
+#define MPF_CONV_EP_AFFINE_F32_NHWC  4   /* out f32 [S,Hout,Wout,Cst] = acc * ep[0][row] + ep[1][row], NO activation */
 #define MPF_CONV_EP_GATED_PLANAR_F32 3   /* out f32 [S,Cst,Hout,Wout] = g (no BatchNorm / activation: the decoder's raw output layer) */
 
 typedef struct MpfConvArgs {
@@ -345,6 +349,8 @@ typedef struct MpfConvArgs {
     float fparams[4];
     int wlds;                         /* 1: the A fragments of a chunk are staged in LDS once per workgroup (many-chunk / many-block
                                          layers), 0: every wave loads its fragments from global memory (tuning choice, same results) */
+    int plane_major;                  /* 1: the plane index is the fastest grid dimension (the S workgroups of a tile back to back: per-image sources
+                                         shared by the planes stay in L2); scheduling only, same results */
 } MpfConvArgs;
 
 int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream);

@@ -36,10 +36,14 @@ constexpr int LD_FMN_INPUT = MPF_CONV_LD_FMN_INPUT;
 constexpr int LD_DIRECT = MPF_CONV_LD_DIRECT;
 constexpr int LD_BILINEAR_CAT = MPF_CONV_LD_BILINEAR_CAT;
 constexpr int LD_NEAREST_PLANE = MPF_CONV_LD_NEAREST_PLANE;
+constexpr int LD_FMN_SYNTH = MPF_CONV_LD_FMN_SYNTH;
+constexpr int LD_BILINEAR_SYNTH = MPF_CONV_LD_BILINEAR_SYNTH;
+constexpr bool is_bilinear(int loader) { return loader == LD_BILINEAR_CAT || loader == LD_BILINEAR_SYNTH; }
 constexpr int EP_AFFINE_RELU = MPF_CONV_EP_AFFINE_RELU;
 constexpr int EP_AFFINE_RELU_F32 = MPF_CONV_EP_AFFINE_RELU_F32;
 constexpr int EP_GATED_ELU = MPF_CONV_EP_GATED_ELU;
 constexpr int EP_GATED_PLANAR_F32 = MPF_CONV_EP_GATED_PLANAR_F32;
+constexpr int EP_AFFINE_F32_NHWC = MPF_CONV_EP_AFFINE_F32_NHWC;
 
 __host__ __device__ constexpr int pix_stride_bytes(int CT, int ST)
 {
@@ -110,6 +114,8 @@ struct Stage<LD_BILINEAR_CAT> {
     bool ok;
 };
 template <>
+struct Stage<LD_BILINEAR_SYNTH> : Stage<LD_BILINEAR_CAT> {};
+template <>
 struct Stage<LD_NEAREST_PLANE> {
     unsigned ia, ib;
     __half2 cm2;            // (cm, cm)
@@ -130,11 +136,11 @@ __device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs 
     st.ok = in_tile && (reflect || (y >= 0 && y < a.Hin && x >= 0 && x < a.Win));
     y = reflect_or_clamp(y, a.Hin, reflect);
     x = reflect_or_clamp(x, a.Win, reflect);
-    if constexpr (LOADER == LD_FMN_INPUT) {
+    if constexpr (LOADER == LD_FMN_INPUT || LOADER == LD_FMN_SYNTH) {
         st.ia = (unsigned)(y * a.Win + x);
     } else if constexpr (LOADER == LD_DIRECT) {
         st.ia = (unsigned)((s * a.Hin + y) * a.Win + x);
-    } else if constexpr (LOADER == LD_BILINEAR_CAT) {
+    } else if constexpr (is_bilinear(LOADER)) {
         // x2 bilinear, align_corners=True (nn.Upsample in model/CPN/unet.py:42): src = dst * (in-1)/(out-1)
         const float fy = a.fparams[0] * (float)y, fx = a.fparams[1] * (float)x;
         int y0 = (int)fy, x0 = (int)fx;
@@ -144,7 +150,7 @@ __device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs 
         // the raw tile holds rows ry0.. and columns rx0.. clamped to the source, so the +1 neighbours exist there at the borders too
         st.ia = (unsigned)((((y0 - ry0) * raw_pitch + (x0 - rx0)) * vpp + sv) * 16);
         st.w00 = hy * hx, st.w01 = hy * lx, st.w10 = ly * hx, st.w11 = ly * lx;
-        st.ib = (unsigned)((s * a.Hin + y) * a.Win + x);
+        st.ib = LOADER == LD_BILINEAR_SYNTH ? (unsigned)(y * a.Win + x) : (unsigned)((s * a.Hin + y) * a.Win + x);
     } else {
         const int ya = a.HA == a.Hin ? y : (y >> 1), xa = a.HA == a.Hin ? x : (x >> 1);
         st.ia = (unsigned)((s * a.HA + ya) * a.WA + xa);
@@ -155,6 +161,19 @@ __device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs 
 }
 
 __device__ __forceinline__ u32x4 select4(bool c, const u32x4 &v) { return u32x4{c ? v[0] : 0u, c ? v[1] : 0u, c ? v[2] : 0u, c ? v[3] : 0u}; }
+
+// The feature-mask network's FIRST layer never materialised (model/CPN/unet.py:44-50): its 64 plane-images differ only in the constant plane
+// channel d_s, and the layer is affine in it up to the ReLU - c1[s] = relu(A' + d_s * B') with A' = BN(conv(r, g, b, disparity, 0)) per image and
+// B' = BN-scale * conv(0, 0, 0, 0, 1) per size, both fp32 [H,W,16].  The consumers of c1 (layer 2, and layer 8's skip input) synthesise the 8
+// channels of vector v of pixel `pix` here: same fp32 value the layer-1 launch would have rounded to fp16 (up to the order of two roundings).
+__device__ __forceinline__ u32x4 synth_c1(const float *__restrict__ A, const float *__restrict__ B, unsigned pix, unsigned v, float d)
+{
+    const float4 *pa = reinterpret_cast<const float4 *>(A + ((size_t)pix * 16 + v * 8)), *pb = reinterpret_cast<const float4 *>(B + ((size_t)pix * 16 + v * 8));
+    const float4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+    const float r[8] = {fmaxf(fmaf(b0.x, d, a0.x), 0.f), fmaxf(fmaf(b0.y, d, a0.y), 0.f), fmaxf(fmaf(b0.z, d, a0.z), 0.f), fmaxf(fmaf(b0.w, d, a0.w), 0.f),
+                        fmaxf(fmaf(b1.x, d, a1.x), 0.f), fmaxf(fmaf(b1.y, d, a1.y), 0.f), fmaxf(fmaf(b1.z, d, a1.z), 0.f), fmaxf(fmaf(b1.w, d, a1.w), 0.f)};
+    return pack8(r);
+}
 
 // 8 consecutive virtual input channels (vector vv = chunk * VPP + sv) of the staged pixel, as 8 fp16.  Written without
 // divergent branches (clamped addresses + selects) so that the loads of all NI passes of a chunk can be in flight together.
@@ -173,7 +192,9 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
         const unsigned va = (unsigned)a.CA >> 3;
         const unsigned vc = vv < va ? vv : va - 1;
         return select4(st.ok && vv < va, ((const u32x4 *)a.srcA)[(size_t)st.ia * va + vc]);
-    } else if constexpr (LOADER == LD_BILINEAR_CAT) {
+    } else if constexpr (LOADER == LD_FMN_SYNTH) {
+        return select4(st.ok && vv < 2u, synth_c1((const float *)a.srcA, (const float *)a.srcB, st.ia, vv < 2u ? vv : 1u, a.plane_vals[s]));
+    } else if constexpr (is_bilinear(LOADER)) {
         const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3;       // va % VPP == 0 (checked by the launcher)
         if ((unsigned)(chunk * VPP) < va) {                                       // uniform: the whole chunk is source A
             const unsigned char *p = raw + st.ia;
@@ -190,6 +211,7 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
             return select4(st.ok, o);
         }
         const unsigned vq = vv - va, vc = vq < vb ? vq : vb - 1;
+        if constexpr (LOADER == LD_BILINEAR_SYNTH) return select4(st.ok && vq < vb, synth_c1((const float *)a.srcB, a.cm, st.ib, vc, a.plane_vals[s]));
         return select4(st.ok && vq < vb, ((const u32x4 *)a.srcB)[(size_t)st.ib * vb + vc]);
     } else {
         // [x2 nearest upsample of srcA (CA may be 0)] ++ [shared features * context mask, context mask, feature mask]
@@ -227,7 +249,7 @@ void k_conv3x3(const MpfConvArgs a)
     constexpr int WVEC = KS * NB * 64, NW = (WVEC + 255) / 256;      // 16-byte weight vectors per chunk, per thread
     constexpr int TILE_BYTES = (LH * LW * PIXB + 255) / 256 * 256;
     static_assert(GROUPS % 4 == 0, "tile must give every wave the same number of pixel groups");
-    constexpr bool RAW = LOADER == LD_BILINEAR_CAT;
+    constexpr bool RAW = is_bilinear(LOADER);
     constexpr int RH = raw_rows(LH), RW = raw_cols(LW), RAWVEC = RH * RW * VPP, NR = (RAWVEC + 255) / 256;
     constexpr int WL_BYTES = WLDS ? KS * NB * 1024 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -240,7 +262,10 @@ void k_conv3x3(const MpfConvArgs a)
     float *eplds = reinterpret_cast<float *>(lds + TILE_BYTES + WL_BYTES + RAW_BYTES_);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.z / a.ncg, cg = blockIdx.z - s * a.ncg;
+    // plane_major: the plane index is the FASTEST grid dimension, so the S workgroups of one tile are dispatched back to back (8 per XCD) and find the
+    // per-image sources they share (LD_FMN_SYNTH / LD_BILINEAR_SYNTH: the A', B' maps) in that XCD's L2 instead of re-fetching them per plane
+    const unsigned bx = a.plane_major ? blockIdx.y : blockIdx.x, by = a.plane_major ? blockIdx.z : blockIdx.y, bz = a.plane_major ? blockIdx.x : blockIdx.z;
+    const int s = (int)bz / a.ncg, cg = (int)bz - s * a.ncg;
     // affine epilogues use rows 0, 1 of all NB blocks; the gated one rows 1, 2 of its NB/2 feature blocks; the planar one none.
     // One value per thread, loaded here (the round trip overlaps the staging set-up) and parked in LDS: in its own region where
     // that costs no resident workgroup (EPW > 0), else in the input tile's space once the last MFMA phase is over.
@@ -253,7 +278,7 @@ void k_conv3x3(const MpfConvArgs a)
         const int row = tid / (EPN ? EPN : 1), c = tid - row * EPN;
         epv = a.ep[(row + (EP_GATED ? 1 : 0)) * (a.nblk * 16) + cg * (NB * 16) + c];
     }
-    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int ox0 = (int)bx * TW, oy0 = (int)by * TH;
     const int ix0 = ox0 * ST - 1, iy0 = oy0 * ST - 1;
 
     // staging slots of this thread: vector sv of tile pixels sp + k * PPT
@@ -367,7 +392,10 @@ void k_conv3x3(const MpfConvArgs a)
                 const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3, vq = (unsigned)(chunk * VPP + sv) - va, vc = vq < vb ? vq : vb - 1;
                 u32x4 ld[NI];
 #pragma unroll
-                for (int k = 0; k < NI; ++k) ld[k] = ((const u32x4 *)a.srcB)[(size_t)stage[k].ib * vb + vc];
+                for (int k = 0; k < NI; ++k) {
+                    if constexpr (LOADER == LD_BILINEAR_SYNTH) ld[k] = synth_c1((const float *)a.srcB, a.cm, stage[k].ib, vc, a.plane_vals[s]);
+                    else ld[k] = ((const u32x4 *)a.srcB)[(size_t)stage[k].ib * vb + vc];
+                }
 #pragma unroll
                 for (int k = 0; k < NI; ++k) staged[k] = select4(stage[k].ok && vq < vb, ld[k]);
             }
@@ -416,7 +444,7 @@ template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS
 int launch_w(const MpfConvArgs &a, hipStream_t st)
 {
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, KS = (9 * CT + 31) / 32;
-    constexpr int RAW_BYTES = LOADER == LD_BILINEAR_CAT ? raw_rows(LH) * raw_cols(LW) * (CT / 8) * 16 : 0;
+    constexpr int RAW_BYTES = is_bilinear(LOADER) ? raw_rows(LH) * raw_cols(LW) * (CT / 8) * 16 : 0;
     constexpr int LDS_OTHER = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + (WLDS ? KS * NB * 1024 : 0) + RAW_BYTES;
     constexpr int LDS_BYTES = LDS_OTHER + ep_lds_floats(EPI, NB, LDS_OTHER) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "tile + weights exceed the LDS of a CU");
@@ -426,6 +454,7 @@ int launch_w(const MpfConvArgs &a, hipStream_t st)
         attr_set = true;
     }
     dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH, a.S * a.ncg);
+    if (a.plane_major) grid = dim3(a.S * a.ncg, (a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH);
     hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS>), grid, dim3(256), LDS_BYTES, st, a);
     return mpf_launch_status("k_conv3x3");
 }
@@ -596,13 +625,19 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     MPF_REQUIRE((a.CA & 7) == 0 && (a.CB & 7) == 0, "mpf_conv3x3_f16: channel counts must be padded to multiples of 8");
     MPF_REQUIRE(a.wpack && a.ep && a.out, "mpf_conv3x3_f16: null weights/epilogue/output");
     MPF_REQUIRE(a.pad_mode == 0 || (a.Hin >= 2 && a.Win >= 2), "mpf_conv3x3_f16: reflection padding needs at least 2 rows and columns");
-    MPF_REQUIRE(a.loader != LD_BILINEAR_CAT || (a.CA % a.ct == 0 && a.CA > 0 && a.CB > 0), "mpf_conv3x3_f16: the upsampled source must fill whole chunks");
-    MPF_REQUIRE((size_t)a.S * a.ncg <= 65535, "mpf_conv3x3_f16: planes x channel groups exceeds the grid limit");
+    MPF_REQUIRE(!is_bilinear(a.loader) || (a.CA % a.ct == 0 && a.CA > 0 && a.CB > 0), "mpf_conv3x3_f16: the upsampled source must fill whole chunks");
+    MPF_REQUIRE((a.loader != LD_FMN_SYNTH && a.loader != LD_BILINEAR_SYNTH) || (a.plane_vals && a.srcA && a.srcB && (a.loader == LD_FMN_SYNTH ? a.CA == 16 : (a.CB == 16 && a.cm))),
+                "mpf_conv3x3_f16: the synthesised first-layer source needs the two fp32 maps (16 channels) and the plane values");
+    MPF_REQUIRE(a.plane_major ? ((a.Wout + 31) / 32 <= 65535 && (a.Hout + 3) / 4 <= 65535) : (size_t)a.S * a.ncg <= 65535, "mpf_conv3x3_f16: grid dimension limit exceeded");
     const int nb = a.nblk / a.ncg;
     const int key = a.loader * 1000 + a.epi * 100 + a.ct * 1 + a.stride * 10000;
     switch (key) {
     // feature-mask UNet (zero padding)
     case 10000 + LD_FMN_INPUT * 1000 + EP_AFFINE_RELU * 100 + 8:      return dispatch_nb<1, 8, LD_FMN_INPUT, EP_AFFINE_RELU>(a, nb, st);
+    // the first layer factorised: its pre-activation maps (fp32, one or two pseudo-planes) and the two consumers that synthesise its output
+    case 10000 + LD_FMN_INPUT * 1000 + EP_AFFINE_F32_NHWC * 100 + 8:  return nb == 1 ? launch<1, 8, LD_FMN_INPUT, EP_AFFINE_F32_NHWC, 1, 8, 32>(a, st) : MPF_ERR_UNSUPPORTED;
+    case 20000 + LD_FMN_SYNTH * 1000 + EP_AFFINE_RELU * 100 + 16:     return nb == 2 ? launch<2, 16, LD_FMN_SYNTH, EP_AFFINE_RELU, 2, 4, 32>(a, st) : MPF_ERR_UNSUPPORTED;
+    case 10000 + LD_BILINEAR_SYNTH * 1000 + EP_AFFINE_RELU * 100 + 16: return nb == 1 ? launch<1, 16, LD_BILINEAR_SYNTH, EP_AFFINE_RELU, 1, 8, 32>(a, st) : MPF_ERR_UNSUPPORTED;
     case 20000 + LD_DIRECT * 1000 + EP_AFFINE_RELU * 100 + 16:        return dispatch_nb<2, 16, LD_DIRECT, EP_AFFINE_RELU>(a, nb, st);
     case 20000 + LD_DIRECT * 1000 + EP_AFFINE_RELU * 100 + 32:        return dispatch_nb<2, 32, LD_DIRECT, EP_AFFINE_RELU>(a, nb, st);
     case 10000 + LD_DIRECT * 1000 + EP_AFFINE_RELU * 100 + 32:        return dispatch_nb<1, 32, LD_DIRECT, EP_AFFINE_RELU>(a, nb, st);

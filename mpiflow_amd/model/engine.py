@@ -19,8 +19,8 @@ import torch
 
 from .. import _lib
 
-LD_FMN_INPUT, LD_DIRECT, LD_BILINEAR_CAT, LD_NEAREST_PLANE = 0, 1, 2, 3
-EP_AFFINE_RELU, EP_AFFINE_RELU_F32, EP_GATED_ELU, EP_GATED_PLANAR_F32 = 0, 1, 2, 3
+LD_FMN_INPUT, LD_DIRECT, LD_BILINEAR_CAT, LD_NEAREST_PLANE, LD_FMN_SYNTH, LD_BILINEAR_SYNTH = 0, 1, 2, 3, 4, 5
+EP_AFFINE_RELU, EP_AFFINE_RELU_F32, EP_GATED_ELU, EP_GATED_PLANAR_F32, EP_AFFINE_F32_NHWC = 0, 1, 2, 3, 4
 
 
 def _ct(layer, default):
@@ -94,8 +94,8 @@ def _bn_affine(bn):
 class ConvLayer:
     """One packed layer + its launch."""
 
-    def __init__(self, device, *, loader, epi, stride, pad_mode, ct, vmap, rows_w, ep, nblk, ncg, Cst, CA, CB, name=""):
-        self.name, self.wlds_default = name, name in _WLDS_LAYERS
+    def __init__(self, device, *, loader, epi, stride, pad_mode, ct, vmap, rows_w, ep, nblk, ncg, Cst, CA, CB, name="", plane_major=False):
+        self.name, self.wlds_default, self.plane_major = name, name.rstrip("sp") in _WLDS_LAYERS or name in _WLDS_LAYERS, plane_major
         self.loader, self.epi, self.stride, self.pad_mode, self.ct = loader, epi, stride, pad_mode, ct
         self.nchunk = vmap.numel() // ct
         self.nblk, self.ncg, self.Cst, self.CA, self.CB = nblk, ncg, Cst, CA, CB
@@ -117,8 +117,9 @@ class ConvLayer:
         return torch.tensor(idx, dtype=torch.long)
 
     @classmethod
-    def affine_relu(cls, device, cbr, segments, *, loader, stride, ct, f32_out=False, name=""):
-        """Conv2d(bias) + BatchNorm(eval) + ReLU (ConvBNReLU, model/CPN/unet.py:6-15), zero padding."""
+    def affine_relu(cls, device, cbr, segments, *, loader, stride, ct, f32_out=False, name="", pre_activation=False, plane_major=False):
+        """Conv2d(bias) + BatchNorm(eval) + ReLU (ConvBNReLU, model/CPN/unet.py:6-15), zero padding.  pre_activation: no ReLU, every channel
+        as fp32 NHWC (EP_AFFINE_F32_NHWC) - the factorised first layer's maps."""
         conv, bn = cbr.layer[0], cbr.layer[1]
         cout = conv.out_channels
         nblk = (cout + 15) // 16
@@ -131,9 +132,10 @@ class ConvLayer:
         nb = nblk if nblk <= 8 else 8
         assert nblk % nb == 0
         CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
-        return cls(device, loader=loader, epi=EP_AFFINE_RELU_F32 if f32_out else EP_AFFINE_RELU, stride=stride, pad_mode=0, ct=ct,
+        epi = EP_AFFINE_F32_NHWC if pre_activation else (EP_AFFINE_RELU_F32 if f32_out else EP_AFFINE_RELU)
+        return cls(device, loader=loader, epi=epi, stride=stride, pad_mode=0, ct=ct,
                    vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep, nblk=nblk, ncg=nblk // nb, Cst=1 if f32_out else pad8(cout),
-                   CA=CA, CB=CB, name=name)
+                   CA=CA, CB=CB, name=name, plane_major=plane_major)
 
     @classmethod
     def gated(cls, device, gconv, bn, segments, *, loader, ct, planar=False, name=""):
@@ -173,6 +175,8 @@ class ConvLayer:
         if out is None:
             if self.epi == EP_AFFINE_RELU_F32:
                 out = torch.empty(S, Hout, Wout, dtype=torch.float32, device=dev)
+            elif self.epi == EP_AFFINE_F32_NHWC:
+                out = torch.empty(S, Hout, Wout, self.Cst, dtype=torch.float32, device=dev)
             elif self.epi == EP_GATED_PLANAR_F32:
                 out = torch.empty(S, self.Cst, Hout, Wout, dtype=torch.float32, device=dev)
             else:
@@ -187,8 +191,9 @@ class ConvLayer:
         a.ct, a.nchunk, a.nblk, a.ncg, a.Cst = self.ct, self.nchunk, self.nblk, self.ncg, self.Cst
         a.loader, a.epi, a.stride, a.pad_mode = self.loader, self.epi, self.stride, self.pad_mode
         a.wlds = int(_wlds(self.name, self.wlds_default))
+        a.plane_major = int(self.plane_major)
         self.last_call = dict(S=S, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, HA=a.HA, WA=a.WA)
-        if self.loader == LD_BILINEAR_CAT:
+        if self.loader in (LD_BILINEAR_CAT, LD_BILINEAR_SYNTH):
             a.fparams[0] = (a.HA - 1) / (Hin - 1) if Hin > 1 else 0.0
             a.fparams[1] = (a.WA - 1) / (Win - 1) if Win > 1 else 0.0
         with torch.cuda.device(dev):
@@ -209,6 +214,10 @@ def layer_accounting(layer):
     flops = 2.0 * S * Hout * Wout * rows_real * cin_real * 9
     if layer.loader == LD_FMN_INPUT:
         rd = Hin * Win * (3 + 1) * 4                                    # image + disparity, fp32, shared by the S planes
+    elif layer.loader == LD_FMN_SYNTH:
+        rd = 2 * Hin * Win * 16 * 4                                     # the two fp32 first-layer maps, shared by the S planes
+    elif layer.loader == LD_BILINEAR_SYNTH:
+        rd = S * c["HA"] * c["WA"] * layer.CA * 2 + 2 * Hin * Win * 16 * 4
     elif layer.loader == LD_DIRECT:
         rd = S * Hin * Win * layer.CA * 2
     elif layer.loader == LD_BILINEAR_CAT:
@@ -217,6 +226,8 @@ def layer_accounting(layer):
         rd = S * c["HA"] * c["WA"] * layer.CA * 2 + (Hin * Win * (layer.CB - 8) * 2 + 2 * S * Hin * Win * 4 if layer.CB else 0)
     if layer.epi == EP_AFFINE_RELU_F32:
         wr = S * Hout * Wout * 4
+    elif layer.epi == EP_AFFINE_F32_NHWC:
+        wr = S * Hout * Wout * layer.Cst * 4
     elif layer.epi == EP_GATED_PLANAR_F32:
         wr = S * layer.Cst * Hout * Wout * 4
     else:
@@ -242,6 +253,29 @@ class FeatMaskEngine:
         self.l7 = A(device, fmn.conv7, [(64, 64), (32, 32)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l7", 16), name="l7")
         self.l8 = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l8", 16), name="l8")
         self.l9 = A(device, fmn.conv9, [(16, 16)], loader=LD_DIRECT, stride=1, ct=16, f32_out=True, name="l9")
+        # The first layer factorised (model/CPN/unet.py:44-50): the 64 plane-images differ only in the constant plane channel d_s and the layer is
+        # affine in it up to the ReLU, c1[s] = relu(A' + d_s * B').  A' (per image) and B' (per size: zero padding makes it position-dependent at
+        # the border) are fp32 [H,W,16] maps from ONE plane's worth of the layer-1 kernel without its ReLU; layers 2 and 8 synthesise c1 in their
+        # loaders, plane index fastest in the grid so that the planes of a tile share the maps in L2.  The 1 GB activation is never written / read
+        # twice, the 0.32 ms launch is gone.  MPIFLOW_FMN_FACTOR=0 keeps the materialised form (A/B, per-layer tests).
+        import os
+        self.factor = os.environ.get("MPIFLOW_FMN_FACTOR", "1") != "0"
+        self.l1p = A(device, fmn.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8, name="l1p", pre_activation=True)
+        self.l2s = A(device, fmn.conv2, [(16, 16)], loader=LD_FMN_SYNTH, stride=2, ct=16, name="l2s", plane_major=True)
+        self.l8s = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_SYNTH, stride=1, ct=_ct("l8", 16), name="l8s", plane_major=True)
+        self._plane_map, self._zeros = {}, {}
+
+    def first_layer_maps(self, image_3HW, disp_HW):
+        """-> (A' [H,W,16] fp32 for this image, B' [H,W,16] fp32 for this size)"""
+        H, W = disp_HW.shape
+        dev = disp_HW.device
+        key = (H, W)
+        if key not in self._plane_map:
+            z3, z1 = torch.zeros(3, H, W, device=dev), torch.zeros(H, W, device=dev)
+            pre = self.l1p(2, H, W, srcA=z3, srcB=z1, plane_vals=torch.tensor([0.0, 1.0], device=dev))
+            self._plane_map[key] = (pre[1] - pre[0]).contiguous()        # BN-scale * conv(0, 0, 0, 0, 1): the bias / shift cancel
+            self._zeros[key] = torch.zeros(1, device=dev)
+        return self.l1p(1, H, W, srcA=image_3HW, srcB=disp_HW, plane_vals=self._zeros[key])[0], self._plane_map[key]
 
     def logits(self, image_3HW, disp_HW, plane_disp_S):
         S = plane_disp_S.numel()
@@ -249,14 +283,21 @@ class FeatMaskEngine:
         if H % 8 or W % 8:
             raise ValueError("feature-mask network needs H and W divisible by 8 (three stride-2 stages and x2 upsampling back)")
         img, dsp, pd = image_3HW.float().contiguous(), disp_HW.float().contiguous(), plane_disp_S.float().contiguous()
-        c1 = self.l1(S, H, W, srcA=img, srcB=dsp, plane_vals=pd)
-        c2 = self.l2(S, H, W, srcA=c1)
+        if self.factor:
+            A1, B1 = self.first_layer_maps(img, dsp)
+            c2 = self.l2s(S, H, W, srcA=A1, srcB=B1, plane_vals=pd)
+        else:
+            c1 = self.l1(S, H, W, srcA=img, srcB=dsp, plane_vals=pd)
+            c2 = self.l2(S, H, W, srcA=c1)
         c3 = self.l3(S, H // 2, W // 2, srcA=c2)
         c4 = self.l4(S, H // 4, W // 4, srcA=c3)
         c5 = self.l5(S, H // 8, W // 8, srcA=c4)
         c6 = self.l6(S, H // 4, W // 4, srcA=c5, srcB=c3, HA=H // 8, WA=W // 8)
         c7 = self.l7(S, H // 2, W // 2, srcA=c6, srcB=c2, HA=H // 4, WA=W // 4)
-        c8 = self.l8(S, H, W, srcA=c7, srcB=c1, HA=H // 2, WA=W // 2)
+        if self.factor:
+            c8 = self.l8s(S, H, W, srcA=c7, srcB=A1, cm=B1, plane_vals=pd, HA=H // 2, WA=W // 2)
+        else:
+            c8 = self.l8(S, H, W, srcA=c7, srcB=c1, HA=H // 2, WA=W // 2)
         return self.l9(S, H, W, srcA=c8)
 
     def __call__(self, image_3HW, disp_HW, plane_disp_S):
@@ -406,7 +447,7 @@ class HipPredictor:
 
     def layers(self):
         f, d = self.fmn, self.dec
-        out = [f.l1, f.l2, f.l3, f.l4, f.l5, f.l6, f.l7, f.l8, f.l9, d.up0[4]]
+        out = ([f.l1p, f.l2s, f.l3, f.l4, f.l5, f.l6, f.l7, f.l8s, f.l9] if f.factor else [f.l1, f.l2, f.l3, f.l4, f.l5, f.l6, f.l7, f.l8, f.l9]) + [d.up0[4]]
         for i in range(4, -1, -1):
             if i < 4:
                 out.append(d.up0[i])

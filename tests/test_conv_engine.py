@@ -119,6 +119,23 @@ def test_fmn_layers_match_torch():
         _close(_nchw(c1, 16), fmn.conv1(x))
         c2 = eng.l2(S, H, W, srcA=c1)
         _close(_nchw(c2, 32), fmn.conv2(_nchw(c1, 16)))
+        # the first layer factorised: c1 = relu(A' + d_s * B') synthesised in layer 2's loader from the two fp32 maps - never written.  The
+        # maps against torch (pre-activation BatchNorm output for plane value 0; the plane channel's share), the synthesised c1 against the
+        # materialised one (equal up to the order of two roundings: at most an fp16 ulp on a few values), layer 2 against torch on either
+        A1, B1 = eng.first_layer_maps(img, dsp)
+        bn, cv = fmn.conv1.layer[1], fmn.conv1.layer[0]
+        pre = lambda t: bn(cv(t))                                  # noqa: E731
+        x0 = torch.cat([img[None], dsp[None, None], torch.zeros(1, 1, H, W, device=dev)], 1)
+        x1 = torch.cat([torch.zeros(1, 4, H, W, device=dev), torch.ones(1, 1, H, W, device=dev)], 1)
+        xz = torch.zeros(1, 5, H, W, device=dev)
+        assert float((A1.permute(2, 0, 1) - pre(x0)[0]).abs().max()) < 2e-5 * max(1.0, float(pre(x0).abs().max()))
+        assert float((B1.permute(2, 0, 1) - (pre(x1) - pre(xz))[0]).abs().max()) < 2e-5 * max(1.0, float(pre(x1).abs().max()))
+        c1s = torch.relu(A1[None] + pd.view(S, 1, 1, 1) * B1[None]).to(torch.float16)
+        d1 = (c1s.float() - c1.float()).abs()
+        assert float((d1 / c1.float().abs().clamp(min=2.0 ** -14)).max()) <= 2.0 ** -9 and float((d1 > 0).float().mean()) < 0.05
+        c2s = eng.l2s(S, H, W, srcA=A1, srcB=B1, plane_vals=pd)
+        _close(_nchw(c2s, 32), fmn.conv2(_nchw(c1s, 16)))
+        _close(_nchw(c2s, 32), fmn.conv2(_nchw(c1, 16)), ulps=6)
         c3 = eng.l3(S, H // 2, W // 2, srcA=c2)
         _close(_nchw(c3, 64), fmn.conv3(_nchw(c2, 32)))
         c4 = eng.l4(S, H // 4, W // 4, srcA=c3)
@@ -131,6 +148,8 @@ def test_fmn_layers_match_torch():
         _close(_nchw(c7, 32), fmn.conv7(torch.cat([_q16(fmn.upsample(_nchw(c6, 64))), _nchw(c2, 32)], 1)), ulps=6)
         c8 = eng.l8(S, H, W, srcA=c7, srcB=c1, HA=H // 2, WA=W // 2)
         _close(_nchw(c8, 16), fmn.conv8(torch.cat([_q16(fmn.upsample(_nchw(c7, 32))), _nchw(c1, 16)], 1)), ulps=6)
+        c8s = eng.l8s(S, H, W, srcA=c7, srcB=A1, cm=B1, plane_vals=pd, HA=H // 2, WA=W // 2)          # skip input synthesised, plane-major grid
+        _close(_nchw(c8s, 16), fmn.conv8(torch.cat([_q16(fmn.upsample(_nchw(c7, 32))), _nchw(c1s, 16)], 1)), ulps=6)
         lg = eng.l9(S, H, W, srcA=c8)
         ref = fmn.conv9(_nchw(c8, 16))[:, 0]
         assert float((lg - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
@@ -276,7 +295,7 @@ def test_engine_at_the_generator_size():
     # the work bench.py's roofline_n1 is quoted on: 20 convolution launches + the plane masks; ~4.1 TFLOP (the reference's convolutions on the
     # real channel counts) and ~12 GB (every layer's sources read once, its output written once) per image at this size
     rows, tot = hp.accounting()
-    assert len(rows) == 21 and [r["name"] for r in rows][:3] == ["l1", "l2", "l3"] and rows[-1]["name"] == "plane_masks"
+    assert len(rows) == 21 and [r["name"] for r in rows][:3] == ["l1p", "l2s", "l3"] and rows[-1]["name"] == "plane_masks"
     assert 3.5e12 < tot["flops"] < 4.6e12 and 9e9 < tot["bytes"] < 15e9, tot
     assert float((cum[-1] - 1).abs().max()) < 1e-5 and float(cum.min()) >= 0 and bool((cum[1:] >= cum[:-1] - 1e-6).all())
     with torch.no_grad():

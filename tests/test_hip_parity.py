@@ -446,6 +446,31 @@ def test_one_call_moving_object_chain_vs_reference_golden(dev, oracle, name):
         _lib.check(_lib.load().mpf_tune(b"chain_grid", 0))
 
 
+@pytest.mark.parametrize("h,w,spread", [(1, 1, 0.0), (3, 7, 0.5), (33, 65, 1.0), (64, 64, 3.0), (100, 300, 0.2), (257, 511, 1.5)])
+def test_one_call_chain_vs_oracle_ragged_shapes_and_pile_ups(dev, oracle, h, w, spread):
+    """mpf_moving_object_chain against the oracle's moving_object (its forward warp is the serial C) on ragged sizes - one pixel, sizes that are
+    no multiple of any tile, every radix-digit width of the sort - with object translations from sub-pixel to far out of the frame (spread x
+    the frame: whole regions clamp onto the border pixels = the pile-up case), random disparities incl. exact zeros, both source-frame forms."""
+    from mpiflow_amd import host_math, moving_obj
+    rs = np.random.RandomState(h * 131 + w)
+    disp = rs.rand(h, w).astype(np.float32)
+    disp[rs.rand(h, w) < 0.05] = 0.0
+    inst = (rs.rand(h, w) < 0.4).astype(np.float32)
+    rgb = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    K = np.array([[0.58 * w, 0, 0.5 * w], [0, 0.58 * h, 0.5 * h], [0, 0, 1]], np.float32)
+    inv_K = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    T = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.tensor([[spread, -0.7 * spread, 0.08]]))
+    want = oracle.moving_object(disp, rgb, K, inv_K, inst, T[0].numpy())
+    chain = moving_obj.MovingObjectChain(h, w, K, inv_K, dev, T_obj=T)
+    for src in (torch.from_numpy(rgb).to(dev), torch.from_numpy(np.ascontiguousarray(rgb[..., ::-1].transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0)).to(dev)):
+        b = chain.run(torch.from_numpy(disp).to(dev), torch.from_numpy(inst).to(dev), src, which=0)
+        assert bits_equal(N(b.safe_x), want["safe_x"]) == 0 and bits_equal(N(b.safe_y), want["safe_y"]) == 0
+        assert bits_equal(N(b.z1), want["z1"]) == 0 and bits_equal(N(b.p1), want["p1"]) == 0 and bits_equal(N(b.flow_01), want["flow01"]) == 0
+        assert bits_equal(N(b.warped), want["warped"]) == 0
+        for k in want["masks"]:
+            assert bits_equal(N(b.masks[k]), want["masks"][k]) == 0, k
+
+
 def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
     """SURVEY 8(d)'s full c3 in the throughput form bench.py times: a stream of 64 x 640 x 960 dynamic pairs through
     pipeline.OverlappedPairRenderer with the moving-object chain attached (side stream, two output sets) - for EVERY pair of the stream

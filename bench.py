@@ -85,6 +85,8 @@ def parse():
     p.add_argument("--main-priority", type=int, default=-1,
                    help="tuning: run the timed workload on a stream of this priority (-1 = the device's highest) instead of the default stream, so that "
                         "the chain's normal-priority side stream is only dispatched where the pair launches leave room")
+    p.add_argument("--main-cu-exclude-stride", type=int, default=0,
+                   help="tuning: the pair stream is barred from every n-th compute unit (use with --chain-cu-stride n: the chain then owns those CUs)")
     p.add_argument("--chain-cu-stride", type=int, default=0, help="tuning: the chain's side stream may only use every n-th compute unit (0 = all)")
     p.add_argument("--merge-in-launch", type=int, default=1,
                    help="1 = Stage D of pair i is a per-pixel prologue of the Stage A+C role of launch i+2 (one launch per pair); 0 = a launch of its own after every pair launch")
@@ -570,6 +572,10 @@ def main():
         order = list(range(a.pairs_per_step if a.pairs_per_step > 0 else B))
     chain = dynamic and not a.no_moving_object
     main_stream = torch.cuda.Stream(dev, priority=a.main_priority) if a.main_priority else None
+    if a.main_cu_exclude_stride > 1:                         # tuning: the pair stream may use every CU EXCEPT those the chain's side stream is confined to
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().mpf_stream_create_cu_subset(-a.main_cu_exclude_stride, 0, ctypes.byref(h)), "mpf_stream_create_cu_subset")
+        main_stream = torch.cuda.ExternalStream(h.value, device=dev)
     if main_stream is not None:
         main_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_stream)

@@ -30,6 +30,10 @@ extern "C" int mpf_version(void) { return MPF_VERSION; }
 // launch): its workgroups then compete for slots on few CUs instead of taking a slot here and there on all of them.
 extern "C" int mpf_stream_create_cu_subset(int stride, int offset, void **out_stream)
 {
+    // stride < 0: the COMPLEMENT - every CU except those of (|stride|, offset) - for the stream of the chip-filling launch, so that the side work's
+    // CUs are its own (no workgroup-slot or issue-slot sharing at all)
+    const bool invert = stride < 0;
+    if (invert) stride = -stride;
     MPF_REQUIRE(out_stream && stride >= 1 && offset >= 0 && offset < stride, "mpf_stream_create_cu_subset: bad argument");
     int dev = 0;
     MPF_HIP(hipGetDevice(&dev));
@@ -40,7 +44,8 @@ extern "C" int mpf_stream_create_cu_subset(int stride, int offset, void **out_st
     memset(mask, 0, sizeof(mask));
     MPF_REQUIRE(ncu <= 1024, "mpf_stream_create_cu_subset: more compute units than the mask holds");
     int n = 0;
-    for (int c = offset; c < ncu; c += stride) { mask[c >> 5] |= 1u << (c & 31); ++n; }
+    for (int c = 0; c < ncu; ++c)
+        if (((c % stride) == offset) != invert) { mask[c >> 5] |= 1u << (c & 31); ++n; }
     MPF_REQUIRE(n >= 1, "mpf_stream_create_cu_subset: empty CU set");
     hipStream_t st = nullptr;
     MPF_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask));

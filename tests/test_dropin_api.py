@@ -130,6 +130,16 @@ def test_render_and_render_tgt_rgb_depth(dev, name):
     assert not mpi_rendering.fused_render_applies(disp, xt, xs, G, Ki, K)
     no_mask = mpi_rendering.render_tgt_rgb_depth(hs, rgb_b, sig, disp, mpi_rendering.get_tgt_xyz_from_plane_disparity(xs, G), xs, G, Ki, K)
     assert no_mask[4] is None and max_abs(N(no_mask[0][0]), g["rtd_rgb"]) < 2e-6
+    # a batch of two (the functions are batched although the entry point is batch-1): item 0 = the case above, item 1 = the other pose
+    G2 = torch.cat([G, T(g["G_dyn"], dev)[None]])
+    rep2 = lambda t: t.repeat(2, *([1] * (t.dim() - 1)))            # noqa: E731
+    xs2 = mpi_rendering.get_src_xyz_from_plane_disparity(hs.meshgrid, rep2(disp), rep2(Ki))
+    xt2 = mpi_rendering.get_tgt_xyz_from_plane_disparity(xs2, G2)
+    assert mpi_rendering.fused_render_applies(rep2(disp), xt2, xs2, G2, rep2(Ki), rep2(K), obj_mask=rep2(om_in))
+    fb = mpi_rendering.render_tgt_rgb_depth(hs, rep2(rgb_b), rep2(sig), rep2(disp), xt2, xs2, G2, rep2(Ki), rep2(K), None, obj_mask=rep2(om_in))
+    gb = mpi_rendering.render_tgt_rgb_depth(hs, rep2(rgb_b), rep2(sig), rep2(disp), xt2, xs2, G2, rep2(Ki), rep2(K), None, obj_mask=rep2(om_in), fused=False)
+    assert all(tuple(t.shape)[0] == 2 for t in fb) and torch.equal(fb[0][0], f_rgb[0]) and torch.equal(fb[3][0], f_flow[0])
+    assert torch.equal(fb[2], gb[2]) and max_abs(N(fb[0]), N(gb[0])) < 1e-6 and max_abs(N(fb[3]), N(gb[3])) < 1e-5 and max_abs(N(fb[4]), N(gb[4])) < 1e-6
 
 
 @pytest.mark.parametrize("name", ["tiny_white", "odd_s20", "s1"])

@@ -511,6 +511,9 @@ def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
                 assert len(done) == 4
                 if not ordered:
                     done[3].ready.synchronize()                          # the independent chain: results come with their own event
+                    ev = torch.cuda.Event()                              # ... and a consumer's `consumed` event protects the set from being rewritten
+                    ev.record()
+                    done[3].consumed = ev
                 _check_chain_against_golden(g, done[3], oracle)          # synchronises (reads back): the NEXT push then overwrites nothing in use
             res.append([N(t).copy() for t in done[:3]])
         for k, (Gc, Gd) in enumerate(poses):

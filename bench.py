@@ -696,7 +696,12 @@ def main():
                 sub.append(sub_record("c3 pipelined: Stage B of pair i + Stage A+C of pair i+1 per launch", 64, 640, 960, 4, dev, True, 5, pipelined=True))
             sub.append(sub_record("c3 + moving-object chain (SURVEY 8(d)'s full c3), serial: pair kernels one after the other + the chain's 5 launches on the same stream",
                                   64, 640, 960, 4, dev, True, 5, moving_object=True))
-            sub.append(sub_record("c3 render only, pipelined (no moving-object chain: the `value` of rounds 1-3)", 64, 640, 960, 4, dev, True, 5, pipelined=True))
+            alone = sub_record("c3 render only, pipelined (no moving-object chain: the `value` of rounds 1-3)", 64, 640, 960, 8, dev, True, 10, pipelined=True)
+            sub.append(alone)
+            if pipelined and chain:
+                # the same launch WITHOUT the chain's kernels running underneath it: what the kernel does on its own on this box (the headline
+                # `roofline` is measured over the timed region, where the chain takes 20 - 26 us per pair from it)
+                out["roofline_pair_alone"] = dict(alone["pair"], pairs_per_s=alone["pairs_per_s"])
             if not (pipelined and chain):
                 sub.append(sub_record("c3 pipelined + moving-object chain on the side stream (SURVEY 8(d)'s full c3 in the throughput form)", 64, 640, 960, 4, dev, True, 5,
                                       pipelined=True, moving_object=True))

@@ -232,7 +232,7 @@ class OverlappedPairRenderer(_PairHostSide):
         self.fusable = S * H * W * 16 < (1 << 32)
 
     def attach_chain(self, chain, high_priority=False, ordered=True, cu_stride=0):
-        """chain: moving_obj.MovingObjectChain with (at least) two output sets.
+        """chain: moving_obj.MovingObjectChain with (at least) two output sets - three with merge_in_launch.
         ordered=True: the chain splats the uint8 source frame the pair's Stage A+C role wrote and its results are stream-ordered on the
           MAIN stream when the pair is handed back - costs the main stream an event record and an event wait per pair (measured: 12 us per
           pair at 64 x 640 x 960, the command processor handles both between two pair launches).
@@ -243,7 +243,11 @@ class OverlappedPairRenderer(_PairHostSide):
           too early, `moving_ready` of push() names the event after which the pair's inputs may be read (None: one is recorded on the main
           stream), and flush() joins the side stream.
         high_priority: the side stream gets the device's highest stream priority (no measurable effect at 64 x 640 x 960)."""
-        assert len(chain.bufs) >= 2 and (chain.H, chain.W) == (self.H, self.W)
+        # a pair's output set must survive until the pair has been handed back: one push() later, two with merge_in_launch - the sets are used
+        # round-robin, so that takes two resp. three of them
+        need = 3 if self.merge_in_launch else 2
+        if len(chain.bufs) < need or (chain.H, chain.W) != (self.H, self.W):
+            raise ValueError("attach_chain: the chain needs %d output sets (n_buffers) of %d x %d for this renderer" % (need, self.H, self.W))
         self.chain, self.chain_ordered, self._chain_next = chain, ordered, 0
         if cu_stride and cu_stride > 1:
             # the side stream may only use every cu_stride-th compute unit: the chain's latency-sized workgroups then sit on few CUs instead of
@@ -269,12 +273,13 @@ class OverlappedPairRenderer(_PairHostSide):
         if self.chain is None or not self.chain_ordered or moving is None:
             return None
         slot["ev_src"].record()
+        which, self._chain_next = self._chain_next, (self._chain_next + 1) % len(self.chain.bufs)      # output sets round-robin (see attach_chain)
         with torch.cuda.stream(self.side):
             self.side.wait_event(slot["ev_src"])
             if os.environ.get("MPF_CHAIN_DEBUG") == "events_only":      # measurement hook (tools/): the event choreography without the chain's kernels
-                b = self.chain.bufs[slot["index"]]
+                b = self.chain.bufs[which]
             else:
-                b = self.chain.run(moving[0], moving[1], slot["src_u8"], which=slot["index"])
+                b = self.chain.run(moving[0], moving[1], slot["src_u8"], which=which)
             slot["ev_chain"].record()
         slot["chain_busy"] = True
         return b

@@ -499,7 +499,7 @@ def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
     def stream(with_chain, high_priority=False, ordered=True, merge_in_launch=False):
         ovl = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=merge_in_launch)
         if with_chain:
-            ovl.attach_chain(moving_obj.MovingObjectChain(H, W, g["K"], g["inv_K"], dev, T_obj=torch.from_numpy(g["T_obj"])[None], n_buffers=2 if ordered else 3),
+            ovl.attach_chain(moving_obj.MovingObjectChain(H, W, g["K"], g["inv_K"], dev, T_obj=torch.from_numpy(g["T_obj"])[None], n_buffers=3 if (merge_in_launch or not ordered) else 2),
                              high_priority=high_priority, ordered=ordered)
         outs = [tuple(torch.empty(s, dtype=dt, device=dev) for s, dt in (((H, W, 2), torch.float32), ((H, W, 3), torch.uint8), ((H, W), torch.uint8))) for _ in range(3)]
         res = []

@@ -363,6 +363,39 @@ int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream);
 int mpf_plane_masks(const float *d_logits, int S, int H, int W, float *d_feature_mask, float *d_cum_mask, float *const *d_cm,
                     float *const *d_fm, void *stream);
 
+/* ---- the single-image part of the producer in fp32: RGBD ResNet-18 encoder + the decoder's bottleneck ----------------------
+ * (model/CPN/encoder.py:20-101: conv1 7x7/2 + bn1 + relu, maxpool, layer1-4 of two BasicBlocks each;
+ *  model/CPN/decoder.py:85-88,131-138: maxpool, conv1x1 + BN + LeakyReLU(0.1), maxpool, conv3x3, x2 nearest, conv3x3, x2 nearest, conv1x1.)
+ * Activations: fp32 NHWC.  fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 epilogue. */
+
+/* x = cat((image - mean) / std, disparity) (model/CPN/encoder.py:84-85,89-93): image f32 [3,H,W], disparity f32 [H,W] -> f32 [H,W,4] */
+int mpf_encoder_input(const float *d_image_3HW, const float *d_disp_HW, int H, int W, float *d_out_HW4, void *stream);
+
+/* One convolution (no bias) + per-channel affine (BatchNorm folded) [+ residual] + activation over one NHWC fp32 image:
+ *   out[p, c] = act(conv(src)[p, c] * scale[c] + shift[c] (+ residual[p, c])),  zero padding.
+ * up = 1: the convolution's input is the x2 nearest-neighbour upsampling of src (Hin x Win is the UPSAMPLED size; src is [Hin/2, Win/2, Cin]).
+ * wpack: f32 [Cout/16][nsteps][64 lanes][4], nsteps = ceil(ksize^2 * Cin/4 / 4): lane (m = l % 16, g = l / 16) of step s holds, for j = 0..3,
+ *   W[16 blk + m][channel 4 (v % (Cin/4)) + j][tap v / (Cin/4)] with v = 4 s + g, zero when the tap index exceeds ksize^2 - 1
+ *   (mpiflow_amd/model/engine.py: pack_weights_f32).  Cin a power of two >= 4, Cout a multiple of 32.
+ * out (f32) and out_f16 (f16, same NHWC shape: what the per-plane decoder's loaders read) are both optional, at least one is required. */
+typedef struct MpfConv2dArgs {
+    const float *src;
+    const float *wpack;
+    const float *scale, *shift;       /* f32 [Cout] */
+    const float *residual;            /* f32 [Hout,Wout,Cout] or NULL */
+    float *out;                       /* f32 [Hout,Wout,Cout] or NULL */
+    void *out_f16;                    /* f16 [Hout,Wout,Cout] or NULL */
+    int Hin, Win, Cin, Hout, Wout, Cout;
+    int ksize, stride, pad;           /* ksize 1, 3 or 7; stride 1 or 2 */
+    int up;                           /* 0, or 1: x2 nearest upsampling of src in front of the convolution */
+    int act;                          /* 0 none, 1 ReLU, 2 LeakyReLU(slope) */
+    float slope;
+} MpfConv2dArgs;
+int mpf_conv2d_f32(const MpfConv2dArgs *args, void *stream);
+
+/* nn.MaxPool2d(3, stride 2, padding 1) on an NHWC fp32 image: [Hin,Win,C] -> [(Hin-1)/2+1, (Win-1)/2+1, C]; C a multiple of 4 */
+int mpf_maxpool3x3s2_f32(const float *d_src_HWC, int Hin, int Win, int C, float *d_out, void *stream);
+
 /* THE REFERENCE'S FFI SYMBOL (external/forward_warping/warping.c:6; bound at moving_obj.py:12-13, called at :127-129).
  * Same name, same argument meaning, HOST pointers: src u8 [h*w*3], idx/idy int64 [h*w] (pre-clamped by the caller, as
  * in the reference), z f32 [h*w], warped u8 [h*w*5] (caller-owned).  Synchronous.  Runs the HIP kernels above on the

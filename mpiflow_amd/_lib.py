@@ -36,6 +36,13 @@ class MpfConvArgs(ctypes.Structure):
                 ("fparams", c_f * 4), ("wlds", c_i), ("plane_major", c_i)]
 
 
+class MpfConv2dArgs(ctypes.Structure):
+    """struct MpfConv2dArgs of include/mpiflow_hip.h: one fp32 convolution of the single-image encoder / bottleneck."""
+    _fields_ = [("src", c_p), ("wpack", c_p), ("scale", c_p), ("shift", c_p), ("residual", c_p), ("out", c_p), ("out_f16", c_p),
+                ("Hin", c_i), ("Win", c_i), ("Cin", c_i), ("Hout", c_i), ("Wout", c_i), ("Cout", c_i),
+                ("ksize", c_i), ("stride", c_i), ("pad", c_i), ("up", c_i), ("act", c_i), ("slope", c_f)]
+
+
 class MpfWarpView(ctypes.Structure):
     """struct MpfWarpView of include/mpiflow_hip.h: one view of mpf_warp_composite_views (device pointers)."""
     _fields_ = [("d_params", c_p), ("d_mask_quads", c_p), ("d_rgb", c_p), ("d_depth", c_p), ("d_objmask", c_p),
@@ -104,6 +111,9 @@ SIGNATURES = {
     "mpf_tune": (c_i, [ctypes.c_char_p, c_i]),
     "mpf_conv3x3_f16": (c_i, [ctypes.POINTER(MpfConvArgs), c_p]),
     "mpf_plane_masks": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p]),
+    "mpf_encoder_input": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+    "mpf_conv2d_f32": (c_i, [ctypes.POINTER(MpfConv2dArgs), c_p]),
+    "mpf_maxpool3x3s2_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
 }
 
 

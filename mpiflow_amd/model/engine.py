@@ -305,6 +305,128 @@ class FeatMaskEngine:
         return torch.softmax(self.logits(image_3HW, disp_HW, plane_disp_S), dim=0)
 
 
+def pack_weights_f32(w, device=None):
+    """Conv2d weight [Cout, Cin, k, k] fp32 -> [Cout/16, nsteps, 64, 4]: the A-operand order of mpf_conv2d_f32 (include/mpiflow_hip.h).
+    K runs over 4-channel vectors v = tap * (Cin/4) + c4; step s covers v = 4s .. 4s+3 (one per 16-lane group g), zero past the last tap."""
+    Cout, Cin, k, _ = w.shape
+    assert Cout % 16 == 0 and Cin % 4 == 0
+    dev = torch.device(device) if device is not None else w.device
+    nv = k * k * (Cin // 4)
+    nsteps = (nv + 3) // 4
+    wv = w.detach().float().to(dev).permute(0, 2, 3, 1).reshape(Cout, nv, 4)
+    wv = torch.cat([wv, torch.zeros(Cout, nsteps * 4 - nv, 4, device=dev)], dim=1).reshape(Cout // 16, 16, nsteps, 4, 4)    # [blk, m, s, g, j]
+    return wv.permute(0, 2, 3, 1, 4).reshape(Cout // 16, nsteps, 64, 4).contiguous()
+
+
+class Conv2dF32:
+    """One single-image fp32 convolution (no bias) + folded BatchNorm [+ residual] + activation: a launch of mpf_conv2d_f32."""
+
+    ACT = {None: 0, "relu": 1, "leaky": 2}
+
+    def __init__(self, device, conv, bn, *, act, up=0, slope=0.0, name=""):
+        assert conv.bias is None and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
+        self.name = name
+        self.k, self.stride, self.pad, self.up = conv.kernel_size[0], conv.stride[0], conv.padding[0], up
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.act, self.slope = self.ACT[act], float(slope)
+        self.wpack = pack_weights_f32(conv.weight, device=device)
+        scale, shift = _bn_affine(bn)
+        self.scale, self.shift = scale.contiguous().to(device), shift.contiguous().to(device)
+
+    def __call__(self, src_HWC, residual=None, f32=True, f16=False):
+        """src_HWC f32 [h,w,Cin] (the source BEFORE the x2 nearest upsampling when up = 1) -> (f32 [Hout,Wout,Cout] or None, f16 same or None)"""
+        hs, ws, c = src_HWC.shape
+        assert c == self.cin and src_HWC.dtype == torch.float32 and src_HWC.is_contiguous()
+        Hin, Win = hs << self.up, ws << self.up
+        Hout, Wout = (Hin + 2 * self.pad - self.k) // self.stride + 1, (Win + 2 * self.pad - self.k) // self.stride + 1
+        dev = src_HWC.device
+        out = torch.empty(Hout, Wout, self.cout, dtype=torch.float32, device=dev) if f32 else None
+        out16 = torch.empty(Hout, Wout, self.cout, dtype=torch.float16, device=dev) if f16 else None
+        a = _lib.MpfConv2dArgs()
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())      # noqa: E731
+        a.src, a.wpack, a.scale, a.shift, a.residual, a.out, a.out_f16 = p(src_HWC), p(self.wpack), p(self.scale), p(self.shift), p(residual), p(out), p(out16)
+        a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout = Hin, Win, self.cin, Hout, Wout, self.cout
+        a.ksize, a.stride, a.pad, a.up, a.act, a.slope = self.k, self.stride, self.pad, self.up, self.act, self.slope
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(_lib.load().mpf_conv2d_f32(ctypes.byref(a), stream), "mpf_conv2d_f32")
+        self.last_call = dict(Hout=Hout, Wout=Wout)
+        return out, out16
+
+    def flops(self):
+        c = self.last_call
+        return 2.0 * c["Hout"] * c["Wout"] * self.cout * self.cin * self.k * self.k
+
+
+def maxpool3x3s2(src_HWC):
+    """nn.MaxPool2d(3, 2, 1) on an NHWC fp32 image (mpf_maxpool3x3s2_f32)"""
+    h, w, c = src_HWC.shape
+    out = torch.empty((h - 1) // 2 + 1, (w - 1) // 2 + 1, c, dtype=torch.float32, device=src_HWC.device)
+    with torch.cuda.device(src_HWC.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.load().mpf_maxpool3x3s2_f32(ctypes.c_void_p(src_HWC.data_ptr()), h, w, c, ctypes.c_void_p(out.data_ptr()), stream), "mpf_maxpool3x3s2_f32")
+    return out
+
+
+class EncoderEngine:
+    """The single-image part of the producer in HIP, fp32: ResnetEncoder.forward (model/CPN/encoder.py:86-101) and the bottleneck at the head
+    of DepthDecoder.forward (model/CPN/decoder.py:131-138) - 24 convolutions + 3 max-pools + the input normalisation, 28 launches, no
+    MIOpen / ATen kernel.  Hands the per-plane decoder exactly what DecoderEngine.shared_inputs did: the bottleneck output and the four
+    skip features as NHWC fp16 (written by the producing convolution's epilogue beside its fp32 output)."""
+
+    def __init__(self, encoder, decoder, device):
+        e = encoder.encoder
+        C = Conv2dF32
+        self.conv1 = C(device, e.conv1, e.bn1, act="relu", name="enc.conv1")
+        self.blocks = []
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(e, "layer%d" % li)):
+                n = "enc.layer%d.%d" % (li, bi)
+                ds = None if blk.downsample is None else C(device, blk.downsample[0], blk.downsample[1], act=None, name=n + ".downsample")
+                self.blocks.append((C(device, blk.conv1, blk.bn1, act="relu", name=n + ".conv1"), C(device, blk.conv2, blk.bn2, act="relu", name=n + ".conv2"), ds))
+        L = lambda seq, up, n: C(device, seq[0], seq[1], act="leaky", slope=seq[2].negative_slope, up=up, name=n)      # noqa: E731
+        self.down1, self.down2 = L(decoder.conv_down1, 0, "dec.conv_down1"), L(decoder.conv_down2, 0, "dec.conv_down2")
+        self.up1, self.up2 = L(decoder.conv_up1, 1, "dec.conv_up1"), L(decoder.conv_up2, 1, "dec.conv_up2")
+
+    def convs(self):
+        out = [self.conv1]
+        for c1, c2, ds in self.blocks:
+            out += [c for c in (ds, c1, c2) if c is not None]
+        return out + [self.down1, self.down2, self.up1, self.up2]
+
+    def forward(self, image_3HW, disp_HW, keep_f32=False):
+        """-> (top f16 [H/32,W/32,512], [c1, b1, b2, b3] f16 NHWC); keep_f32: also the fp32 NHWC tensors [c1, b1, b2, b3, b4, top] (tests)"""
+        H, W = disp_HW.shape
+        dev = disp_HW.device
+        img, dsp = image_3HW.float().contiguous(), disp_HW.float().contiguous()
+        x = torch.empty(H, W, 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(_lib.load().mpf_encoder_input(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(dsp.data_ptr()), H, W, ctypes.c_void_p(x.data_ptr()), stream),
+                       "mpf_encoder_input")
+        c1, c1h = self.conv1(x, f16=True)
+        f32, f16 = [c1], [c1h]
+        x = maxpool3x3s2(c1)
+        for i, (conv_a, conv_b, ds) in enumerate(self.blocks):
+            identity = x if ds is None else ds(x)[0]
+            y, _ = conv_a(x)
+            last_of_stage = i % 2 == 1
+            x, xh = conv_b(y, residual=identity, f16=last_of_stage and i < 7)
+            if last_of_stage:
+                f32.append(x)
+                if xh is not None:
+                    f16.append(xh)
+        t, _ = self.down1(maxpool3x3s2(x))
+        t, _ = self.down2(maxpool3x3s2(t))
+        t, _ = self.up1(t)
+        top, toph = self.up2(t, f32=keep_f32, f16=True)
+        if keep_f32:
+            return toph, f16, f32 + [top]
+        return toph, f16
+
+    __call__ = forward
+
+
 class DecoderEngine:
     """DepthDecoder.forward (model/CPN/decoder.py:124-174) for B = 1: bottleneck on torch, the 11 gated convolutions over
     S planes in HIP.  Returns the raw last-layer output [S,4,H,W] fp32 and the cumulative mask [S,H,W] fp32 - the hand-off
@@ -400,7 +522,8 @@ class HipPredictor:
     it: the forward is ~30 launches of a few hundred microseconds each, so Python/launch overhead would otherwise be as long
     as the GPU work.  With a graph the returned tensors are STATIC buffers, overwritten by the next call."""
 
-    def __init__(self, model, encoder_dtype=None, graph=False):
+    def __init__(self, model, encoder_dtype=None, graph=False, encoder=None):
+        import os
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.MpiFlowHipError("HipPredictor needs the model on the GPU; there is no CPU path")
@@ -408,6 +531,11 @@ class HipPredictor:
         self.encoder_dtype = encoder_dtype
         self.fmn = FeatMaskEngine(model.fmn, dev)
         self.dec = DecoderEngine(model.decoder, model.encoder.num_ch_enc, dev, amp_dtype=encoder_dtype)
+        # the single-image part: "hip" (default) = EncoderEngine, fp32 HIP kernels; "torch" = the torch modules (MIOpen / ATen), kept for A/B
+        self.encoder_kind = encoder or os.environ.get("MPIFLOW_ENCODER", "hip")
+        if self.encoder_kind not in ("hip", "torch"):
+            raise ValueError("encoder must be 'hip' or 'torch', not %r" % (self.encoder_kind,))
+        self.enc = EncoderEngine(model.encoder, model.decoder, dev) if self.encoder_kind == "hip" else None
         self.graph = graph
         self._graphs = {}
         self._side, self._fork, self._join = torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event()
@@ -429,14 +557,17 @@ class HipPredictor:
             # MIOpen's default algorithm choice for these batch-1 convolutions is not run-to-run reproducible (1e-4 on the 1/32 feature
             # map, amplified to ~1 % of the output range by a random-weight decoder); its deterministic algorithms are, and the
             # encoder is hidden underneath the feature-mask network either way - so a replayed graph equals an eager run bit for bit
-            det = torch.backends.cudnn.deterministic
-            torch.backends.cudnn.deterministic = True
-            try:
-                with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=self.encoder_dtype is not None):
-                    feats = m.encoder(src_imgs, src_depths)
-                shared = self.dec.shared_inputs(feats)
-            finally:
-                torch.backends.cudnn.deterministic = det
+            if self.enc is not None:
+                feats, shared = None, self.enc(src_imgs[0], src_depths[0, 0])
+            else:
+                det = torch.backends.cudnn.deterministic
+                torch.backends.cudnn.deterministic = True
+                try:
+                    with torch.autocast("cuda", dtype=self.encoder_dtype, enabled=self.encoder_dtype is not None):
+                        feats = m.encoder(src_imgs, src_depths)
+                    shared = self.dec.shared_inputs(feats)
+                finally:
+                    torch.backends.cudnn.deterministic = det
             self._join.record(self._side)
         masks = plane_masks(self.fmn.logits(src_imgs[0], src_depths[0, 0], disp))
         main.wait_event(self._join)

@@ -510,7 +510,7 @@ def generator_record(n_images=64, repeat=5, timeout=600):
                                          "state as 1 / (1 + start-up / run time)" % (n_images * repeat, n_images * repeat / max(1e-9, float(steady[-1].split(":")[1].split("pairs/s")[0])) if steady else float("nan")))
         if steady:
             rec["pairs_per_s_steady_state"] = float(steady[-1].split(":")[1].split("pairs/s")[0])
-            rec["steady_state_note"] = "the CLI's own figure: pairs after the first image / time after the first image (start-up = graph capture, first MIOpen calls, excluded)"
+            rec["steady_state_note"] = "the CLI's own figure: pairs after the first image / time after the first image (start-up = graph capture and first launches, excluded)"
         return rec
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -521,8 +521,8 @@ MFMA_F16_PEAK = 2.5e15   # dense fp16 MFMA, flop/s (MI355X_MICROARCH.md; AMD's h
 
 def n1_record(dev, S=64, H=384, W=1280, iters=10):
     """SURVEY 8(f) N1 - the AdaMPI producer on the HIP engine (mpiflow_amd.model.engine.HipPredictor, random weights of the reference's
-    architecture, the generator's 64 x 384 x 1280): one image = 20 mpf_conv3x3_f16 launches + mpf_plane_masks (+ the batch-1 torch encoder on a
-    side stream), replayed from one hipGraph.  Algorithmic flops = the reference's own convolutions on the real channel counts; algorithmic
+    architecture, the generator's 64 x 384 x 1280): one image = 20 mpf_conv3x3_f16 launches + mpf_plane_masks + the single-image encoder / bottleneck
+    (24 mpf_conv2d_f32 launches, 3 max-pools, the input normalisation: fp32, on a side stream), replayed from one hipGraph.  Algorithmic flops = the reference's own convolutions on the real channel counts; algorithmic
     bytes = every layer's sources read once and its output written once in the engine's storage types (HipPredictor.accounting).  Both
     roofline fractions are of the whole forward: it is bound by neither alone."""
     from mpiflow_amd.model import MPIPredictor
@@ -543,7 +543,7 @@ def n1_record(dev, S=64, H=384, W=1280, iters=10):
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / iters * 1e-3
     rec = {"workload": "AdaMPI producer (N1) on the HIP engine: %d planes x %d x %d, fp16 storage / fp32 accumulate, one hipGraph replay per image" % (S, H, W),
-           "ms_per_image": t * 1e3, "images_per_s": 1.0 / t, "launches": len(rows),
+           "ms_per_image": t * 1e3, "images_per_s": 1.0 / t, "launches": sum(r.get("launches", 1) for r in rows), "encoder": hp.encoder_kind,
            "algorithmic_flops_per_image": tot["flops"], "algorithmic_bytes_per_image": tot["bytes"],
            "hbm": {"bound": "hbm", "achieved": tot["bytes"] / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": tot["bytes"] / t / HBM_PEAK},
            "mfma": {"bound": "mfma", "achieved": tot["flops"] / t / 1e12, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": tot["flops"] / t / MFMA_F16_PEAK},

@@ -37,9 +37,9 @@ _T_PROCESS = time.perf_counter()                  # start-up is reported from he
 # dmabuf IPC (the only mode this node pool's driver supports) for RCCL's peer-memory exchange between the per-GPU processes;
 # already exported by the launch environment, set here for a bare `torchrun gen_3dphoto_dynamic.py`
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# MIOpen (the batch-1 torch encoder / bottleneck of the producer network) in its immediate mode: on a box whose MIOpen user cache is empty the
-# default find mode spends 2.9-3.3 s searching / compiling in the FIRST forward, the immediate mode 0.3 s (tools/miopen_cold_start.py,
-# profiles/r4/generator_startup.txt); the encoder runs hidden underneath the feature-mask network either way.  Set it yourself to override.
+# MIOpen in its immediate mode - only the --model-engine torch path (and MPIFLOW_ENCODER=torch) still reaches MIOpen; the default hip engine runs
+# the whole network on this repo's kernels.  On a box whose MIOpen user cache is empty the default find mode spends 2.9-3.3 s searching /
+# compiling in the FIRST forward, the immediate mode 0.3 s (tools/miopen_cold_start.py, profiles/r4/generator_startup.txt).  Set it yourself to override.
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import numpy as np
@@ -72,9 +72,10 @@ def parse(argv=None):
                         "disparity: a hard-assignment stand-in built from the disparity map (NOT the reference's producer - for smoke runs)")
     p.add_argument("--model-dtype", choices=["fp32", "fp16", "bf16"], default="fp32", help="autocast dtype of the network's convolutions")
     p.add_argument("--model-engine", choices=["hip", "torch"], default="hip",
-                   help="hip (default): the per-plane networks - feature-mask UNet and gated decoder, > 98 %% of the network's flops - on the MFMA "
-                        "convolution engine (fp16 storage, fp32 accumulate: the precision of the reference's own GPU run, which calls .half() on model "
-                        "and inputs, gen_3dphoto_dynamic_v2.py:46,59,82-84), one hipGraph per image, 8.5 ms per 64 x 384 x 1280 image; torch: every "
+                   help="hip (default): the whole network on this repo's HIP kernels - the per-plane feature-mask UNet and gated decoder (> 98 %% of "
+                        "the flops) on the fp16 MFMA convolution engine (fp16 storage, fp32 accumulate: the precision of the reference's own GPU run, which "
+                        "calls .half() on model and inputs, gen_3dphoto_dynamic_v2.py:46,59,82-84), the single-image encoder / bottleneck in fp32 - one "
+                        "hipGraph per image, 7.8 ms per 64 x 384 x 1280 image; torch: every "
                         "convolution on PyTorch/MIOpen (fp32 with --model-dtype fp32 = the reference's CPU numerics, 115 ms per image)")
     p.add_argument("--inpaint", choices=list(U.INPAINT_METHODS), default="auto",
                    help="hole filling of the rendered frame (reference: cv2.inpaint NS radius 3).  auto = cv2 when OpenCV is installed, else "
@@ -325,10 +326,10 @@ def main(argv=None):
         n_pairs += finish_pending()                                        # the PREVIOUS image's pairs go to the writers now, behind this image's launches
         pending.append((name, n_new, hand_off))
         if t_first is None and n_owned >= len(lanes):
-            t_first, n_first = time.perf_counter(), n_pairs + sum(q[1] for q in pending)       # start-up (graph capture, first MIOpen calls) ends once every lane has run
+            t_first, n_first = time.perf_counter(), n_pairs + sum(q[1] for q in pending)       # start-up (graph capture, first launches) ends once every lane has run
             if rank == 0:
                 print("start-up: %.2f s from process start until the first image was submitted (imports %.2f s, set-up + model + weight packing "
-                      "%.2f s, first image incl. MIOpen's first calls and the graph capture %.2f s)" % (
+                      "%.2f s, first image incl. the graph capture %.2f s)" % (
                           t_first - _T_PROCESS, t_main - _T_PROCESS, t_start - t_main, t_first - t_start))
     n_pairs += finish_pending()
     with lap("drain writers"):

@@ -4,8 +4,9 @@ The S-times-batched parts of the network - the feature-mask UNet (reference mode
 decoder (model/CPN/decoder.py:74-174) - are run as 20 launches of `mpf_conv3x3_f16` (mpiflow_amd/csrc/mpf_conv.hip):
 every launch is one 3x3 convolution over all S planes whose loader synthesises the layer's input (the expand / cat /
 upsample / reflection-pad tensors of the reference are never written) and whose epilogue applies BatchNorm, activation and
-the gate.  The single-image parts (ResNet-18 encoder, the 1x1 / 3x3 bottleneck at 1/32 .. 1/128 resolution) stay on
-torch: they are batch-1 and a few percent of the work.
+the gate.  The single-image parts (ResNet-18 encoder model/CPN/encoder.py:20-101, the 1x1 / 3x3 bottleneck at 1/32 .. 1/128 resolution
+model/CPN/decoder.py:131-138) are 24 launches of `mpf_conv2d_f32` (mpiflow_amd/csrc/mpf_encoder.hip, fp32 MFMA) + 3 max-pools on a side
+stream underneath the feature-mask network: 1 % of the work, no MIOpen / ATen kernel left in the forward.
 
 Precision: fp16 storage and MFMA inputs, fp32 accumulation and epilogue - the reference's own GPU configuration
 (`.half()`, gen_3dphoto_dynamic_v2.py:46,59,82-84).  `MPIPredictor.forward` (fp32 torch) remains the bit-exact mirror of
@@ -350,7 +351,8 @@ class Conv2dF32:
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(_lib.load().mpf_conv2d_f32(ctypes.byref(a), stream), "mpf_conv2d_f32")
-        self.last_call = dict(Hout=Hout, Wout=Wout)
+        self.last_call = dict(Hout=Hout, Wout=Wout, bytes=float(src_HWC.numel() * 4 + self.wpack.numel() * 4 + (residual.numel() * 4 if residual is not None else 0)
+                                                                + Hout * Wout * self.cout * ((4 if f32 else 0) + (2 if f16 else 0))))
         return out, out16
 
     def flops(self):
@@ -514,11 +516,13 @@ def pad16(c):
 class HipPredictor:
     """MPIPredictor.forward(raw=True) (model/AdaMPI.py:55-78) for one image with the per-plane networks on the HIP engine.
 
-    encoder_dtype: autocast dtype of the batch-1 torch part (ResNet-18 encoder, bottleneck).  Default None = fp32: it runs on a
-    side stream underneath the feature-mask network either way, fp16 is not faster there (0.98 vs 1.15 ms) and costs 3x the
-    end-to-end error (mean |rgb| error vs the fp32 model 3.2e-3 with an fp32 encoder, 1.1e-2 with fp16; torch fp16: 1.2e-2).
+    encoder: "hip" (default; env MPIFLOW_ENCODER) = EncoderEngine, the single-image part as fp32 HIP kernels (0.64 ms alone, forward 7.8 ms);
+    "torch" = the torch modules on MIOpen / ATen (0.99 ms alone, forward 8.4 ms: its kernels take more from the feature-mask network they
+    run beside), kept for A/B.  encoder_dtype: autocast dtype of that torch variant.  Default None = fp32: fp16 is not faster there and
+    costs 3x the end-to-end error (mean |rgb| error vs the fp32 model 3.2e-3 with an fp32 encoder, 1.1e-2 with fp16; torch fp16: 1.2e-2) -
+    which is why the HIP encoder computes in fp32 too.
 
-    graph=True captures the whole forward (torch encoder + 21 HIP launches) into one hipGraph per input size and replays
+    graph=True captures the whole forward (28 single-image + 21 per-plane HIP launches) into one hipGraph per input size and replays
     it: the forward is ~30 launches of a few hundred microseconds each, so Python/launch overhead would otherwise be as long
     as the GPU work.  With a graph the returned tensors are STATIC buffers, overwritten by the next call."""
 
@@ -548,18 +552,18 @@ class HipPredictor:
     def _forward(self, src_imgs, src_depths):
         m = self.model
         disp = self._plane_disp
-        # the batch-1 torch part (encoder, bottleneck: ~60 small launches) runs on a side stream underneath the feature-mask
+        # the single-image part (encoder, bottleneck: 28 small launches) runs on a side stream underneath the feature-mask
         # network, which fills the GPU on its own; the decoder joins the two
         main = torch.cuda.current_stream()
         self._fork.record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(self._fork)
-            # MIOpen's default algorithm choice for these batch-1 convolutions is not run-to-run reproducible (1e-4 on the 1/32 feature
-            # map, amplified to ~1 % of the output range by a random-weight decoder); its deterministic algorithms are, and the
-            # encoder is hidden underneath the feature-mask network either way - so a replayed graph equals an eager run bit for bit
             if self.enc is not None:
-                feats, shared = None, self.enc(src_imgs[0], src_depths[0, 0])
+                feats, shared = None, self.enc(src_imgs[0], src_depths[0, 0])       # deterministic by construction (fixed split-K order)
             else:
+                # MIOpen's default algorithm choice for these batch-1 convolutions is not run-to-run reproducible (1e-4 on the 1/32 feature
+                # map, amplified to ~1 % of the output range by a random-weight decoder); its deterministic algorithms are, and the
+                # encoder is hidden underneath the feature-mask network either way - so a replayed graph equals an eager run bit for bit
                 det = torch.backends.cudnn.deterministic
                 torch.backends.cudnn.deterministic = True
                 try:
@@ -586,13 +590,17 @@ class HipPredictor:
         return out + [d.disp0]
 
     def accounting(self):
-        """Per-layer and total algorithmic flops / HBM bytes of the 20 convolution launches of the last forward (layer_accounting), plus
-        the plane-mask pass (logits read twice, cumulative mask + pyramid written)."""
+        """Per-layer and total algorithmic flops / HBM bytes of the 20 per-plane convolution launches of the last forward (layer_accounting), the
+        plane-mask pass (logits read twice, cumulative mask + pyramid written) and - one row - the single-image part on the HIP encoder (its 24
+        convolutions: real flops; source, residual, weights read once, outputs written once)."""
         rows = [layer_accounting(L) for L in self.layers() if getattr(L, "last_call", None)]
         c = self.fmn.l9.last_call
         n = c["S"] * c["Hout"] * c["Wout"] * 4
         rows.append(dict(name="plane_masks", flops=0.0, bytes=float(2 * n + n + 2 * n * (1 / 4 + 1 / 16 + 1 / 64 + 1 / 256 + 1 / 1024)), read_bytes=float(2 * n),
                          write_bytes=float(n + 2 * n * (1 / 4 + 1 / 16 + 1 / 64 + 1 / 256 + 1 / 1024))))
+        if self.enc is not None:
+            convs = [c for c in self.enc.convs() if getattr(c, "last_call", None)]
+            rows.append(dict(name="single_image_part", flops=sum(c.flops() for c in convs), bytes=sum(c.last_call["bytes"] for c in convs), launches=len(convs) + 4))
         return rows, dict(flops=sum(r["flops"] for r in rows), bytes=sum(r["bytes"] for r in rows))
 
     @torch.no_grad()

@@ -143,7 +143,7 @@ def test_single_gpu_line_has_sub_records_and_names_the_dynamic_pair():
     pa = d["roofline_pair_alone"]                   # the same launch without the chain's kernels underneath it (render-only sub-record)
     assert "k_pair_overlap" in pa["kernel"] and 0.05 < pa["frac"] < 1.0 and pa["algorithmic_bytes_per_launch"] == rf["algorithmic_bytes_per_launch"]
     n1 = d["roofline_n1"]
-    assert "error" not in n1 and n1["launches"] == 21 and 0 < n1["hbm"]["frac"] < 1 and 0 < n1["mfma"]["frac"] < 1 and n1["ms_per_image"] > 0
+    assert "error" not in n1 and n1["launches"] == 21 + 28 and n1["encoder"] == "hip" and 0 < n1["hbm"]["frac"] < 1 and 0 < n1["mfma"]["frac"] < 1 and n1["ms_per_image"] > 0
     b5 = d["batch512"]
     assert b5["batch_images"] == 512 and b5["per_rank_pairs"] == [512] and b5["pairs_per_s"] > 0
     ac, sb = d["roofline_stage_ac"], d["roofline_stage_b"]

@@ -332,7 +332,8 @@ def test_engine_at_the_generator_size():
     # the work bench.py's roofline_n1 is quoted on: 20 convolution launches + the plane masks; ~4.1 TFLOP (the reference's convolutions on the
     # real channel counts) and ~12 GB (every layer's sources read once, its output written once) per image at this size
     rows, tot = hp.accounting()
-    assert len(rows) == 21 and [r["name"] for r in rows][:3] == ["l1p", "l2s", "l3"] and rows[-1]["name"] == "plane_masks"
+    assert len(rows) == 22 and [r["name"] for r in rows][:3] == ["l1p", "l2s", "l3"] and rows[-2]["name"] == "plane_masks"
+    assert rows[-1]["name"] == "single_image_part" and 3.5e10 < rows[-1]["flops"] < 3.9e10 and rows[-1]["launches"] == 28
     assert 3.5e12 < tot["flops"] < 4.6e12 and 9e9 < tot["bytes"] < 15e9, tot
     assert float((cum[-1] - 1).abs().max()) < 1e-5 and float(cum.min()) >= 0 and bool((cum[1:] >= cum[:-1] - 1e-6).all())
     with torch.no_grad():
@@ -349,8 +350,9 @@ def test_engine_at_the_generator_size():
 @pytest.mark.gpu
 def test_graph_replay_equals_eager():
     """One captured hipGraph per input size; replays with new inputs reproduce the eager run BIT FOR BIT - masks and raw output: the HIP
-    kernels are deterministic, and the batch-1 torch encoder runs with MIOpen's deterministic algorithms (its default choice differs by
-    1e-4 from run to run on the 1/32 feature map, which a random-weight decoder amplifies to ~1 % of the output range)."""
+    kernels are deterministic (the encoder's split-K sums have a fixed order; the torch encoder variant runs with MIOpen's deterministic
+    algorithms - its default choice differs by 1e-4 from run to run on the 1/32 feature map, which a random-weight decoder amplifies to ~1 %
+    of the output range)."""
     from mpiflow_amd.model.engine import HipPredictor
     dev = _gpu()
     S, H, W = 4, 128, 128

@@ -332,6 +332,9 @@ int mpf_moving_object_chain(const float *d_disp, const float *h_inv_k9, const fl
 #define MPF_CONV_EP_GATED_ELU        2   /* g = (accF + ep[0][rowF]) * sigmoid(accM + ep[0][rowM]); out f16 NHWC = elu(g * ep[1][rowF] + ep[2][rowF]) */
 #define MPF_CONV_EP_AFFINE_F32_NHWC  4   /* out f32 [S,Hout,Wout,Cst] = acc * ep[0][row] + ep[1][row], NO activation */
 #define MPF_CONV_EP_GATED_PLANAR_F32 3   /* out f32 [S,Cst,Hout,Wout] = g (no BatchNorm / activation: the decoder's raw output layer) */
+#define MPF_CONV_EP_GATED_ELU_PAIRED 6   /* EP_GATED_ELU with feature / gate rows interleaved (packed row 2c = feature c, 2c+1 = gate c; ep[1], ep[2] indexed by channel):
+                                           24 output channels in 3 blocks instead of 4 */
+#define MPF_CONV_EP_GATED_PLANAR_F32_PAIRED 5 /* the same from ONE 16-row block (nblk = 1, Cst <= 8): packed row 2c = feature c, row 2c+1 = gate c */
 
 typedef struct MpfConvArgs {
     const void *srcA, *srcB;          /* see the loader */

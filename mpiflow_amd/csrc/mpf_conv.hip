@@ -43,6 +43,8 @@ constexpr int EP_AFFINE_RELU = MPF_CONV_EP_AFFINE_RELU;
 constexpr int EP_AFFINE_RELU_F32 = MPF_CONV_EP_AFFINE_RELU_F32;
 constexpr int EP_GATED_ELU = MPF_CONV_EP_GATED_ELU;
 constexpr int EP_GATED_PLANAR_F32 = MPF_CONV_EP_GATED_PLANAR_F32;
+constexpr int EP_GATED_PLANAR_F32_PAIRED = MPF_CONV_EP_GATED_PLANAR_F32_PAIRED;
+constexpr int EP_GATED_ELU_PAIRED = MPF_CONV_EP_GATED_ELU_PAIRED;
 constexpr int EP_AFFINE_F32_NHWC = MPF_CONV_EP_AFFINE_F32_NHWC;
 
 __host__ __device__ constexpr int pix_stride_bytes(int CT, int ST)
@@ -56,7 +58,7 @@ __host__ __device__ constexpr int pix_stride_bytes(int CT, int ST)
 __host__ __device__ constexpr int lds_workgroups(int bytes) { return 163840 / ((bytes + 1279) / 1280 * 1280); }
 __host__ __device__ constexpr int ep_lds_floats(int EPI, int NB, int other_lds_bytes)
 {
-    const int n = EPI == EP_GATED_PLANAR_F32 ? 0 : (EPI == EP_GATED_ELU ? 2 * (NB / 2) * 16 : 2 * NB * 16);
+    const int n = (EPI == EP_GATED_PLANAR_F32 || EPI == EP_GATED_PLANAR_F32_PAIRED) ? 0 : EPI == EP_GATED_ELU_PAIRED ? 2 * NB * 8 : (EPI == EP_GATED_ELU ? 2 * (NB / 2) * 16 : 2 * NB * 16);
     return lds_workgroups(other_lds_bytes + n * 4) == lds_workgroups(other_lds_bytes) ? n : 0;
 }
 
@@ -269,8 +271,8 @@ void k_conv3x3(const MpfConvArgs a)
     // affine epilogues use rows 0, 1 of all NB blocks; the gated one rows 1, 2 of its NB/2 feature blocks; the planar one none.
     // One value per thread, loaded here (the round trip overlaps the staging set-up) and parked in LDS: in its own region where
     // that costs no resident workgroup (EPW > 0), else in the input tile's space once the last MFMA phase is over.
-    constexpr bool EP_GATED = EPI == EP_GATED_ELU || EPI == EP_GATED_PLANAR_F32;
-    constexpr int EPN = EPI == EP_GATED_PLANAR_F32 ? 0 : (EPI == EP_GATED_ELU ? (NB / 2) * 16 : NB * 16);
+    constexpr bool EP_GATED = EPI == EP_GATED_ELU || EPI == EP_GATED_PLANAR_F32 || EPI == EP_GATED_PLANAR_F32_PAIRED || EPI == EP_GATED_ELU_PAIRED;
+    constexpr int EPN = (EPI == EP_GATED_PLANAR_F32 || EPI == EP_GATED_PLANAR_F32_PAIRED) ? 0 : EPI == EP_GATED_ELU_PAIRED ? NB * 8 : (EPI == EP_GATED_ELU ? (NB / 2) * 16 : NB * 16);
     constexpr int EPW = ep_lds_floats(EPI, NB, TILE_BYTES + WL_BYTES + RAW_BYTES_) / 2;
     static_assert(2 * EPN <= 256 && 2 * EPN * 4 <= TILE_BYTES, "one epilogue value per thread");
     float epv = 0.f;
@@ -328,7 +330,7 @@ void k_conv3x3(const MpfConvArgs a)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI == EP_GATED_ELU || EPI == EP_GATED_PLANAR_F32) {
+        if constexpr (EP_GATED) {
             const float *bias = a.ep + (cg * NB + b) * 16 + 4 * q;
             init = f32x4{bias[0], bias[1], bias[2], bias[3]};
         }
@@ -651,6 +653,12 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     case 10000 + LD_DIRECT * 1000 + EP_GATED_ELU * 100 + 16:          return dispatch_nb<1, 16, LD_DIRECT, EP_GATED_ELU>(a, nb, st);
     case 10000 + LD_DIRECT * 1000 + EP_AFFINE_RELU * 100 + 16:        return dispatch_nb<1, 16, LD_DIRECT, EP_AFFINE_RELU>(a, nb, st);
     case 10000 + LD_DIRECT * 1000 + EP_GATED_PLANAR_F32 * 100 + 16:   return dispatch_nb<1, 16, LD_DIRECT, EP_GATED_PLANAR_F32>(a, nb, st);
+    case 10000 + LD_NEAREST_PLANE * 1000 + EP_GATED_ELU_PAIRED * 100 + 16:
+        return nb == 3 ? launch<1, 16, LD_NEAREST_PLANE, EP_GATED_ELU_PAIRED, 3, 8, 32>(a, st) : MPF_ERR_UNSUPPORTED;
+    case 10000 + LD_DIRECT * 1000 + EP_GATED_ELU_PAIRED * 100 + 16:
+        return nb == 3 ? launch<1, 16, LD_DIRECT, EP_GATED_ELU_PAIRED, 3, 8, 32>(a, st) : MPF_ERR_UNSUPPORTED;
+    case 10000 + LD_DIRECT * 1000 + EP_GATED_PLANAR_F32_PAIRED * 100 + 16:
+        return nb == 1 && a.Cst <= 8 ? launch<1, 16, LD_DIRECT, EP_GATED_PLANAR_F32_PAIRED, 1, 8, 32>(a, st) : MPF_ERR_UNSUPPORTED;
     }
     mpf_set_error("mpf_conv3x3_f16: combination loader=%d epilogue=%d ct=%d stride=%d is not built", a.loader, a.epi, a.ct, a.stride);
     return MPF_ERR_UNSUPPORTED;

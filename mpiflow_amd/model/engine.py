@@ -15,13 +15,14 @@ the reference model; this engine is the fast path of `gen_3dphoto_dynamic.py --m
 This module only PACKS parameters (host side, torch CPU) and sequences launches; all arithmetic is in the HIP kernels.
 """
 import ctypes
+import os
 
 import torch
 
 from .. import _lib
 
 LD_FMN_INPUT, LD_DIRECT, LD_BILINEAR_CAT, LD_NEAREST_PLANE, LD_FMN_SYNTH, LD_BILINEAR_SYNTH = 0, 1, 2, 3, 4, 5
-EP_AFFINE_RELU, EP_AFFINE_RELU_F32, EP_GATED_ELU, EP_GATED_PLANAR_F32, EP_AFFINE_F32_NHWC = 0, 1, 2, 3, 4
+EP_AFFINE_RELU, EP_AFFINE_RELU_F32, EP_GATED_ELU, EP_GATED_PLANAR_F32, EP_AFFINE_F32_NHWC, EP_GATED_PLANAR_F32_PAIRED, EP_GATED_ELU_PAIRED = 0, 1, 2, 3, 4, 5, 6
 
 
 def _ct(layer, default):
@@ -143,7 +144,23 @@ class ConvLayer:
         """GatedConv (+ BatchNorm + ELU when bn is given), reflection padding (model/CPN/decoder.py:10-71)."""
         cf, cmk = gconv.conv2d, gconv.mask_conv2d
         cout = cf.out_channels
+        if planar and bn is None and cout <= 8 and os.environ.get("MPIFLOW_DISP_PAIRED", "1") != "0":
+            # the 4-channel output layer: feature and gate rows interleaved in ONE 16-row block (row 2c / 2c + 1) instead of one block each
+            rows_w, ep = torch.zeros(16, cf.in_channels, 3, 3), torch.zeros(3, 16)
+            rows_w[0:2 * cout:2], rows_w[1:2 * cout:2] = cf.weight.detach().float().cpu(), cmk.weight.detach().float().cpu()
+            ep[0, 0:2 * cout:2], ep[0, 1:2 * cout:2] = cf.bias.detach().float().cpu(), cmk.bias.detach().float().cpu()
+            return cls(device, loader=loader, epi=EP_GATED_PLANAR_F32_PAIRED, stride=1, pad_mode=1, ct=ct, vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep,
+                       nblk=1, ncg=1, Cst=cout, CA=segments[0][0], CB=(segments[1][0] if len(segments) > 1 else 0), name=name)
         nf_total = (cout + 15) // 16
+        if not planar and bn is not None and (2 * cout + 15) // 16 == 3 and os.environ.get("MPIFLOW_GATED_PAIRED", "1") != "0":
+            # 24 output channels: feature / gate rows interleaved fill 3 blocks, the block-per-half layout needs 2 + 2 half-empty ones
+            rows_w, ep = torch.zeros(48, cf.in_channels, 3, 3), torch.zeros(3, 48)
+            rows_w[0:2 * cout:2], rows_w[1:2 * cout:2] = cf.weight.detach().float().cpu(), cmk.weight.detach().float().cpu()
+            ep[0, 0:2 * cout:2], ep[0, 1:2 * cout:2] = cf.bias.detach().float().cpu(), cmk.bias.detach().float().cpu()
+            scale, shift = _bn_affine(bn)
+            ep[1, :cout], ep[2, :cout] = scale.cpu(), shift.cpu()
+            return cls(device, loader=loader, epi=EP_GATED_ELU_PAIRED, stride=1, pad_mode=1, ct=ct, vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep,
+                       nblk=3, ncg=1, Cst=pad8(cout), CA=segments[0][0], CB=(segments[1][0] if len(segments) > 1 else 0), name=name)
         nf = max(d for d in (4, 3, 2, 1) if nf_total % d == 0)            # feature blocks per workgroup (NB = 2 nf in {2,4,6,8})
         ncg = nf_total // nf
         nblk = 2 * nf_total
@@ -178,7 +195,7 @@ class ConvLayer:
                 out = torch.empty(S, Hout, Wout, dtype=torch.float32, device=dev)
             elif self.epi == EP_AFFINE_F32_NHWC:
                 out = torch.empty(S, Hout, Wout, self.Cst, dtype=torch.float32, device=dev)
-            elif self.epi == EP_GATED_PLANAR_F32:
+            elif self.epi in (EP_GATED_PLANAR_F32, EP_GATED_PLANAR_F32_PAIRED):
                 out = torch.empty(S, self.Cst, Hout, Wout, dtype=torch.float32, device=dev)
             else:
                 out = torch.empty(S, Hout, Wout, self.Cst, dtype=torch.float16, device=dev)
@@ -229,7 +246,7 @@ def layer_accounting(layer):
         wr = S * Hout * Wout * 4
     elif layer.epi == EP_AFFINE_F32_NHWC:
         wr = S * Hout * Wout * layer.Cst * 4
-    elif layer.epi == EP_GATED_PLANAR_F32:
+    elif layer.epi in (EP_GATED_PLANAR_F32, EP_GATED_PLANAR_F32_PAIRED):
         wr = S * layer.Cst * Hout * Wout * 4
     else:
         wr = S * Hout * Wout * layer.Cst * 2

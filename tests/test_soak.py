@@ -44,6 +44,15 @@ def test_engine_first_layer_factorisation_soak():
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+def test_encoder_kernels_soak():
+    """tools/soak_encoder.py: the fp32 single-image convolution / max-pool kernels on random shapes (kernel 1 / 3 / 7, strides, paddings, x2 nearest
+    in front, residual, activations, partial tiles, both split-K variants) and the whole encoder at random sizes, against torch in fp64."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_encoder.py"), "40", "2"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_pair_vs_oracle_soak(oracle):
     """The fused pair against the CPU oracle (kernel-exp mode: same IEEE op sequence) on random small problems: every plane count from 1 to 40,
     frames from one pixel to 60 x 90, random stacks / images / soft masks, poses from the reference sampler's range up to 6 x beyond it (planes

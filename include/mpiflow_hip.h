@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define MPF_VERSION 301   /* round 3: + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered */
+#define MPF_VERSION 401   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
+                             round 4 (401): + mpf_moving_object_chain, mpf_warp_views_blend_next_merge_prev, mpf_stream_create_cu_subset / _destroy,
+                             mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6 */
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)

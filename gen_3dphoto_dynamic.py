@@ -92,8 +92,8 @@ def parse(argv=None):
                         "between 2 and 32 - the ranks of a node share its host cores")
     p.add_argument("--lanes", type=int, default=1,
                    help="images in flight on this GPU, each with its own streams, plane-stack buffer and network graph (same files for any "
-                        "value).  Measured on MI355X: 1 lane 359 pairs/s, 2 lanes 267, 3 lanes 298 - the kernels are sized to fill the GPU on "
-                        "their own, concurrent images only fight over the caches")
+                        "value).  Measured on MI355X (round 4, 64 images x 5 pairs, same box): 1 lane 417 - 426 pairs/s, 2 lanes 419 - 426, 3 lanes "
+                        "415 - every kernel is sized to fill the GPU on its own, a second image in flight finds nothing left to use")
     opt, _ = p.parse_known_args(argv)
     return opt
 

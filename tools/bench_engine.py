@@ -49,7 +49,7 @@ for lst in times.values():
     L, (s, hin, win) = lst[0][2], lst[0][3]
     hout, wout = (hin - 1) // L.stride + 1, (win - 1) // L.stride + 1
     flops = 2.0 * s * hout * wout * L.nblk * 16 * L.nchunk * E.ksteps(L.ct) * 32
-    outb = s * hout * wout * (L.Cst * 2 if L.epi in (0, 2) else 4 * L.Cst)
+    outb = s * hout * wout * (L.Cst * 2 if L.epi in (0, 2, 6) else 4 * L.Cst)      # fp16 NHWC epilogues (affine, gated, gated interleaved) / fp32 ones
     tot += t
     print("%-6d %-4d %-3d %-5d %-14s %9.3f %9.1f %9.1f  %s (%d, %s)" % (L.loader, L.epi, L.ct, L.nblk, "%d,%d,%d" % (s, hin, win), t, flops / t / 1e9, outb / t / 1e6,
                                                                     L.name, L.nblk // L.ncg, "lds" if E._wlds(L.name, L.wlds_default) else "per wave"))

@@ -162,6 +162,13 @@ class ConvLayer:
             return cls(device, loader=loader, epi=EP_GATED_ELU_PAIRED, stride=1, pad_mode=1, ct=ct, vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep,
                        nblk=3, ncg=1, Cst=pad8(cout), CA=segments[0][0], CB=(segments[1][0] if len(segments) > 1 else 0), name=name)
         nf = max(d for d in (4, 3, 2, 1) if nf_total % d == 0)            # feature blocks per workgroup (NB = 2 nf in {2,4,6,8})
+        if nf == 4:
+            # the 8-block kernels hold 128 accumulator + 158 other registers: ONE wave per SIMD, nothing to hide a load behind.  With 4 blocks
+            # (3 waves per SIMD) the 192-channel layers run 0.25 -> 0.215 ms (up0_4) and 0.48 -> 0.42 ms (up1_4) at 64 x 384 x 1280
+            nf = 2
+        for item in os.environ.get("MPIFLOW_NF", "").split(","):          # tuning aid: MPIFLOW_NF="up0_4=2,up1_4=3"
+            if item.partition("=")[0].strip() == name and nf_total % int(item.partition("=")[2]) == 0:
+                nf = int(item.partition("=")[2])
         ncg = nf_total // nf
         nblk = 2 * nf_total
         rows_w = torch.zeros(nblk * 16, cf.in_channels, 3, 3)

@@ -132,6 +132,12 @@ class ConvLayer:
         ep[0, :cout] = scale.cpu()
         ep[1, :cout] = (shift + conv.bias.detach().float() * scale).cpu()
         nb = nblk if nblk <= 8 else 8
+        if nb == 8 and stride == 1:
+            nb = 4              # l5: the stride-1 8-block kernel runs ONE wave per SIMD (128 accumulator registers); 4 blocks: 0.21 -> 0.17 ms.
+                                # (the stride-2 l4 is the other way round: 0.20 ms with 8 blocks, 0.27 with 4)
+        for item in os.environ.get("MPIFLOW_NB", "").split(","):          # tuning aid: MPIFLOW_NB="l4=4,l5=4"
+            if item.partition("=")[0].strip() == name and nblk % int(item.partition("=")[2]) == 0:
+                nb = int(item.partition("=")[2])
         assert nblk % nb == 0
         CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
         epi = EP_AFFINE_F32_NHWC if pre_activation else (EP_AFFINE_RELU_F32 if f32_out else EP_AFFINE_RELU)

@@ -37,10 +37,6 @@ _T_PROCESS = time.perf_counter()                  # start-up is reported from he
 # dmabuf IPC (the only mode this node pool's driver supports) for RCCL's peer-memory exchange between the per-GPU processes;
 # already exported by the launch environment, set here for a bare `torchrun gen_3dphoto_dynamic.py`
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# MIOpen in its immediate mode - only the --model-engine torch path (and MPIFLOW_ENCODER=torch) still reaches MIOpen; the default hip engine runs
-# the whole network on this repo's kernels.  On a box whose MIOpen user cache is empty the default find mode spends 2.9-3.3 s searching /
-# compiling in the FIRST forward, the immediate mode 0.3 s (tools/miopen_cold_start.py, profiles/r4/generator_startup.txt).  Set it yourself to override.
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import numpy as np
 import torch
@@ -70,7 +66,11 @@ def parse(argv=None):
     p.add_argument("--mpi-from", choices=["model", "npz", "disparity"], default="model",
                    help="model: the AdaMPI network from --ckpt_path, as the reference always does; npz: precomputed stacks base/mpis/NAME.npz; "
                         "disparity: a hard-assignment stand-in built from the disparity map (NOT the reference's producer - for smoke runs)")
-    p.add_argument("--model-dtype", choices=["fp32", "fp16", "bf16"], default="fp32", help="autocast dtype of the network's convolutions")
+    p.add_argument("--model-dtype", choices=["auto", "fp16", "bf16", "fp32", "fp64"], default="auto",
+                   help="arithmetic of the network.  --model-engine hip: auto | fp16 = the fast engine (fp16 storage, fp32 accumulate, 7.7 ms per image); fp32 = the "
+                        "PARITY-GRADE engine, every convolution on mpf_pconv in the arithmetic of the reference's CPU path (fp32 storage / products / accumulation on "
+                        "v_mfma_f32_16x16x4_f32); fp64 = the same kernels in double (equals the torch modules run in double to 1e-10).  --model-engine torch: "
+                        "auto | fp32 = plain fp32, fp16 | bf16 = torch autocast")
     p.add_argument("--model-engine", choices=["hip", "torch"], default="hip",
                    help="hip (default): the whole network on this repo's HIP kernels - the per-plane feature-mask UNet and gated decoder (> 98 %% of "
                         "the flops) on the fp16 MFMA convolution engine (fp16 storage, fp32 accumulate: the precision of the reference's own GPU run, which "
@@ -141,6 +141,12 @@ def main(argv=None):
     opt = parse(argv)
     if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(opt, argv)
+    if opt.model_engine == "torch" or os.environ.get("MPIFLOW_ENCODER") == "torch":
+        # MIOpen in its immediate mode, ONLY for the paths that reach MIOpen (the hip engines run the whole network on this repo's kernels): on a
+        # box whose MIOpen user cache is empty the default find mode spends 2.9-3.3 s searching / compiling in the FIRST forward, the immediate
+        # mode 0.3 s (tools/miopen_cold_start.py, profiles/r4/generator_startup.txt).  Read by MIOpen at its first convolution; set it yourself
+        # to override.  (The fp32 "reference numerics" producer is --model-engine hip --model-dtype fp32, which never touches MIOpen.)
+        os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -188,7 +194,12 @@ def main(argv=None):
     img_base, disp_base, mask_base = (os.path.join(opt.base, d) for d in ("images", "disps", "masks"))
     names = sorted(os.listdir(img_base))
     model = None
-    amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype)
+    amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype) if opt.model_engine == "torch" else None
+    if opt.model_engine == "hip" and opt.model_dtype == "bf16":
+        raise SystemExit("gen_3dphoto_dynamic: --model-engine hip computes in fp16 (auto), fp32 or fp64; bf16 is a torch autocast dtype (--model-engine torch)")
+    if opt.model_engine == "torch" and opt.model_dtype == "fp64":
+        raise SystemExit("gen_3dphoto_dynamic: --model-dtype fp64 is the HIP precise engine's (--model-engine hip)")
+    precise_dtype = {"fp32": torch.float32, "fp64": torch.float64}.get(opt.model_dtype) if opt.model_engine == "hip" else None
     if opt.mpi_from == "model":                                            # the reference's only producer (:52-60, :92-93)
         from mpiflow_amd.model import MPIPredictor
         if opt.ckpt_path.startswith("random:"):
@@ -231,9 +242,12 @@ def main(argv=None):
                 self.fill_ws = torch.empty(int(_lib.load().mpf_fill_holes_workspace(opt.height, opt.width)), dtype=torch.uint8, device=dev)
                 self.inputs = dict(image=torch.empty((3, opt.height, opt.width), device=dev), disp=torch.empty((opt.height, opt.width), device=dev))
                 self.hip_model = None
-                if use_hip_model:
+                if use_hip_model and precise_dtype is not None:
+                    from mpiflow_amd.model.precise import PrecisePredictor
+                    self.hip_model = PrecisePredictor(model, dtype=precise_dtype)      # the accuracy mode: fp32 / fp64 on mpf_pconv
+                elif use_hip_model:
                     from mpiflow_amd.model.engine import HipPredictor
-                    self.hip_model = HipPredictor(model, encoder_dtype=amp, graph=True)
+                    self.hip_model = HipPredictor(model, graph=True)
             self.tail_stream.wait_stream(self.stream)
 
     lanes = [Lane() for _ in range(max(1, opt.lanes))]

@@ -31,9 +31,11 @@
 extern "C" {
 #endif
 
-#define MPF_VERSION 401   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
+#define MPF_VERSION 501   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
                              round 4 (401): + mpf_moving_object_chain, mpf_warp_views_blend_next_merge_prev, mpf_stream_create_cu_subset / _destroy,
-                             mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6 */
+                             mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6;
+                             round 5 (501): + the parity-grade producer engine mpf_pconv, mpf_pfmn_input, mpf_pencoder_input, mpf_pbilinear2x, mpf_pper_plane,
+                             mpf_pplane_masks, mpf_pmaxpool3x3s2 */
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)
@@ -400,6 +402,60 @@ int mpf_conv2d_f32(const MpfConv2dArgs *args, void *stream);
 
 /* nn.MaxPool2d(3, stride 2, padding 1) on an NHWC fp32 image: [Hin,Win,C] -> [(Hin-1)/2+1, (Win-1)/2+1, C]; C a multiple of 4 */
 int mpf_maxpool3x3s2_f32(const float *d_src_HWC, int Hin, int Win, int C, float *d_out, void *stream);
+
+/* ---- the producer network's PARITY-GRADE engine: fp32 or fp64 throughout (mpiflow_amd/csrc/mpf_pconv.hip) -------------------------
+ * Every convolution of MPIPredictor.forward (model/AdaMPI.py:55-78) in the arithmetic of the reference's CPU path: fp32 storage, fp32
+ * products, fp32 accumulation (v_mfma_f32_16x16x4_f32), or fp64 throughout (v_mfma_f64_16x16x4_f64) - `dtype` selects.  Activations are
+ * NHWC tensors of `dtype` with the channel count zero-padded to a multiple of 4; the accuracy mode behind
+ * `gen_3dphoto_dynamic.py --model-engine hip --model-dtype fp32|fp64` (mpiflow_amd/model/precise.py: PrecisePredictor). */
+#define MPF_DTYPE_F32 0
+#define MPF_DTYPE_F64 1
+#define MPF_PCONV_EP_AFFINE       0   /* out [S,Hout,Wout,Cst] = act(acc * scale[row] + shift[row] (+ residual))   (ConvBNReLU model/CPN/unet.py:6-15; the encoder's conv + BN) */
+#define MPF_PCONV_EP_AFFINE_MAP   1   /* same, row 0 only, out [S,Hout,Wout]   (the feature-mask logits, model/CPN/unet.py:66) */
+#define MPF_PCONV_EP_GATED        2   /* g = accF * sigmoid(accM) (biases = initial accumulators); out NHWC = elu(g * scale[c] + shift[c])   (model/CPN/decoder.py:10-71) */
+#define MPF_PCONV_EP_GATED_PLANAR 3   /* out [S,Cst,Hout,Wout] = g   (the decoder's raw output layer, model/CPN/decoder.py:164-165) */
+
+/* One convolution over S plane-images (or one image, S = 1):  input = cat(A', B) along channels, A' = srcA or its x2 nearest up-sampling
+ * (up = 1; HA = Hin / 2), zero or reflection padding, ksize 1 | 3 | 7, stride 1 | 2.
+ * wpack: [nblk][nsteps][64 lanes][4] of dtype, nsteps = ceil(ksize^2 * (CA+CB)/4 / 4): lane (m = l % 16, g = l / 16) of step s holds, for
+ *   j = 0..3, W[physical row 16 blk + m][virtual channel 4 (v % V) + j][tap v / V] with v = 4 s + g, V = (CA+CB)/4, zero past the last tap.
+ *   LOGICAL row L of a block (what the epilogue rows are indexed by) sits at physical row L for fp32 and at (L >> 2) + 4 (L & 3) for fp64
+ *   (the C/D register layouts of the two MFMA instructions differ).  Gated epilogues: logical rows (2c, 2c+1) of the packed row sequence
+ *   = (feature, gate) of channel c; bias [nblk*16] by logical row; scale / shift [nblk*8] by channel.  Affine epilogues: scale / shift
+ *   [nblk*16] by logical row (conv bias folded into shift). */
+typedef struct MpfPConvArgs {
+    const void *srcA;                 /* dtype [S (or 1 when shareA), HA, WA, CA] */
+    const void *srcB;                 /* dtype [S (or 1 when shareB), Hin, Win, CB] or NULL (CB = 0) */
+    const void *wpack;
+    const void *scale, *shift;        /* dtype, see above */
+    const void *bias;                 /* dtype [nblk*16], gated epilogues only */
+    const void *residual;             /* dtype [S,Hout,Wout,Cst] or NULL (EP_AFFINE) */
+    void *out;
+    int dtype;                        /* MPF_DTYPE_F32 | MPF_DTYPE_F64 */
+    int S, Hin, Win, Hout, Wout;      /* Hin x Win: the virtual conv input (after up-sampling) */
+    int HA, WA, CA, CB;
+    int up, shareA, shareB;
+    int ksize, stride, pad, pad_mode; /* pad_mode 0 zero, 1 reflection (pad 1) */
+    int nblk, Cst, epi, act;          /* act: 0 none, 1 ReLU, 2 LeakyReLU(slope) (affine epilogues) */
+    double slope;                     /* rounded to `dtype` by the kernel, as torch rounds the Python float to the tensor's dtype */
+} MpfPConvArgs;
+int mpf_pconv(const MpfPConvArgs *args, void *stream);
+
+/* the tensors the reference builds with expand / cat / Upsample / adaptive_avg_pool2d, materialised in `dtype`:
+ * mpf_pfmn_input      cat(image, disparity, plane disparity) per plane (model/CPN/unet.py:44-50) -> [S,H,W,8] (channels 5..7 zero)
+ * mpf_pencoder_input  cat((image - mean) / std, disparity) (model/CPN/encoder.py:84-85,89-93) -> [H,W,4]
+ * mpf_pbilinear2x     nn.Upsample(x2, bilinear, align_corners=True) (model/CPN/unet.py:42): [S,h,w,C] -> [S,2h,2w,C]
+ * mpf_pper_plane      cat(feat * context_mask, context_mask, feature_mask) (model/CPN/decoder.py:140-150): feat [h,w,C], masks [S,h,w] -> [S,h,w,C+4]
+ * mpf_pplane_masks    softmax over the planes (model/CPN/unet.py:68-69), cumulative / context masks (model/CPN/decoder.py:126-130) and their
+ *                     k x k block means for k = 2..32 (adaptive_avg_pool2d, :143-146); d_cm / d_fm are HOST arrays of 5 device pointers
+ * mpf_pmaxpool3x3s2   nn.MaxPool2d(3, 2, 1) on [Hin,Win,C] */
+int mpf_pfmn_input(const float *d_image_3HW, const float *d_disp_HW, const float *d_plane_vals, int S, int H, int W, void *d_out, int dtype, void *stream);
+int mpf_pencoder_input(const float *d_image_3HW, const float *d_disp_HW, int H, int W, void *d_out, int dtype, void *stream);
+int mpf_pbilinear2x(const void *d_src, int S, int h, int w, int C, void *d_dst, int dtype, void *stream);
+int mpf_pper_plane(const void *d_feat_hwC, const void *d_cm, const void *d_fm, int S, int h, int w, int C, void *d_out, int dtype, void *stream);
+int mpf_pplane_masks(const void *d_logits, int S, int H, int W, void *d_feature_mask, void *d_cum_mask, void *d_context_mask, void *const *d_cm,
+                     void *const *d_fm, int dtype, void *stream);
+int mpf_pmaxpool3x3s2(const void *d_src_HWC, int Hin, int Win, int C, void *d_out, int dtype, void *stream);
 
 /* THE REFERENCE'S FFI SYMBOL (external/forward_warping/warping.c:6; bound at moving_obj.py:12-13, called at :127-129).
  * Same name, same argument meaning, HOST pointers: src u8 [h*w*3], idx/idy int64 [h*w] (pre-clamped by the caller, as

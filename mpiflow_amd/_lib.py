@@ -43,6 +43,14 @@ class MpfConv2dArgs(ctypes.Structure):
                 ("ksize", c_i), ("stride", c_i), ("pad", c_i), ("up", c_i), ("act", c_i), ("slope", c_f)]
 
 
+class MpfPConvArgs(ctypes.Structure):
+    """struct MpfPConvArgs of include/mpiflow_hip.h: one convolution of the parity-grade (fp32 / fp64) producer engine."""
+    _fields_ = [("srcA", c_p), ("srcB", c_p), ("wpack", c_p), ("scale", c_p), ("shift", c_p), ("bias", c_p), ("residual", c_p), ("out", c_p),
+                ("dtype", c_i), ("S", c_i), ("Hin", c_i), ("Win", c_i), ("Hout", c_i), ("Wout", c_i),
+                ("HA", c_i), ("WA", c_i), ("CA", c_i), ("CB", c_i), ("up", c_i), ("shareA", c_i), ("shareB", c_i),
+                ("ksize", c_i), ("stride", c_i), ("pad", c_i), ("pad_mode", c_i), ("nblk", c_i), ("Cst", c_i), ("epi", c_i), ("act", c_i), ("slope", ctypes.c_double)]
+
+
 class MpfWarpView(ctypes.Structure):
     """struct MpfWarpView of include/mpiflow_hip.h: one view of mpf_warp_composite_views (device pointers)."""
     _fields_ = [("d_params", c_p), ("d_mask_quads", c_p), ("d_rgb", c_p), ("d_depth", c_p), ("d_objmask", c_p),
@@ -114,6 +122,13 @@ SIGNATURES = {
     "mpf_encoder_input": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "mpf_conv2d_f32": (c_i, [ctypes.POINTER(MpfConv2dArgs), c_p]),
     "mpf_maxpool3x3s2_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "mpf_pconv": (c_i, [ctypes.POINTER(MpfPConvArgs), c_p]),
+    "mpf_pfmn_input": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "mpf_pencoder_input": (c_i, [c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "mpf_pbilinear2x": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "mpf_pper_plane": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "mpf_pplane_masks": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_i, c_p]),
+    "mpf_pmaxpool3x3s2": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
 }
 
 

@@ -500,7 +500,7 @@ def generator_record(n_images=64, repeat=5, timeout=600):
                "producer_precision": "HIP engine: fp16 storage, fp16 MFMA, fp32 accumulate and epilogue - the precision of the reference's own GPU run (.half(), "
                                      "gen_3dphoto_dynamic_v2.py:46,59,82-84), NOT the fp32 CPU parity target of the render path; its error against the fp32 model "
                                      "(random weights) is bounded by tests/test_conv_engine.py ENGINE_BARS, e.g. mean |sigmoid(rgb)| 3.2e-3 at this size "
-                                     "(torch fp16 autocast: 1.2e-2); --model-engine torch --model-dtype fp32 runs the fp32 mirror",
+                                     "(torch fp16 autocast: 1.2e-2); --model-engine hip --model-dtype fp32 runs the parity-grade engine (roofline_n1.precise)",
                "pairs": n_images * repeat, "flo_files_written": n_files, "process_seconds": dt,
                "pairs_per_s_whole_process": n_images * repeat / dt, "summary_line": summary[-1] if summary else None}
         if startup:
@@ -548,7 +548,33 @@ def n1_record(dev, S=64, H=384, W=1280, iters=10):
            "hbm": {"bound": "hbm", "achieved": tot["bytes"] / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": tot["bytes"] / t / HBM_PEAK},
            "mfma": {"bound": "mfma", "achieved": tot["flops"] / t / 1e12, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": tot["flops"] / t / MFMA_F16_PEAK},
            "layers": [{"name": r["name"], "GB": r["bytes"] / 1e9, "GFLOP": r["flops"] / 1e9} for r in rows]}
-    del hp, m
+    del hp
+    torch.cuda.empty_cache()
+    # the PARITY-GRADE modes of the same network (mpiflow_amd.model.precise.PrecisePredictor: every convolution on mpf_pconv, fp32 with fp64 carries
+    # or fp64 throughout; materialised fp32 / fp64 NHWC activations; eager launches).  Rooflines: the dense fp32 / fp64 MFMA rates (157 / 79 TFLOP/s).
+    from mpiflow_amd.model.precise import PrecisePredictor
+    rec["precise"] = {}
+    for name, dt, peak in (("fp32", torch.float32, 157.3e12), ("fp64", torch.float64, 78.6e12)):
+        try:
+            pp = PrecisePredictor(m, dtype=dt)
+            pp(img, dsp)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(2):
+                pp(img, dsp)
+            e1.record()
+            torch.cuda.synchronize()
+            tp = e0.elapsed_time(e1) / 2 * 1e-3
+            _, ptot = pp.accounting()
+            rec["precise"][name] = {"workload": "the same image on the parity-grade engine, %s (tests/test_precise_engine.py: fp64 = the torch modules in double to 1e-10; fp32 closer to "
+                                                "them than torch's own fp32)" % name, "ms_per_image": tp * 1e3, "launches": len(pp.layers()) + 20,
+                                    "algorithmic_flops_per_image": ptot["flops"], "materialised_bytes_per_image": ptot["bytes"],
+                                    "mfma": {"bound": "mfma", "achieved": ptot["flops"] / tp / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ptot["flops"] / tp / peak}}
+            del pp
+        except Exception as e:                                                   # noqa: BLE001
+            rec["precise"][name] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+    del m
     torch.cuda.empty_cache()
     return rec
 

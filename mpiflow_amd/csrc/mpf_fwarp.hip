@@ -18,6 +18,12 @@
 //     workgroup per bucket of 2^lb consecutive targets finishes the sort in LDS and resolves its targets (k_fw_bucket): no
 //     second histogram / scan / scatter, no global winner array, no separate fill, mark and write launches;
 //   * larger images: the general path - two or three passes with 8..11-bit digits, mark, write.
+// Round 5 (5 launches -> 3 for the moving-object chain, no workgroup barrier left in the splat): the sort became a GATHER.  Targets come from a
+// projection of raster-ordered sources, so the visitors of 256 consecutive targets sit in a handful of 64-source slabs; pass 1 records the
+// [min, max] target of every slab and of every 1024-source tile beside the keys, and ONE WAVE per bucket of 256 targets collects its visitors
+// from the slabs whose range touches the bucket - in raster order, so stability is free -, counting-sorts them by target in LDS and resolves
+// them (k_fw_gather_resolve).  No histogram table, no column scan, no scatter, no second key / value arrays; pile-ups of any size are
+// streamed through the wave's LDS in chunks that carry (last z, winner, collision) per target.  The round-2 path stays as fwarp_path 2.
 // Integer/byte work, bandwidth-trivial (N = h*w <= a few million 4-byte keys, 2-3 radix passes): the design goal is
 // bit-exact equality with the serial C, with bounded cost for pathological pile-ups (thousands of sources clamped onto
 // one border pixel), which is what the global sort buys over per-target lists.
@@ -120,16 +126,24 @@ MPF_DEV void mpf_project_point(const float *P, float X, float Y, float Z, int H,
 // units, truncation + clamp, flow.  Shared by the stand-alone kernel and by the chain's fused first sort pass (same IEEE op sequence).
 struct MpfMoOut { float *p1, *z1; int64_t *safe_x, *safe_y; float *flow01; };
 
+MPF_DEV uint32_t mpf_mo_pixel_v(const float disp_n, const MpfMoProj &m, const float inst_n, int H, int W, const int64_t n, const MpfMoOut &o);
+
 MPF_DEV uint32_t mpf_mo_pixel(const float *__restrict__ disp, const MpfMoProj &m, const float *__restrict__ inst, int H, int W, const int64_t n,
                               const MpfMoOut &o)
 {
+    return mpf_mo_pixel_v(disp[n], m, inst[n], H, W, n, o);
+}
+
+// the same with the two inputs of pixel n already loaded (pass 1 of the gather path loads its four pixels' inputs before the first store)
+MPF_DEV uint32_t mpf_mo_pixel_v(const float disp_n, const MpfMoProj &m, const float inst_n, int H, int W, const int64_t n, const MpfMoOut &o)
+{
     const float fx = (float)(n % W), fy = (float)(n / W);
-    float dep = 1.0f / (disp[n] + 0.005f);                              // moving_obj.py:29-30
+    float dep = 1.0f / (disp_n + 0.005f);                               // moving_obj.py:29-30
     dep = (dep > 100.0f) ? 100.0f : dep;
     float cam[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) cam[c] = dep * mpf_row3_xy1(m.ik[3 * c], m.ik[3 * c + 1], m.ik[3 * c + 2], fx, fy);   // geometry.py:42-43
-    const bool sel = inst[n] > 0.0f;                                    // moving_obj.py:108-112
+    const bool sel = inst_n > 0.0f;                                     // moving_obj.py:108-112
     float nx, ny, z;
     if (sel) mpf_project_point(m.Po, cam[0], cam[1], cam[2], H, W, nx, ny, z);
     else     mpf_project_point(m.Ps, cam[0], cam[1], cam[2], H, W, nx, ny, z);
@@ -565,6 +579,314 @@ k_fw_bucket(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ v
     }
 }
 
+// ---- round 5: gather instead of sort ----------------------------------------------------------------------------------------------
+#define FWG_TILE 1024             // sources per tile of pass 1 (one 256-thread workgroup, 4 per thread) = 16 slabs of 64
+#define FWG_LB 8                  // a bucket = 256 consecutive targets, resolved by one wave
+#define FWG_CAP 512               // visitors a wave keeps in LDS per chunk; a bucket with more is streamed through in chunks
+
+MPF_DEV uint32_t fwg_wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+MPF_DEV uint32_t fwg_wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+
+// Pass 1: the key (target) of every source - computed by the projection of moving_obj.py:29-124 (PROJ) or from the caller's idx / idy -, and the
+// [min, max] key of every 64-source slab and every 1024-source tile.  Slabs / tiles beyond N get the empty range [0xFFFFFFFF, 0].
+template <bool PROJ>
+__global__ void __launch_bounds__(256)
+k_fw_keys_ranges(const float *__restrict__ disp, const MpfMoProj m, const float *__restrict__ inst, const MpfMoOut o, const int64_t *__restrict__ idx,
+                 const int64_t *__restrict__ idy, int h, int w, uint32_t N, uint32_t ntiles, uint32_t *__restrict__ keys, uint32_t *__restrict__ slab_min,
+                 uint32_t *__restrict__ slab_max, uint32_t *__restrict__ tile_min, uint32_t *__restrict__ tile_max)
+{
+    __shared__ uint32_t red[4][2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t tmin = 0xFFFFFFFFu, tmax = 0u;
+        // the four pixels' inputs first: the outputs are plain (possibly aliasing) pointers, so a load behind a store would wait for it
+        float dv[4], iv[4];
+        int64_t xv[4], yv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t n = tile * FWG_TILE + it * 256 + tid;
+            const uint32_t nc = n < N ? n : N - 1;
+            if constexpr (PROJ) { dv[it] = disp[nc]; iv[it] = inst[nc]; }
+            else { xv[it] = idx[nc]; yv[it] = idy[nc]; }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t n = tile * FWG_TILE + it * 256 + tid;
+            uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+            if (n < N) {
+                uint32_t key;
+                if constexpr (PROJ) {
+                    key = mpf_mo_pixel_v(dv[it], m, iv[it], h, w, (int64_t)n, o);
+                } else {
+                    int64_t x = xv[it], y = yv[it];
+                    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);                      // the reference does no bounds check (the caller pre-clamps, moving_obj.py:121-122)
+                    y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+                    key = (uint32_t)(y * w + x);
+                }
+                keys[n] = key;
+                kmin = kmax = key;
+            }
+            kmin = fwg_wave_min(kmin);
+            kmax = fwg_wave_max(kmax);
+            if (lane == 0) {
+                const uint32_t slab = tile * 16 + it * 4 + wave;
+                slab_min[slab] = kmin;
+                slab_max[slab] = kmax;
+            }
+            tmin = kmin < tmin ? kmin : tmin;
+            tmax = kmax > tmax ? kmax : tmax;
+        }
+        if (lane == 0) { red[wave][0] = tmin; red[wave][1] = tmax; }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t a = red[0][0], b = red[0][1];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) { a = red[k][0] < a ? red[k][0] : a; b = red[k][1] > b ? red[k][1] : b; }
+            tile_min[tile] = a;
+            tile_max[tile] = b;
+        }
+        __syncthreads();
+    }
+}
+
+// Pass 2: ONE WAVE per bucket of 256 consecutive targets (a 64-thread workgroup: __syncthreads() is a wait for the wave's own LDS traffic, not a
+// barrier).  (1) the tiles, then the slabs, whose key range touches the bucket; (2) their keys, 64 at a time in raster order: the matching
+// lanes append (source index, target, z) to the chunk; (3) per chunk: count per target, scan, stable placement by target (ballot ranking),
+// then per sorted slot "z < z of the previous visitor of the same target" - the previous visitor of a chunk's first slot of a target is the
+// carried last z (1000 for a target nobody visited yet: dlut, warping.c:11) -, the last such slot per target (LDS atomicMax) becomes the
+// target's winner so far, the last slot of every target updates its carried z and its collision flag (warping.c:24-27);  (4) the 5 output
+// bytes of every target of the bucket (warping.c:13-29), and on request the planes H = valid, M = 1 - (collision == valid)
+// (moving_obj.py:133-142) the mask kernel would otherwise re-read from the 5-byte records.
+__global__ void __launch_bounds__(64)
+k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ slab_min, const uint32_t *__restrict__ slab_max,
+                    const uint32_t *__restrict__ tile_min, const uint32_t *__restrict__ tile_max, uint32_t N, uint32_t ntiles, const float *__restrict__ z,
+                    const uint8_t *__restrict__ src, const float *__restrict__ src_f, uint8_t *__restrict__ warped, int zero_fill,
+                    uint8_t *__restrict__ Hm, uint8_t *__restrict__ Mm)
+{
+    constexpr int NT = 1 << FWG_LB;
+    __shared__ uint32_t g_src[FWG_CAP], g_tl[FWG_CAP];      // gathered, raster order
+    __shared__ float g_z[FWG_CAP];
+    __shared__ uint32_t s_src[FWG_CAP], s_tl[FWG_CAP];      // sorted by (target, raster index)
+    __shared__ float s_z[FWG_CAP];
+    __shared__ uint32_t hc[NT], cur[NT], winslot[NT], winsrc[NT], state[NT];
+    __shared__ float zlast[NT];
+    __shared__ uint32_t clist[512];                         // candidate tiles of one batch of the tile table (ordered)
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t nbuckets = (N + NT - 1) >> FWG_LB;
+
+    // one chunk of `cnt` gathered visitors -> the carried per-target state
+    auto process = [&](const uint32_t cnt) {
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) hc[lane + 64 * k] = 0;
+        __syncthreads();
+        for (uint32_t j = lane; j < cnt; j += 64) atomicAdd(&hc[g_tl[j]], 1u);
+        __syncthreads();
+        {   // exclusive scan: lane l owns targets 4l .. 4l+3
+            uint32_t v[NT / 64], sum = 0;
+#pragma unroll
+            for (int k = 0; k < NT / 64; ++k) { v[k] = hc[lane * (NT / 64) + k]; sum += v[k]; }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off);
+                if (lane >= (uint32_t)off) inc += o;
+            }
+            uint32_t base = inc - sum;
+#pragma unroll
+            for (int k = 0; k < NT / 64; ++k) { cur[lane * (NT / 64) + k] = base; base += v[k]; }
+        }
+        __syncthreads();
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {           // stable placement, 64 visitors (in raster order) per round
+            const uint32_t j = j0 + lane;
+            const bool valid = j < cnt;
+            const uint32_t d = valid ? g_tl[j] : 0u;
+            unsigned long long mask = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < FWG_LB; ++bit) {
+                const bool on = (d >> bit) & 1;
+                const unsigned long long bal = __ballot(on);
+                mask &= on ? bal : ~bal;
+            }
+            const uint32_t rank = __popcll(mask & lt);
+            if (valid) {
+                const uint32_t pos = cur[d] + rank;
+                s_src[pos] = g_src[j]; s_tl[pos] = d; s_z[pos] = g_z[j];
+            }
+            __syncthreads();
+            if (valid && rank == 0) cur[d] += __popcll(mask);
+            __syncthreads();
+        }
+        for (uint32_t j = lane; j < cnt; j += 64) {           // z test against the previous visitor of the same target
+            const uint32_t t = s_tl[j];
+            const bool has_pred = (j > 0) && (s_tl[j - 1] == t);
+            const float zprev = has_pred ? s_z[j - 1] : zlast[t];
+            if (s_z[j] < zprev) atomicMax(&winslot[t], j + 1);                    // warping.c:19
+        }
+        __syncthreads();
+        for (uint32_t j = lane; j < cnt; j += 64) {           // the last visitor of every target in this chunk carries the state on
+            const uint32_t t = s_tl[j];
+            if (j + 1 < cnt && s_tl[j + 1] == t) continue;
+            const bool has_pred = (j > 0) && (s_tl[j - 1] == t);
+            const float zprev = has_pred ? s_z[j - 1] : zlast[t];
+            state[t] = 1u | ((zprev == 1000.0f) ? 2u : 0u);                         // visited | collision byte (warping.c:24-27)
+            const uint32_t wj = winslot[t];
+            if (wj) { winsrc[t] = s_src[wj - 1] + 1u; winslot[t] = 0u; }
+            zlast[t] = s_z[j];                                                       // dlut[y,x] = z, unconditionally (warping.c:29)
+        }
+        __syncthreads();
+    };
+
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        const uint32_t lo = b << FWG_LB, hi = lo + (NT - 1);
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) {
+            const uint32_t t = lane + 64 * k;
+            zlast[t] = 1000.0f; winslot[t] = 0u; winsrc[t] = 0u; state[t] = 0u;
+        }
+        uint32_t cnt = 0;
+        __syncthreads();
+        // candidate tiles, 512 table entries per batch (8 independent loads per lane in flight); typically a bucket sees 1-3 candidates
+        for (uint32_t t0 = 0; t0 < ntiles; t0 += 512) {
+            uint32_t mn[8], mx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t tile = t0 + 64 * k + lane;
+                const bool ok = tile < ntiles;
+                mn[k] = ok ? tile_min[tile] : 0xFFFFFFFFu;
+                mx[k] = ok ? tile_max[tile] : 0u;
+            }
+            uint32_t nct = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool hit = mn[k] <= hi && mx[k] >= lo;
+                const unsigned long long bm = __ballot(hit);
+                if (hit) clist[nct + __popcll(bm & lt)] = t0 + 64 * k + lane;
+                nct += __popcll(bm);
+            }
+            __syncthreads();
+            for (uint32_t c0 = 0; c0 < nct; c0 += 4) {       // 4 candidate tiles = 64 slabs per round
+                const uint32_t ci = c0 + (lane >> 4);
+                const uint32_t slab = ci < nct ? clist[ci] * 16 + (lane & 15u) : 0u;
+                const bool shit = ci < nct && slab_min[slab] <= hi && slab_max[slab] >= lo;
+                unsigned long long sm = __ballot(shit);
+                while (sm) {                                   // the touching slabs in raster order, four at a time (their 8 loads in flight together)
+                    if (cnt > FWG_CAP - 256) {                 // the next four slabs might not fit: fold the chunk into the carried state
+                        __syncthreads();
+                        process(cnt);
+                        cnt = 0;
+                    }
+                    uint32_t key[4];
+                    float zz[4];
+                    uint32_t nn[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t n = 0xFFFFFFFFu;
+                        if (sm) {
+                            const int first = __ffsll((long long)sm) - 1;
+                            sm &= sm - 1ull;
+                            n = __shfl(slab, first) * 64 + lane;
+                        }
+                        const bool ok = n < N;
+                        nn[q] = n;
+                        key[q] = ok ? keys[n] : 0xFFFFFFFFu;
+                        zz[q] = ok ? z[n] : 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool match = (key[q] >> FWG_LB) == b && nn[q] < N;
+                        const unsigned long long mm = __ballot(match);
+                        if (match) {
+                            const uint32_t pos = cnt + __popcll(mm & lt);
+                            g_src[pos] = nn[q]; g_tl[pos] = key[q] & (NT - 1); g_z[pos] = zz[q];
+                        }
+                        cnt += __popcll(mm);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        if (cnt) process(cnt);
+        // the 5 bytes of every target of the bucket
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) {
+            const uint32_t tl = lane + 64 * k;
+            const uint64_t t = (uint64_t)lo + tl;
+            if (t >= N) continue;
+            const uint32_t st = state[tl];
+            uint8_t *o = warped + (size_t)t * 5;
+            if (st & 1u) {
+                const uint32_t ws = winsrc[tl];
+                if (ws) {                                                           // no visitor passed the z test: the colour bytes keep what they held
+                    const uint32_t v = ws - 1u;
+                    if (src_f) {                                                    // the frame given as float [3,h,w] in 0..1: its uint8 BGR form, utils/utils.py:174-177
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) o[c] = mpf_to_u8(src_f[(size_t)(2 - c) * N + v]);
+                    } else {
+                        const uint8_t *sp = src + (size_t)v * 3;
+                        o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
+                    }
+                } else if (zero_fill) {
+                    o[0] = o[1] = o[2] = 0;
+                }
+                o[3] = 1;                                                           // warping.c:23
+                o[4] = (st >> 1) & 1u;
+            } else if (zero_fill) {                                                 // targets nobody visited (moving_obj.py:123 zero-inits)
+                o[0] = o[1] = o[2] = o[3] = o[4] = 0;
+            }
+            if (Hm) {
+                Hm[t] = (uint8_t)(st & 1u);
+                Mm[t] = (uint8_t)((st & 1u) && !(st & 2u));                         // 1 - (collision == valid)
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// moving_obj.py:143-150 from the planes pass 2 wrote: M' = dilate3x3(M), P = (M' == M), H' = H * P.  Four pixels per thread.
+__global__ void __launch_bounds__(256)
+k_warp_masks_planes(const uint8_t *__restrict__ Hm, const uint8_t *__restrict__ Mm, int H, int W, uint8_t *__restrict__ Md, uint8_t *__restrict__ P,
+                    uint8_t *__restrict__ Hp)
+{
+    const int W4 = (W + 3) >> 2;
+    const int64_t total = (int64_t)H * W4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W4), x0 = (int)(i - (int64_t)y * W4) * 4;
+        uint8_t col[6] = {0, 0, 0, 0, 0, 0};                                        // column maxima over rows y-1..y+1 for x0-1 .. x0+4 (the border never wins the max)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            const uint8_t *row = Mm + (size_t)yy * W;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int xx = x0 - 1 + k;
+                if (xx >= 0 && xx < W) { const uint8_t v = row[xx]; col[k] = v > col[k] ? v : col[k]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k;
+            if (x >= W) break;
+            const size_t n = (size_t)y * W + x;
+            uint8_t md = col[k] > col[k + 1] ? col[k] : col[k + 1];
+            md = col[k + 2] > md ? col[k + 2] : md;
+            const uint8_t p = (uint8_t)(md == Mm[n]);
+            Md[n] = md; P[n] = p; Hp[n] = (uint8_t)(Hm[n] * p);
+        }
+    }
+}
+
 // ---- resolve (the general path: images above 2^22 pixels) ------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256)
@@ -606,15 +928,15 @@ k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
     o[4] = (zprev == 1000.0f) ? 1 : 0;                                // warping.c:24-27
 }
 
-static int g_fw_path = 0;       // mpf_tune("fwarp_path", 1): force the general multi-pass path (tests; images above 2^22 pixels take it anyway)
+static int g_fw_path = 0;       // mpf_tune("fwarp_path", p): 0 = gather (round 5; images up to 2^24 pixels), 1 = the general multi-pass radix path (what larger
+                                // images take), 2 = round 2's one-pass sort + per-bucket workgroups (kept for A/B and as a second witness in the tests).
+                                // Process-global and not thread-safe, like every mpf_tune knob: set it before launching work, from one thread.
 
 void mpf_fwarp_set_path(int v) { g_fw_path = v; }
 static int g_fw_grid = 0;       // mpf_tune("chain_grid", g): cap the workgroup count of every sort / resolve / mask launch at g (0 = one per tile);
                                 // fewer, longer-lived workgroups for runs underneath a chip-filling launch of another stream
 void mpf_fwarp_set_grid(int v) { g_fw_grid = v < 0 ? 0 : v; }
 static inline uint32_t fw_cap(uint32_t n) { return (g_fw_grid > 0 && n > (uint32_t)g_fw_grid) ? (uint32_t)g_fw_grid : n; }
-static int g_fw_stop = 0;       // mpf_tune("chain_stop", n): bench-only ablation, the fast path returns after its first n launches (results invalid)
-void mpf_fwarp_set_stop(int v) { g_fw_stop = v; }
 void mpf_fwarp_set_prio(int v) { g_fw_prio = v < 0 ? 0 : (v > 3 ? 3 : v); }
 
 static inline uint32_t fw_blocks(int64_t N) { return (uint32_t)((N + SORT_TILE - 1) / SORT_TILE); }
@@ -632,8 +954,10 @@ extern "C" size_t mpf_forward_warp_workspace(int h, int w)
 struct FwProj { const float *disp; MpfMoProj m; const float *inst; MpfMoOut out; const float *src_f; };
 
 static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_idy, const float *d_z, uint8_t *d_warped, int h,
-                  int w, void *d_workspace, size_t workspace_bytes, void *stream, bool zero_fill, const FwProj *proj = nullptr)
+                  int w, void *d_workspace, size_t workspace_bytes, void *stream, bool zero_fill, const FwProj *proj = nullptr,
+                  uint8_t *planes_H = nullptr, uint8_t *planes_M = nullptr, bool *planes_written = nullptr)
 {
+    if (planes_written) *planes_written = false;
     const float *src_f = proj ? proj->src_f : nullptr;
     MPF_REQUIRE((d_src || src_f) && d_idx && d_idy && d_z && d_warped && d_workspace && h >= 1 && w >= 1, "mpf_forward_warp: bad argument");
     const int64_t N64 = (int64_t)h * w;
@@ -654,16 +978,27 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
 
     int bits = 0;
     while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)N) ++bits;
-    if (bits <= 2 * RADIX_BITS_MAX && g_fw_path == 0) {
+    if (bits <= 24 && g_fw_path == 0) {
+        // round 5: gather instead of sort - keys + slab / tile ranges, then one wave per bucket of 256 targets (k_fw_gather_resolve)
+        const uint32_t ntiles = (N + FWG_TILE - 1) / FWG_TILE, nslabs = ntiles * 16, nbuckets = (N + (1u << FWG_LB) - 1) >> FWG_LB;
+        uint32_t *slab_min = keys[1], *slab_max = keys[1] + nslabs, *tile_min = slab_max + nslabs, *tile_max = tile_min + ntiles;   // 34 N / 1024 words of the second key array
+        static const MpfMoProj no_proj = {};
+        if (proj) hipLaunchKernelGGL((k_fw_keys_ranges<true>), dim3(fw_cap(ntiles)), dim3(256), 0, st, proj->disp, proj->m, proj->inst, proj->out, d_idx, d_idy, h, w, N,
+                                     ntiles, keys[0], slab_min, slab_max, tile_min, tile_max);
+        else hipLaunchKernelGGL((k_fw_keys_ranges<false>), dim3(fw_cap(ntiles)), dim3(256), 0, st, (const float *)nullptr, no_proj, (const float *)nullptr, MpfMoOut{}, d_idx,
+                                d_idy, h, w, N, ntiles, keys[0], slab_min, slab_max, tile_min, tile_max);
+        hipLaunchKernelGGL(k_fw_gather_resolve, dim3(fw_cap(nbuckets)), dim3(64), 0, st, keys[0], slab_min, slab_max, tile_min, tile_max, N, ntiles, d_z, d_src, src_f,
+                           d_warped, zero_fill ? 1 : 0, planes_H, planes_M);
+        if (planes_written) *planes_written = planes_H != nullptr;
+        return mpf_launch_status("forward_warp kernels");
+    }
+    if (bits <= 2 * RADIX_BITS_MAX && g_fw_path == 2) {
         // the fast path: one stable pass on the high bits, then one workgroup per bucket of 2^lb targets sorts and resolves it
         const int lb = bits <= 16 ? 8 : (bits <= 18 ? 9 : (bits <= 20 ? 10 : 11));
         const int hb = bits > lb ? bits - lb : 1;                        // 1 .. 11 high bits (hb < 8: the pass still uses 8-bit digits)
         const int pb = hb < 8 ? 8 : hb;
         const uint32_t nbuckets = (uint32_t)(((uint64_t)N + ((uint64_t)1 << lb) - 1) >> lb);
 #define MPF_FW_PASS1(PBv)                                                                                                          \
-        if (g_fw_stop == 1) { \
-          if (proj) hipLaunchKernelGGL((k_mo_project_keys_hist<PBv>), dim3(fw_cap(nb)), dim3(SORT_THREADS), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out, keys[0], vals[0], N, lb, hist, g_fw_prio); \
-          return 0; } \
         if (proj) hipLaunchKernelGGL((k_mo_project_keys_hist<PBv>), dim3(fw_cap(nb)), dim3(SORT_THREADS), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out, keys[0], vals[0], N, lb, hist, g_fw_prio); \
         else hipLaunchKernelGGL((k_fw_keys_hist<PBv>), dim3(fw_cap(nb)), dim3(SORT_THREADS), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], N, lb, hist);      \
         hipLaunchKernelGGL(k_radix_colscan, dim3(fw_cap((1u << PBv) / 4u)), dim3(256), 0, st, hist, nb, 1u << PBv, totals, g_fw_prio);                       \
@@ -675,7 +1010,6 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
         default: MPF_FW_PASS1(11); break;
         }
 #undef MPF_FW_PASS1
-        if (g_fw_stop == 3) return 0;
 #define MPF_FW_BUCKET(LBv) hipLaunchKernelGGL((k_fw_bucket<LBv>), dim3(fw_cap(nbuckets)), dim3(SORT_THREADS), 0, st, keys[1], vals[1], keys[0], vals[0], totals, \
                                               N, d_z, d_src, d_warped, zero_fill ? 1 : 0, g_fw_prio, src_f)
         switch (lb) {
@@ -773,9 +1107,15 @@ extern "C" int mpf_moving_object_chain(const float *d_disp, const float *h_inv_k
     memcpy(pr.m.Po, h_P_obj12, sizeof(pr.m.Po));
     pr.out = MpfMoOut{ out->d_p1, out->d_z1, out->d_safe_x, out->d_safe_y, out->d_flow01 };
     pr.src_f = d_src_f32_3HW;
-    const int rc = fw_run(d_src_u8, out->d_safe_x, out->d_safe_y, out->d_z1, out->d_warped, H, W, d_workspace, workspace_bytes, stream, true, &pr);
-    if (rc || !masks || (g_fw_stop >= 1 && g_fw_stop <= 4)) return rc;
-    return mpf_warp_masks(out->d_warped, H, W, out->d_Hm, out->d_M, out->d_Md, out->d_P, out->d_Hp, stream);
+    bool planes = false;
+    const int rc = fw_run(d_src_u8, out->d_safe_x, out->d_safe_y, out->d_z1, out->d_warped, H, W, d_workspace, workspace_bytes, stream, true, &pr,
+                          masks ? out->d_Hm : nullptr, masks ? out->d_M : nullptr, &planes);
+    if (rc || !masks) return rc;
+    if (!planes) return mpf_warp_masks(out->d_warped, H, W, out->d_Hm, out->d_M, out->d_Md, out->d_P, out->d_Hp, stream);
+    const int64_t quads = (int64_t)H * ((W + 3) / 4);
+    hipLaunchKernelGGL(k_warp_masks_planes, dim3(fw_cap((unsigned)((quads + 255) / 256))), dim3(256), 0, (hipStream_t)stream, out->d_Hm, out->d_M, H, W, out->d_Md, out->d_P,
+                       out->d_Hp);
+    return mpf_launch_status("k_warp_masks_planes");
 }
 
 // ---- the reference's FFI symbol (host pointers) -----------------------------------------------------------------

@@ -1790,7 +1790,6 @@ extern "C" int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int
 
 void mpf_fwarp_set_path(int v);      // mpf_fwarp.hip
 void mpf_fwarp_set_prio(int v);
-void mpf_fwarp_set_stop(int v);
 void mpf_fwarp_set_grid(int v);
 
 extern "C" int mpf_tune(const char *key, int value)
@@ -1803,7 +1802,6 @@ extern "C" int mpf_tune(const char *key, int value)
     if (key && !strcmp(key, "view_shift")) { g_view_shift = value < 0 ? 0 : value; return 0; }
     if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
     if (key && !strcmp(key, "chain_grid")) { mpf_fwarp_set_grid(value); return 0; }
-    if (key && !strcmp(key, "chain_stop")) { mpf_fwarp_set_stop(value); return 0; }
     if (key && !strcmp(key, "chain_prio")) { mpf_fwarp_set_prio(value); return 0; }
     if (key && !strcmp(key, "ovl_xcd_a")) { g_ovl_xcd_a = (value < 0 || value > 7) ? 0 : value; return 0; }
     mpf_set_error("mpf_tune: unknown key");

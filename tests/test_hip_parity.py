@@ -283,15 +283,17 @@ def test_forward_warp_random_vs_oracle(dev, oracle, h, w, spread):
     want = oracle.forward_warping(src, idx, idy, z, h, w)
     got = ops.forward_warp(T(src, dev), T(idx, dev), T(idy, dev), T(z, dev), h, w)
     assert bits_equal(N(got), want) == 0
-    # the general multi-pass path (what images above 2^22 pixels take) gives the same bytes
+    # the general multi-pass radix path (what images above 2^24 pixels take) and round 2's one-pass sort + per-bucket workgroups (fwarp_path 2)
+    # give the same bytes as the default gather path
     from mpiflow_amd import _lib
     lib = _lib.load()
-    try:
-        _lib.check(lib.mpf_tune(b"fwarp_path", 1))
-        got2 = ops.forward_warp(T(src, dev), T(idx, dev), T(idy, dev), T(z, dev), h, w)
-    finally:
-        _lib.check(lib.mpf_tune(b"fwarp_path", 0))
-    assert bits_equal(N(got2), want) == 0
+    for path in (1, 2):
+        try:
+            _lib.check(lib.mpf_tune(b"fwarp_path", path))
+            got2 = ops.forward_warp(T(src, dev), T(idx, dev), T(idy, dev), T(z, dev), h, w)
+        finally:
+            _lib.check(lib.mpf_tune(b"fwarp_path", 0))
+        assert bits_equal(N(got2), want) == 0, path
 
 
 def test_forward_warping_ffi_symbol_host_pointers(dev, oracle):

@@ -459,7 +459,7 @@ def overlap_record(S, H, W, dev, n_streams=2, images=4, steps=8):
             "streams": n_streams, "pairs_per_s": n / dt, "us_per_pair": dt / n * 1e6, "pairs_timed": n}
 
 
-def generator_record(n_images=64, repeat=5, timeout=600):
+def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64):
     """The data generator end to end (gen_3dphoto_dynamic.py, the reference's entry point gen_3dphoto_dynamic_v2.py:20-122): PNG decode,
     input stage, AdaMPI network (random weights of the reference's architecture: no checkpoint offline) on the HIP engine, blend once per
     image, `repeat` pairs per image, hole filling (cv2.inpaint's NS restated, on the writer threads), PNG + .flo files - on a synthetic
@@ -475,7 +475,7 @@ def generator_record(n_images=64, repeat=5, timeout=600):
             os.makedirs(os.path.join(base, d))
         rs = np.random.RandomState(0)
         yy, xx = np.mgrid[0:375, 0:1242]
-        for i in range(n_images):
+        for i in range(min(n_images, n_distinct)):
             img = (np.clip(0.5 + 0.25 * np.sin(xx / (17.0 + i)) + 0.25 * np.cos(yy / 23.0) + 0.05 * rs.randn(375, 1242), 0, 1) * 255).astype(np.uint8)
             Image.fromarray(np.stack([img, np.roll(img, 7, 1), np.roll(img, 13, 0)], -1)).save(os.path.join(base, "images", "%04d.png" % i))
             Image.fromarray((255 * (0.1 + 0.8 * yy / 375)).astype(np.uint8)).save(os.path.join(base, "disps", "%04d.png" % i))
@@ -483,6 +483,9 @@ def generator_record(n_images=64, repeat=5, timeout=600):
             m[150:300, 300:600] = 1
             m[200:330, 800:1000] = 2
             Image.fromarray(m).save(os.path.join(base, "masks", "%04d.png" % i))
+        for i in range(n_distinct, n_images):                # the rest of the set: links to the distinct files (decoded, uploaded and rendered like any other image)
+            for d in ("images", "disps", "masks"):
+                os.symlink(os.path.join(base, d, "%04d.png" % (i % n_distinct)), os.path.join(base, d, "%04d.png" % i))
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         cmd = [sys.executable, os.path.join(ROOT, "gen_3dphoto_dynamic.py"), "--base", base, "--out", os.path.join(tmp, "out"), "--repeat", str(repeat),
                "--mpi-from", "model", "--ckpt_path", "random:0", "--model-engine", "hip", "--inpaint", "builtin"]
@@ -602,10 +605,11 @@ def main():
         order = list(range(a.pairs_per_step if a.pairs_per_step > 0 else B))
     chain = dynamic and not a.no_moving_object
     main_stream = torch.cuda.Stream(dev, priority=a.main_priority) if a.main_priority else None
+    masked_main = None
     if a.main_cu_exclude_stride > 1:                         # tuning: the pair stream may use every CU EXCEPT those the chain's side stream is confined to
-        h = ctypes.c_void_p()
-        _lib.check(_lib.load().mpf_stream_create_cu_subset(-a.main_cu_exclude_stride, 0, ctypes.byref(h)), "mpf_stream_create_cu_subset")
-        main_stream = torch.cuda.ExternalStream(h.value, device=dev)
+        masked_main = ctypes.c_void_p()
+        _lib.check(_lib.load().mpf_stream_create_cu_subset(-a.main_cu_exclude_stride, 0, ctypes.byref(masked_main)), "mpf_stream_create_cu_subset")
+        main_stream = torch.cuda.ExternalStream(masked_main.value, device=dev)
     if main_stream is not None:
         main_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_stream)
@@ -692,7 +696,12 @@ def main():
             "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.mode == "batch" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "merge_in_launch": bool(a.merge_in_launch) if pipelined else None, "chain_cu_stride": a.chain_cu_stride, "main_stream_priority": a.main_priority, "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None, "tune": a.tune,
+            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "merge_in_launch": bool(a.merge_in_launch) if pipelined else None, "chain_cu_stride": a.chain_cu_stride, "main_stream_priority": a.main_priority, "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None,
+                       "chain_join": (("per pair on the main stream (event wait before the pair is handed back)" if a.chain_ordered else
+                                       "the chain is an independent side pipeline: each pair's moving-object results carry their own `ready` event and are NOT joined "
+                                       "with the pair's render results per pair inside the timed region (no consumer runs in this bench); the side stream is joined once, "
+                                       "in the timed region's final flush.  --chain-ordered 1 measures the per-pair join (round 4: +12 us per pair)") if chain and pipelined else None),
+                       "tune": a.tune,
                        "pairs_per_step_per_gpu": len(order), "resident_stacks_per_gpu": B, "timed_seconds": dt,
                        "sharding": "independent images per rank (i % world == rank), stats all-reduce only",
                        "device": _lib.device_info(local),
@@ -761,6 +770,12 @@ def main():
             out["cpu_baseline"]["reference_measured_in_build_container"] = \
                 "reference render_3dphoto_dynamic (the same full dynamic pair) 64x640x960: 104.8 s on 8 threads (tests/golden/make_golden.py)"
         print(json.dumps(out))
+    if getattr(wl, "r", None) is not None and hasattr(wl.r, "close"):
+        wl.r.close()                                         # a CU-masked side stream (--chain-cu-stride)
+    if masked_main is not None:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        _lib.check(_lib.load().mpf_stream_destroy(masked_main), "mpf_stream_destroy")
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -428,12 +428,12 @@ def render_image(opt, dev, K, out, name, item, obj_indices, pose_params, lane, m
         with torch.cuda.stream(tail_stream):
             tail_stream.wait_event(ready)
             for r, res in enumerate(results):
-                for tns in (res["frame_mix"], res["fill_mask"], res["flow_mix"]):
+                for tns in (res["frame_mix"], res["fill_mask"], res["flow_mix"]) + ((res["slab"],) if res.get("slab") is not None else ()):
                     tns.record_stream(tail_stream)
                 flo_path, png_path = os.path.join(out, "flows", f"{name}_{r}.flo"), os.path.join(out, "dst_images", f"{name}_{r}.png")   # :120-121
                 with lap("hole fill / PNG scanlines + hand-off to the writers"):
                     if fill_mode in ("cv2", "builtin"):                    # :284-286 on the host, on a writer thread
-                        ring.submit_pair_fill(res["flow_mix"], res["frame_mix"], res["fill_mask"], flo_path, png_path)
+                        ring.submit_pair_fill(res["flow_mix"], res["frame_mix"], res["fill_mask"], flo_path, png_path, slab=res.get("slab"))   # one D2H copy per pair
                     else:
                         frame = ops.fill_holes(res["frame_mix"], res["fill_mask"], workspace=fill_ws) if fill_mode == "peel" else res["frame_mix"]
                         ring.submit_pair(res["flow_mix"], ops.png_scanlines(frame), flo_path, png_path)

@@ -35,7 +35,7 @@ extern "C" {
                              round 4 (401): + mpf_moving_object_chain, mpf_warp_views_blend_next_merge_prev, mpf_stream_create_cu_subset / _destroy,
                              mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6;
                              round 5 (501): + the parity-grade producer engine mpf_pconv, mpf_pfmn_input, mpf_pencoder_input, mpf_pbilinear2x, mpf_pper_plane,
-                             mpf_pplane_masks, mpf_pmaxpool3x3s2 */
+                             mpf_pplane_masks, mpf_pmaxpool3x3s2; MpfMergeArgs + obj_mask_stride, mpf_merge_ex */
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)
@@ -60,8 +60,12 @@ int mpf_device_info(int device, int *cu_count, size_t *hbm_bytes, char *arch, si
 int mpf_stream_create_cu_subset(int stride, int offset, void **out_stream);
 int mpf_stream_destroy(void *stream);
 
-/* bench/tuning knobs (never change results): "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2); "stage_b" = Stage B kernel
- * variant; "ovl_depth" = planes of loads a Stage A+C wave keeps in flight inside mpf_warp_views_and_blend_next (4 or 8) */
+/* bench/tuning knobs: "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2); "stage_b" = Stage B kernel variant; "planar_lds";
+ * "ovl_depth" = planes of loads a Stage A+C wave keeps in flight inside the pair launch (4 or 8); "ovl_xcd_a"; "view_shift"; "fwarp_path" = 0 gather
+ * (default) | 1 general radix path | 2 round 2's sort path; "chain_grid" / "chain_prio" (grid cap / s_setprio of the forward-warp kernels).  None of
+ * these changes a result - every variant is bit-identical, which the tests assert - except "ovl_ablate" and "stage_b" 101..106, which exist for
+ * timing ablations only and produce INVALID outputs.  The knobs are PROCESS-GLOBAL plain ints, not per-stream and NOT thread-safe: set them from one
+ * thread while no other thread is launching work through this library.  Unknown keys return MPF_ERR_BAD_ARGUMENT. */
 int mpf_tune(const char *key, int value);
 
 /* ================= fused hot path =============================================================================== */
@@ -162,10 +166,13 @@ typedef struct MpfMergeArgs {
     const float *d_frame, *d_frame_dyn;        /* [3,H,W] the two rendered views */
     const float *d_mask, *d_mask_dyn;          /* [H,W] their rendered object masks */
     const float *d_flow, *d_flow_dyn;          /* [2,H,W] the two volume-rendered flows */
-    const float *d_obj_mask;                   /* [H,W] source-frame object mask */
+    const float *d_obj_mask;                   /* [H,W] source-frame object mask (see obj_mask_stride) */
     float thresh;
     float *d_flow_mix;                         /* [H,W,2] */
     uint8_t *d_frame_mix, *d_fill_mask;        /* [H,W,3] BGR, [H,W] */
+    int obj_mask_stride;                       /* floats between consecutive pixels of d_obj_mask: 0 | 1 = a plain [H,W] map; 4 = the first component of a
+                                                  mask-quad buffer [H,W,4] (what Stage A+C wrote for that pair: quads[n].x == obj_mask[n]) - lets a pipelined
+                                                  caller merge a pair from buffers it owns, whatever happened to the caller's mask tensor since */
 } MpfMergeArgs;
 int mpf_warp_views_blend_next_merge_prev(const float *d_rgba, const MpfWarpView *views, int n_views,
                                          const float *d_mpi_next, const float *d_img_next, const float *d_params_next, int P,
@@ -179,6 +186,9 @@ int mpf_warp_views_blend_next_merge_prev(const float *d_rgba, const MpfWarpView 
 int mpf_merge(const float *d_frame, const float *d_frame_dyn, const float *d_mask, const float *d_mask_dyn,
               const float *d_flow, const float *d_flow_dyn, const float *d_obj_mask, float thresh, int H, int W,
               float *d_flow_mix, uint8_t *d_frame_mix, uint8_t *d_fill_mask, void *stream);
+
+/* mpf_merge with its arguments as the struct (obj_mask_stride honoured) */
+int mpf_merge_ex(const MpfMergeArgs *args, int H, int W, void *stream);
 
 /* The depth-ordered variant of Stage D's frame ("utils/utils copy.py":278-303, the reference's older per-image module): frame_mix as
  * mpf_merge computes it, except that where both layers cover the pixel (both masks non-zero) and depth > depth_dyn the dynamic layer's

@@ -66,7 +66,7 @@ class MpfMovingObjectOut(ctypes.Structure):
 class MpfMergeArgs(ctypes.Structure):
     """struct MpfMergeArgs of include/mpiflow_hip.h: mpf_merge's arguments, for the merge folded into a pair launch."""
     _fields_ = [("d_frame", c_p), ("d_frame_dyn", c_p), ("d_mask", c_p), ("d_mask_dyn", c_p), ("d_flow", c_p), ("d_flow_dyn", c_p),
-                ("d_obj_mask", c_p), ("thresh", c_f), ("d_flow_mix", c_p), ("d_frame_mix", c_p), ("d_fill_mask", c_p)]
+                ("d_obj_mask", c_p), ("thresh", c_f), ("d_flow_mix", c_p), ("d_frame_mix", c_p), ("d_fill_mask", c_p), ("obj_mask_stride", c_i)]
 
 
 MAX_VIEWS = 16          # MPF_MAX_VIEWS
@@ -88,6 +88,7 @@ SIGNATURES = {
     "mpf_warp_views_blend_next_merge_prev": (c_i, [c_p, ctypes.POINTER(MpfWarpView), c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i,
                                                   ctypes.POINTER(MpfMergeArgs), c_p]),
     "mpf_merge": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "mpf_merge_ex": (c_i, [ctypes.POINTER(MpfMergeArgs), c_i, c_i, c_p]),
     "mpf_merge_depth_ordered": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p, c_p]),
     "mpf_fill_holes_workspace": (c_sz, [c_i, c_i]),
     "mpf_fill_holes": (c_i, [c_p, c_p, c_i, c_i, c_p, c_sz, c_p]),

@@ -1430,7 +1430,7 @@ MPF_DEV void mpf_merge_pixel(const MpfMergeArgs &a, const int64_t n, const int64
     const float th = a.thresh;
     // every input first, unconditionally (all addresses are valid): written as `cond ? a[n] : b[n]` hipcc branches around the loads and
     // the wave sits out six dependent round trips in a kernel that is nothing but latency
-    const float om = a.d_obj_mask[n], m = a.d_mask[n], md = a.d_mask_dyn[n];
+    const float om = a.d_obj_mask[n * (a.obj_mask_stride > 1 ? a.obj_mask_stride : 1)], m = a.d_mask[n], md = a.d_mask_dyn[n];
     const float fx = a.d_flow[n], fy = a.d_flow[N + n], gx = a.d_flow_dyn[n], gy = a.d_flow_dyn[N + n];
     float fr[3], fd[3];
 #pragma unroll
@@ -1738,6 +1738,44 @@ extern "C" int mpf_warp_views_blend_next_merge_prev(const float *d_rgba, const M
         for (int v = 0; v < n_views && views; ++v)
             MPF_REQUIRE(views[v].d_rgb != mg.d_frame && views[v].d_rgb != mg.d_frame_dyn && views[v].d_objmask != mg.d_mask && views[v].d_objmask != mg.d_mask_dyn,
                         "mpf_warp_views_blend_next_merge_prev: the merged pair's views must not be the views this launch renders");
+        MPF_REQUIRE(mg.obj_mask_stride >= 0 && mg.obj_mask_stride <= 4, "mpf_warp_views_blend_next_merge_prev: obj_mask_stride must be 0..4");
+        // The folded merge is race-free only if (1) the thread that merges pixel n is the ONLY one that writes anything the merge of pixel n reads:
+        // the merged pair's flows are either disjoint from the flows this launch writes or exactly those planes (d_flows_next + {0, 2N}: same pixel,
+        // same thread, read before written), its object mask is disjoint from the launch's outputs or exactly the .x of d_quads_next (same argument),
+        // and (2) what the merge writes overlaps nothing this launch reads or writes.
+        const size_t Nn = (size_t)H * W;
+        auto overlaps = [](const void *a, size_t an, const void *b, size_t bn) {
+            return a && b && (const char *)a < (const char *)b + bn && (const char *)b < (const char *)a + an;
+        };
+        const size_t flows_next_bytes = (size_t)P * 2 * Nn * sizeof(float);
+        const float *fl[2] = { mg.d_flow, mg.d_flow_dyn };
+        for (int k = 0; k < 2; ++k) {
+            const bool aligned = d_flows_next && P == 2 && (fl[k] == d_flows_next || fl[k] == d_flows_next + 2 * Nn);
+            MPF_REQUIRE(aligned || !overlaps(fl[k], 2 * Nn * sizeof(float), d_flows_next, flows_next_bytes),
+                        "mpf_warp_views_blend_next_merge_prev: merge_prev's flows must be disjoint from d_flows_next or exactly its two pose planes");
+        }
+        const size_t om_bytes = Nn * sizeof(float) * (size_t)(mg.obj_mask_stride > 1 ? mg.obj_mask_stride : 1);
+        const bool om_is_quads = mg.obj_mask_stride == 4 && (const void *)mg.d_obj_mask == (const void *)d_quads_next;
+        MPF_REQUIRE(om_is_quads || (!overlaps(mg.d_obj_mask, om_bytes, d_quads_next, Nn * 16) && !overlaps(mg.d_obj_mask, om_bytes, d_quads_complement_next, Nn * 16) &&
+                                    !overlaps(mg.d_obj_mask, om_bytes, d_out_rgba_next, (size_t)S * Nn * 16) && !overlaps(mg.d_obj_mask, om_bytes, d_flows_next, flows_next_bytes)),
+                    "mpf_warp_views_blend_next_merge_prev: merge_prev's object mask must not be a buffer this launch writes (other than the .x of d_quads_next, stride 4)");
+        const struct { const void *p; size_t n; const char *what; } outs[3] = { { mg.d_flow_mix, 2 * Nn * sizeof(float), "flow_mix" }, { mg.d_frame_mix, 3 * Nn, "frame_mix" },
+                                                                                  { mg.d_fill_mask, Nn, "fill_mask" } };
+        for (int k = 0; k < 3; ++k) {
+            bool bad = overlaps(outs[k].p, outs[k].n, d_out_rgba_next, (size_t)S * Nn * 16) || overlaps(outs[k].p, outs[k].n, d_rgba, (size_t)S * Nn * 16) ||
+                       overlaps(outs[k].p, outs[k].n, d_flows_next, flows_next_bytes) || overlaps(outs[k].p, outs[k].n, d_quads_next, Nn * 16) ||
+                       overlaps(outs[k].p, outs[k].n, d_quads_complement_next, Nn * 16) || overlaps(outs[k].p, outs[k].n, d_src_u8_bgr_next, 3 * Nn) ||
+                       overlaps(outs[k].p, outs[k].n, d_obj_mask_next, Nn * 4) || overlaps(outs[k].p, outs[k].n, mg.d_obj_mask, om_bytes) ||
+                       overlaps(outs[k].p, outs[k].n, mg.d_flow, 2 * Nn * 4) || overlaps(outs[k].p, outs[k].n, mg.d_flow_dyn, 2 * Nn * 4) ||
+                       overlaps(outs[k].p, outs[k].n, mg.d_frame, 3 * Nn * 4) || overlaps(outs[k].p, outs[k].n, mg.d_frame_dyn, 3 * Nn * 4) ||
+                       overlaps(outs[k].p, outs[k].n, mg.d_mask, Nn * 4) || overlaps(outs[k].p, outs[k].n, mg.d_mask_dyn, Nn * 4);
+            for (int j = k + 1; j < 3; ++j) bad = bad || overlaps(outs[k].p, outs[k].n, outs[j].p, outs[j].n);
+            for (int v = 0; v < n_views && views; ++v)
+                bad = bad || overlaps(outs[k].p, outs[k].n, views[v].d_rgb, 3 * Nn * 4) || overlaps(outs[k].p, outs[k].n, views[v].d_objmask, Nn * 4) ||
+                      overlaps(outs[k].p, outs[k].n, views[v].d_depth, Nn * 4) || overlaps(outs[k].p, outs[k].n, views[v].d_tgt_mask, Nn * 4) ||
+                      overlaps(outs[k].p, outs[k].n, views[v].d_rgb_u8_bgr, 3 * Nn) || overlaps(outs[k].p, outs[k].n, views[v].d_mask_quads, Nn * 16);
+            MPF_REQUIRE(!bad, "mpf_warp_views_blend_next_merge_prev: merge_prev's %s overlaps a buffer this launch reads or writes", outs[k].what);
+        }
     }
     MPF_REQUIRE(d_rgba && views && d_mpi_next && d_img_next && d_params_next && d_out_rgba_next, "mpf_warp_views_and_blend_next: null pointer");
     MPF_REQUIRE(d_out_rgba_next != d_rgba, "mpf_warp_views_and_blend_next: the stack being rendered and the stack being written must be different buffers");
@@ -1827,7 +1865,19 @@ extern "C" int mpf_merge(const float *d_frame, const float *d_frame_dyn, const f
     MPF_REQUIRE(d_frame && d_frame_dyn && d_mask && d_mask_dyn && d_flow && d_flow_dyn && d_obj_mask && d_flow_mix &&
                     d_frame_mix && d_fill_mask && H >= 1 && W >= 1, "mpf_merge: bad argument");
     const int64_t N = (int64_t)H * W;
-    const MpfMergeArgs m = { d_frame, d_frame_dyn, d_mask, d_mask_dyn, d_flow, d_flow_dyn, d_obj_mask, thresh, d_flow_mix, d_frame_mix, d_fill_mask };
+    const MpfMergeArgs m = { d_frame, d_frame_dyn, d_mask, d_mask_dyn, d_flow, d_flow_dyn, d_obj_mask, thresh, d_flow_mix, d_frame_mix, d_fill_mask, 1 };
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m, N);
+    return mpf_launch_status("k_merge");
+}
+
+extern "C" int mpf_merge_ex(const MpfMergeArgs *args, int H, int W, void *stream)
+{
+    MPF_REQUIRE(args && H >= 1 && W >= 1, "mpf_merge_ex: bad argument");
+    const MpfMergeArgs &m = *args;
+    MPF_REQUIRE(m.d_frame && m.d_frame_dyn && m.d_mask && m.d_mask_dyn && m.d_flow && m.d_flow_dyn && m.d_obj_mask && m.d_flow_mix && m.d_frame_mix && m.d_fill_mask,
+                "mpf_merge_ex: null pointer");
+    MPF_REQUIRE(m.obj_mask_stride >= 0 && m.obj_mask_stride <= 4, "mpf_merge_ex: obj_mask_stride must be 0..4");
+    const int64_t N = (int64_t)H * W;
     hipLaunchKernelGGL(k_merge, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m, N);
     return mpf_launch_status("k_merge");
 }

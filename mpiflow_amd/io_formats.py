@@ -182,10 +182,15 @@ class OutputRing:
 
     def _new_slot(self):
         torch, H, W = self._torch, self.H, self.W
-        slot = dict(flow=torch.empty((H, W, 2), dtype=torch.float32).pin_memory(),
-                    scan=torch.empty((H, 3 * W + 1), dtype=torch.uint8).pin_memory())
-        if self._host_fill is not None:
-            slot.update(frame=torch.empty((H, W, 3), dtype=torch.uint8).pin_memory(), hole=torch.empty((H, W), dtype=torch.uint8).pin_memory())
+        slot = dict(scan=torch.empty((H, 3 * W + 1), dtype=torch.uint8).pin_memory())
+        if self._host_fill is None:
+            slot.update(flow=torch.empty((H, W, 2), dtype=torch.float32).pin_memory())
+        else:
+            # flow | frame | hole in ONE page-locked buffer with the layout of ops.pair_slab: a pair rendered into such a slab leaves the GPU in one
+            # device-to-host copy (3 per pair before: on this ROCm build every copy to pinned memory is a blit kernel that parks a workgroup per CU)
+            n = H * W
+            slab = torch.empty(12 * n, dtype=torch.uint8).pin_memory()
+            slot.update(slab=slab, flow=slab[:8 * n].view(torch.float32).view(H, W, 2), frame=slab[8 * n:11 * n].view(H, W, 3), hole=slab[11 * n:].view(H, W))
         return slot
 
     def _get_slot(self):
@@ -218,14 +223,17 @@ class OutputRing:
         finally:
             self._free.put(slot)
 
-    def submit_pair_fill(self, flow_HW2_dev, frame_bgr_dev, hole_dev, flo_path, png_path):
+    def submit_pair_fill(self, flow_HW2_dev, frame_bgr_dev, hole_dev, flo_path, png_path, slab=None):
         """Like submit_pair, but the frame leaves the GPU unfilled together with its hole mask and the writer thread runs
-        `host_fill` on it before encoding."""
+        `host_fill` on it before encoding.  slab: the device buffer the three tensors are views of (ops.pair_slab) - then ONE copy."""
         assert self._host_fill is not None
         slot = self._get_slot()
-        slot["flow"].copy_(flow_HW2_dev, non_blocking=True)
-        slot["frame"].copy_(frame_bgr_dev, non_blocking=True)
-        slot["hole"].copy_(hole_dev, non_blocking=True)
+        if slab is not None and slab.numel() == slot["slab"].numel():
+            slot["slab"].copy_(slab, non_blocking=True)
+        else:
+            slot["flow"].copy_(flow_HW2_dev, non_blocking=True)
+            slot["frame"].copy_(frame_bgr_dev, non_blocking=True)
+            slot["hole"].copy_(hole_dev, non_blocking=True)
         ev = self._torch.cuda.Event()
         ev.record()
         self._track(self._pool.submit(self._finish, slot, ev, flo_path, [png_path], True))

@@ -25,13 +25,22 @@ LD_FMN_INPUT, LD_DIRECT, LD_BILINEAR_CAT, LD_NEAREST_PLANE, LD_FMN_SYNTH, LD_BIL
 EP_AFFINE_RELU, EP_AFFINE_RELU_F32, EP_GATED_ELU, EP_GATED_PLANAR_F32, EP_AFFINE_F32_NHWC, EP_GATED_PLANAR_F32_PAIRED, EP_GATED_ELU_PAIRED = 0, 1, 2, 3, 4, 5, 6
 
 
+def _env_override(var, layer):
+    """The integer a tuning variable of the form "l7=32,up1_1=16" assigns to `layer`, or None.  Empty items (an unset variable, a trailing comma),
+    unnamed layers and values that are not integers are ignored."""
+    if not layer:
+        return None
+    for item in os.environ.get(var, "").split(","):
+        key, _, val = item.partition("=")
+        if key.strip() == layer and val.strip().lstrip("-").isdigit():
+            return int(val)
+    return None
+
+
 def _ct(layer, default):
     """Channels staged per tap and chunk for a layer; MPIFLOW_CT="l7=32,up1_1=16" overrides (tuning aid)."""
-    import os
-    for item in os.environ.get("MPIFLOW_CT", "").split(","):
-        if item.partition("=")[0].strip() == layer:
-            return int(item.partition("=")[2])
-    return default
+    v = _env_override("MPIFLOW_CT", layer)
+    return default if v is None else v
 
 
 # layers whose weights go through LDS once per workgroup (by LDS-DMA) - all but three, measured per layer at 64x384x1280
@@ -42,7 +51,6 @@ _WLDS_LAYERS = {"l1", "l5", "l6", "l7", "l8", "l9", "up0_4", "up1_4", "up0_3", "
 
 def _wlds(layer, default):
     """MPIFLOW_WLDS="all" | "none" | "l8,up1_1" overrides the per-layer choice (tuning aid)."""
-    import os
     v = os.environ.get("MPIFLOW_WLDS")
     if v is None:
         return default
@@ -135,9 +143,9 @@ class ConvLayer:
         if nb == 8 and stride == 1:
             nb = 4              # l5: the stride-1 8-block kernel runs ONE wave per SIMD (128 accumulator registers); 4 blocks: 0.21 -> 0.17 ms.
                                 # (the stride-2 l4 is the other way round: 0.20 ms with 8 blocks, 0.27 with 4)
-        for item in os.environ.get("MPIFLOW_NB", "").split(","):          # tuning aid: MPIFLOW_NB="l4=4,l5=4"
-            if item.partition("=")[0].strip() == name and nblk % int(item.partition("=")[2]) == 0:
-                nb = int(item.partition("=")[2])
+        v = _env_override("MPIFLOW_NB", name)                             # tuning aid: MPIFLOW_NB="l4=4,l5=4"
+        if v is not None and v > 0 and nblk % v == 0:
+            nb = v
         assert nblk % nb == 0
         CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
         epi = EP_AFFINE_F32_NHWC if pre_activation else (EP_AFFINE_RELU_F32 if f32_out else EP_AFFINE_RELU)
@@ -172,9 +180,9 @@ class ConvLayer:
             # the 8-block kernels hold 128 accumulator + 158 other registers: ONE wave per SIMD, nothing to hide a load behind.  With 4 blocks
             # (3 waves per SIMD) the 192-channel layers run 0.25 -> 0.215 ms (up0_4) and 0.48 -> 0.42 ms (up1_4) at 64 x 384 x 1280
             nf = 2
-        for item in os.environ.get("MPIFLOW_NF", "").split(","):          # tuning aid: MPIFLOW_NF="up0_4=2,up1_4=3"
-            if item.partition("=")[0].strip() == name and nf_total % int(item.partition("=")[2]) == 0:
-                nf = int(item.partition("=")[2])
+        v = _env_override("MPIFLOW_NF", name)                             # tuning aid: MPIFLOW_NF="up0_4=2,up1_4=3"
+        if v is not None and v > 0 and nf_total % v == 0:
+            nf = v
         ncg = nf_total // nf
         nblk = 2 * nf_total
         rows_w = torch.zeros(nblk * 16, cf.in_channels, 3, 3)
@@ -275,26 +283,36 @@ class FeatMaskEngine:
 
     def __init__(self, fmn, device):
         A = ConvLayer.affine_relu
-        self.l1 = A(device, fmn.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8, name="l1")
-        self.l2 = A(device, fmn.conv2, [(16, 16)], loader=LD_DIRECT, stride=2, ct=16, name="l2")
+        self._fmn, self._device = fmn, device
+        self.factor = os.environ.get("MPIFLOW_FMN_FACTOR", "1") != "0"
         self.l3 = A(device, fmn.conv3, [(32, 32)], loader=LD_DIRECT, stride=2, ct=32, name="l3")
         self.l4 = A(device, fmn.conv4, [(64, 64)], loader=LD_DIRECT, stride=2, ct=32, name="l4")
         self.l5 = A(device, fmn.conv5, [(128, 128)], loader=LD_DIRECT, stride=1, ct=_ct("l5", 32), name="l5")
         self.l6 = A(device, fmn.conv6, [(128, 128), (64, 64)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l6", 16), name="l6")
         self.l7 = A(device, fmn.conv7, [(64, 64), (32, 32)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l7", 16), name="l7")
-        self.l8 = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l8", 16), name="l8")
         self.l9 = A(device, fmn.conv9, [(16, 16)], loader=LD_DIRECT, stride=1, ct=16, f32_out=True, name="l9")
         # The first layer factorised (model/CPN/unet.py:44-50): the 64 plane-images differ only in the constant plane channel d_s and the layer is
         # affine in it up to the ReLU, c1[s] = relu(A' + d_s * B').  A' (per image) and B' (per size: zero padding makes it position-dependent at
         # the border) are fp32 [H,W,16] maps from ONE plane's worth of the layer-1 kernel without its ReLU; layers 2 and 8 synthesise c1 in their
         # loaders, plane index fastest in the grid so that the planes of a tile share the maps in L2.  The 1 GB activation is never written / read
         # twice, the 0.32 ms launch is gone.  MPIFLOW_FMN_FACTOR=0 keeps the materialised form (A/B, per-layer tests).
-        import os
-        self.factor = os.environ.get("MPIFLOW_FMN_FACTOR", "1") != "0"
-        self.l1p = A(device, fmn.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8, name="l1p", pre_activation=True)
-        self.l2s = A(device, fmn.conv2, [(16, 16)], loader=LD_FMN_SYNTH, stride=2, ct=16, name="l2s", plane_major=True)
-        self.l8s = A(device, fmn.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_SYNTH, stride=1, ct=_ct("l8", 16), name="l8s", plane_major=True)
+        # Only the set the mode uses is packed and uploaded; the other one is built on first access (per-layer tests, A/B runs).
         self._plane_map, self._zeros = {}, {}
+
+    _LAZY = {"l1": lambda A, f, d: A(d, f.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8, name="l1"),
+             "l2": lambda A, f, d: A(d, f.conv2, [(16, 16)], loader=LD_DIRECT, stride=2, ct=16, name="l2"),
+             "l8": lambda A, f, d: A(d, f.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_CAT, stride=1, ct=_ct("l8", 16), name="l8"),
+             "l1p": lambda A, f, d: A(d, f.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8, name="l1p", pre_activation=True),
+             "l2s": lambda A, f, d: A(d, f.conv2, [(16, 16)], loader=LD_FMN_SYNTH, stride=2, ct=16, name="l2s", plane_major=True),
+             "l8s": lambda A, f, d: A(d, f.conv8, [(32, 32), (16, 16)], loader=LD_BILINEAR_SYNTH, stride=1, ct=_ct("l8", 16), name="l8s", plane_major=True)}
+
+    def __getattr__(self, name):                       # only reached when the attribute does not exist yet
+        build = FeatMaskEngine._LAZY.get(name)
+        if build is None or "_fmn" not in self.__dict__:
+            raise AttributeError(name)
+        layer = build(ConvLayer.affine_relu, self._fmn, self._device)
+        setattr(self, name, layer)
+        return layer
 
     def first_layer_maps(self, image_3HW, disp_HW):
         """-> (A' [H,W,16] fp32 for this image, B' [H,W,16] fp32 for this size)"""

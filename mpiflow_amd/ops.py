@@ -261,19 +261,41 @@ def warp_views_and_blend_next(rgba, views, mpi_next, img_next, dparams_next, P, 
     return [v["out"] for v in views]
 
 
-def merge_args(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh, out):
-    """mpf_merge's arguments as the struct a pair launch takes (warp_views_and_blend_next(merge_prev=...)).  All tensors fp32 contiguous on the
-    device, out = (flow_mix [H,W,2] f32, frame_mix [H,W,3] u8, fill_mask [H,W] u8); the caller keeps them alive until the launch was issued."""
+def merge_args(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh, out, obj_mask_stride=1):
+    """mpf_merge's arguments as the struct a pair launch takes (warp_views_and_blend_next(merge_prev=...)) or mpf_merge_ex.  All tensors fp32
+    contiguous on the device, out = (flow_mix [H,W,2] f32, frame_mix [H,W,3] u8, fill_mask [H,W] u8) on the same device; the caller keeps them
+    alive until the launch was issued.  obj_mask_stride = 4: `obj_mask` is a mask-quad buffer [H,W,4] whose .x is the object mask."""
     import numpy as np
     for t in (frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask):
         assert t.is_cuda and t.dtype == _f32 and t.is_contiguous()
+    _, H, W = frame.shape
+    assert obj_mask_stride in (1, 4) and obj_mask.numel() == H * W * obj_mask_stride, (obj_mask_stride, tuple(obj_mask.shape))
+    fm, fr, fi = out
+    assert fm.is_cuda and fm.dtype == _f32 and fm.is_contiguous() and tuple(fm.shape) == (H, W, 2), "flow_mix must be f32 [H,W,2], contiguous"
+    assert fr.is_cuda and fr.dtype == torch.uint8 and fr.is_contiguous() and tuple(fr.shape) == (H, W, 3), "frame_mix must be u8 [H,W,3], contiguous"
+    assert fi.is_cuda and fi.dtype == torch.uint8 and fi.is_contiguous() and tuple(fi.shape) == (H, W), "fill_mask must be u8 [H,W], contiguous"
+    assert fm.device == fr.device == fi.device == frame.device, "merge outputs must live on the device of the views"
     return _lib.MpfMergeArgs(frame.data_ptr(), frame_dyn.data_ptr(), mask.data_ptr(), mask_dyn.data_ptr(), flow.data_ptr(), flow_dyn.data_ptr(),
-                             obj_mask.data_ptr(), float(np.float32(thresh)), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+                             obj_mask.data_ptr(), float(np.float32(thresh)), fm.data_ptr(), fr.data_ptr(), fi.data_ptr(), int(obj_mask_stride))
+
+
+def pair_slab(H, W, device):
+    """One contiguous device buffer holding a pair's three products - flow_mix [H,W,2] f32 | frame_mix [H,W,3] u8 | fill_mask [H,W] u8 (12 H W bytes) -
+    so that they leave the GPU in ONE device-to-host copy (io_formats.OutputRing.submit_pair_fill(slab=...)).  -> (slab u8 [12 H W], (flow_mix, frame_mix, fill_mask) views)"""
+    n = H * W
+    slab = torch.empty(12 * n, dtype=torch.uint8, device=device)
+    return slab, slab_views(slab, H, W)
+
+
+def slab_views(slab, H, W):
+    n = H * W
+    return (slab[:8 * n].view(torch.float32).view(H, W, 2), slab[8 * n:11 * n].view(H, W, 3), slab[11 * n:12 * n].view(H, W))
 
 
 @_on_device
-def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.99, out=None):
-    """Stage D.  out: optional preallocated (flow_mix [H,W,2] f32, frame_mix [H,W,3] u8, fill_mask [H,W] u8)."""
+def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.99, out=None, obj_mask_stride=1):
+    """Stage D.  out: optional preallocated (flow_mix [H,W,2] f32, frame_mix [H,W,3] u8, fill_mask [H,W] u8); default: views of one pair_slab.
+    obj_mask_stride = 4: `obj_mask` is a mask-quad buffer [H,W,4] whose .x is the object mask (mpf_merge_ex)."""
     lib = _lib.load()
     frame = _dev(frame, "frame")
     _, H, W = frame.shape
@@ -281,9 +303,14 @@ def merge(frame, frame_dyn, mask, mask_dyn, flow, flow_dyn, obj_mask, thresh=0.9
     if out is not None:
         flow_mix, frame_mix, fill = out
     else:
-        flow_mix = torch.empty((H, W, 2), dtype=_f32, device=dev)
-        frame_mix = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-        fill = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        _, (flow_mix, frame_mix, fill) = pair_slab(H, W, dev)
+    if obj_mask_stride != 1:
+        import ctypes
+        a = merge_args(frame, _dev(frame_dyn, "frame_dyn").reshape(3, H, W), _dev(mask, "mask").reshape(H, W), _dev(mask_dyn, "mask_dyn").reshape(H, W),
+                       _dev(flow, "flow").reshape(2, H, W), _dev(flow_dyn, "flow_dyn").reshape(2, H, W), _dev(obj_mask, "obj_mask"), thresh,
+                       (flow_mix, frame_mix, fill), obj_mask_stride=obj_mask_stride)
+        _lib.check(lib.mpf_merge_ex(ctypes.byref(a), H, W, _stream()), "mpf_merge_ex")
+        return flow_mix, frame_mix, fill
     args = [_dev(frame_dyn, "frame_dyn").reshape(3, H, W), _dev(mask, "mask").reshape(H, W),
             _dev(mask_dyn, "mask_dyn").reshape(H, W), _dev(flow, "flow").reshape(2, H, W),
             _dev(flow_dyn, "flow_dyn").reshape(2, H, W), _dev(obj_mask, "obj_mask").reshape(H, W)]

@@ -164,7 +164,8 @@ class PairRenderer(_PairHostSide):
         """The `repeat` pairs of ONE image (gen_3dphoto_dynamic_v2.py:99-118) whose blended stack is already in self.rgba (blend()):
         per pair a flow-only Stage A+C (both flows + the mask quads), then ALL their posed views - 2 per pair - in as few Stage B
         launches as 16 views per launch allow, then a merge per pair.  obj_masks: R tensors [H,W]; poses: R (G_cam, G_dyn) tuples.
-        Same results, bit for bit, as R calls of render_pair(..., reuse_blend=True).  Returns R dicts(flow_mix, frame_mix, fill_mask)."""
+        Same results, bit for bit, as R calls of render_pair(..., reuse_blend=True).  Returns R dicts(flow_mix, frame_mix, fill_mask, slab):
+        the three products are views of `slab` (ops.pair_slab)."""
         R = len(obj_masks)
         bufs = self._pair_buffers(R)
         views = []
@@ -182,8 +183,9 @@ class PairRenderer(_PairHostSide):
         out = []
         for om, b in zip(obj_masks, bufs):
             v = b["views"]
-            flow_mix, frame_mix, fill = ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"][0], b["flows"][1], om, thresh)
-            out.append(dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill))
+            slab, views3 = ops.pair_slab(self.H, self.W, self.device)      # the three products in one buffer: they leave the GPU in one copy
+            flow_mix, frame_mix, fill = ops.merge(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"][0], b["flows"][1], om, thresh, out=views3)
+            out.append(dict(flow_mix=flow_mix, frame_mix=frame_mix, fill_mask=fill, slab=slab))
         return out
 
 
@@ -198,9 +200,10 @@ class OverlappedPairRenderer(_PairHostSide):
     fill_mask [H,W] u8) is written, stream-ordered, by the time push returns); flush() completes the last one.  Two slots of
     per-pair buffers (blended stack, flows, quads, views) alternate: a slot is rewritten only after its pair has been merged.
 
-    LIFETIME of the caller's tensors: `obj_mask` and `out` of pair i (and `moving`'s disparity / instance mask) are read / written by
-    the launches that COMPLETE pair i, i.e. inside the NEXT push() / flush().  They must stay untouched until that call has been issued;
-    a streaming caller alternates two buffers (as the renderer's own slots do).  `mpi` / `image` are consumed by the push they are given to.
+    LIFETIME of the caller's tensors: `mpi`, `image` and `obj_mask` are consumed by the push() they are given to (stream-ordered: they may be
+    rewritten on the same stream right after it returns) - the deferred merge reads the object mask from the slot's own mask quads, not from
+    the caller's tensor.  `out` of pair i (and `moving`'s disparity / instance mask) is written / read by the launches that COMPLETE pair i,
+    i.e. inside the NEXT push() / flush() (two further push() calls with merge_in_launch): it must stay untouched until that call has been issued.
 
     attach_chain(chain): SURVEY 8(d)'s full c3 - the moving-object chain of every pair (moving_obj.MovingObjectChain: depth -> flow
     projection, forward warp of the pair's uint8 source frame, masks; moving_obj.py:29-150) runs on a SIDE stream.  The chain of pair i
@@ -212,12 +215,13 @@ class OverlappedPairRenderer(_PairHostSide):
     8 us of kernel plus two launch boundaries on the critical path): the Stage A+C role of launch i+2 merges pair i as a per-pixel prologue
     (mpf_warp_views_blend_next_merge_prev) - the thread that merges a pixel is the one that later overwrites that pixel's flows in the
     slot the two pairs share, so no further buffering is needed.  The stream is then ONE launch per pair and nothing else; push() hands back
-    the pair enqueued TWO calls earlier, `obj_mask` / `out` of a pair must stay untouched for two further push() calls (three alternating
-    buffers), and flush() returns a list (the last two pairs)."""
+    the pair enqueued TWO calls earlier, `out` of a pair must stay untouched for two further push() calls (three alternating buffers), and
+    flush() returns the last two pairs."""
 
     def __init__(self, S, H, W, device, thresh=MASK_THRESH, merge_in_launch=False):
         self.S, self.H, self.W, self.device, self.thresh = S, H, W, torch.device(device), thresh
         self.merge_in_launch, self._merging, self.chain_ordered = merge_in_launch, None, True
+        self.guard_unconsumed = True                                 # see _start_chain_unordered
         f32, dev = torch.float32, self.device
         self.slots = [dict(rgba=ops.alloc_rgba_stack(S, H, W, dev), flows=torch.empty((2, 2, H, W), dtype=f32, device=dev),
                            quads=[torch.empty((H, W, 4), dtype=f32, device=dev) for _ in range(2)],
@@ -239,8 +243,10 @@ class OverlappedPairRenderer(_PairHostSide):
         ordered=False: the chain is an independent side pipeline.  It converts the pair's float image to the same uint8 bytes itself, so it
           needs no output of the render path and NOTHING is inserted into the main stream: it is issued at the top of push(), each handed-back
           ops.MovingObjectBuffers carries `.ready` (a torch event to wait for on whatever stream consumes it; `image` / `moving` tensors of
-          that pair must stay untouched until then), a consumer that sets `.consumed` (event) on a set protects it from being rewritten
-          too early, `moving_ready` of push() names the event after which the pair's inputs may be read (None: one is recorded on the main
+          that pair must stay untouched until then).  A set is rewritten len(chain.bufs) push() calls after it was handed out: a consumer
+          on another stream sets `.consumed` (an event) on it and the chain waits for that; without one the chain waits for an event recorded
+          on the caller's stream at the push() that reuses the set (`guard_unconsumed`, default on), which covers every consumer on that
+          stream.  `moving_ready` of push() names the event after which the pair's inputs may be read (None: one is recorded on the main
           stream), and flush() joins the side stream.
         high_priority: the side stream gets the device's highest stream priority (no measurable effect at 64 x 640 x 960)."""
         # a pair's output set must survive until the pair has been handed back: one push() later, two with merge_in_launch - the sets are used
@@ -249,6 +255,9 @@ class OverlappedPairRenderer(_PairHostSide):
         if len(chain.bufs) < need or (chain.H, chain.W) != (self.H, self.W):
             raise ValueError("attach_chain: the chain needs %d output sets (n_buffers) of %d x %d for this renderer" % (need, self.H, self.W))
         self.chain, self.chain_ordered, self._chain_next = chain, ordered, 0
+        if cu_stride and cu_stride > 1 and high_priority:
+            raise ValueError("attach_chain: a CU-masked side stream (cu_stride) has no priority; give one of cu_stride / high_priority")
+        self.close()                                                  # a previously attached chain's CU-masked stream
         if cu_stride and cu_stride > 1:
             # the side stream may only use every cu_stride-th compute unit: the chain's latency-sized workgroups then sit on few CUs instead of
             # taking a slot here and there on all of them, underneath a launch that fills the whole chip
@@ -263,6 +272,24 @@ class OverlappedPairRenderer(_PairHostSide):
             self.side = torch.cuda.Stream(self.device, priority=-1 if high_priority else 0)
         for k, s in enumerate(self.slots):
             s["index"], s["ev_src"], s["ev_chain"], s["moving"] = k, torch.cuda.Event(), torch.cuda.Event(), None
+
+    def close(self):
+        """Give back the CU-masked side stream of attach_chain(cu_stride=...) (mpf_stream_create_cu_subset), after it has drained."""
+        h = getattr(self, "_side_handle", None)
+        if h is not None:
+            from . import _lib
+            self._side_handle = None
+            try:
+                self.side.synchronize()
+            finally:
+                self.side = None
+                _lib.load().mpf_stream_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                             # noqa: BLE001 - interpreter shutdown
+            pass
 
     def _views(self, slot, prep):
         return [dict(dparams=prep["warp"][v], quads=slot["quads"][v], out=slot["views"][v]) for v in range(2)]
@@ -293,10 +320,20 @@ class OverlappedPairRenderer(_PairHostSide):
         if moving_ready is None:
             moving_ready = torch.cuda.Event()
             moving_ready.record()
+        guard = None
+        if b.consumed is None and getattr(b, "ready", None) is not None and self.guard_unconsumed:
+            # the set was handed out before and its consumer left no `consumed` event: everything enqueued on the CALLER's stream up to this push()
+            # (len(chain.bufs) pushes after the hand-back) finishes before the chain rewrites the set - a consumer on that stream is safe without
+            # doing anything, one on another stream must set `consumed`
+            guard = torch.cuda.Event()
+            guard.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(moving_ready)
             if b.consumed is not None:
                 self.side.wait_event(b.consumed)
+                b.consumed = None
+            elif guard is not None:
+                self.side.wait_event(guard)
             self.chain.run(moving[0], moving[1], image, which=which)
             b.ready = torch.cuda.Event()
             b.ready.record()
@@ -310,15 +347,15 @@ class OverlappedPairRenderer(_PairHostSide):
 
     def _out_of(self, pend):
         if pend["out"] is None:
-            f32, dev, H, W = torch.float32, self.device, self.H, self.W
-            pend["out"] = (torch.empty((H, W, 2), dtype=f32, device=dev), torch.empty((H, W, 3), dtype=torch.uint8, device=dev),
-                           torch.empty((H, W), dtype=torch.uint8, device=dev))
+            pend["out"] = ops.pair_slab(self.H, self.W, self.device)[1]           # one buffer: the three products can leave in one copy
         return pend["out"]
 
     def _merge_operands(self, pend):
+        """The merge of a pair reads ONLY buffers of the pair's slot: its object mask is the .x of the mask quads its Stage A+C role wrote
+        (quads[n].x == obj_mask[n], stride 4), so the caller's mask tensor is consumed by the push() it is given to."""
         slot = pend["slot"]
         v = slot["views"]
-        return (v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], slot["flows"][0], slot["flows"][1], pend["om"])
+        return (v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], slot["flows"][0], slot["flows"][1], slot["quads"][0])
 
     def _handed_back(self, pend):
         done = tuple(pend["out"])
@@ -330,7 +367,7 @@ class OverlappedPairRenderer(_PairHostSide):
 
     def _finish(self, pend):
         """Stage D as a launch of its own, then the pair is handed back."""
-        ops.merge(*self._merge_operands(pend), self.thresh, out=self._out_of(pend))
+        ops.merge(*self._merge_operands(pend), self.thresh, out=self._out_of(pend), obj_mask_stride=4)
         return self._handed_back(pend)
 
     def _blend_alone(self, slot, mpi, image, prep, obj_mask, cum_mask):
@@ -349,7 +386,7 @@ class OverlappedPairRenderer(_PairHostSide):
         obj_mask = obj_mask.reshape(self.H, self.W)
         if obj_mask.dtype != torch.float32 or not obj_mask.is_contiguous():
             obj_mask = obj_mask.to(torch.float32).contiguous()
-        new = dict(slot=slot, prep=prep, om=obj_mask, out=out, moving=self._start_chain_unordered(image, moving, moving_ready))
+        new = dict(slot=slot, prep=prep, out=out, moving=self._start_chain_unordered(image, moving, moving_ready))
         self._wait_chain_of(slot)                                    # this slot's source frame is about to be rewritten
         pend = self._pending
         if pend is None:
@@ -359,7 +396,7 @@ class OverlappedPairRenderer(_PairHostSide):
             self._blend_alone(slot, mpi, image, prep, obj_mask, cum_mask)
         else:
             mg, self._merging = self._merging, None
-            mp = ops.merge_args(*self._merge_operands(mg), self.thresh, self._out_of(mg)) if mg is not None else None
+            mp = ops.merge_args(*self._merge_operands(mg), self.thresh, self._out_of(mg), obj_mask_stride=4) if mg is not None else None
             launch = lambda: ops.warp_views_and_blend_next(                                                   # noqa: E731
                 pend["slot"]["rgba"], self._views(pend["slot"], pend["prep"]), mpi, image, prep["blend"], 2, slot["rgba"],
                 out_flows_next=slot["flows"], src_u8_next=slot["src_u8"], obj_mask_next=obj_mask, quads_next=slot["quads"][0],
@@ -381,8 +418,9 @@ class OverlappedPairRenderer(_PairHostSide):
         return done
 
     def flush(self):
-        """Complete what is in flight: the last pair's stand-alone Stage B launch and the outstanding merges.  Returns the last pair's
-        (flow_mix, frame_mix, fill_mask[, chain buffers]) or None; with merge_in_launch a LIST of the (up to two) pairs completed here, oldest first."""
+        """Complete what is in flight: the last pair's stand-alone Stage B launch and the outstanding merges.  Returns the LIST of the pairs
+        completed here, oldest first - each (flow_mix, frame_mix, fill_mask[, chain buffers]): at most one, with merge_in_launch at most two,
+        [] when nothing was pending."""
         pend, mg = self._pending, self._merging
         self._pending = self._merging = None
         res = []
@@ -393,9 +431,7 @@ class OverlappedPairRenderer(_PairHostSide):
                 res.append(self._finish(p))
         if self.chain is not None and not self.chain_ordered:
             torch.cuda.current_stream().wait_stream(self.side)                # the independent chain joins the main stream here
-        if self.merge_in_launch:
-            return res
-        return res[-1] if res else None
+        return res
 
     @property
     def pending_slot(self):

@@ -63,6 +63,20 @@ def test_conv_args_struct_matches_header(tmp_path):
 
 
 
+def test_merge_args_struct_matches_header(tmp_path):
+    import ctypes
+    from mpiflow_amd import _lib
+    fields = [f[0] for f in _lib.MpfMergeArgs._fields_]
+    src = tmp_path / "o.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mpiflow_hip.h"\nint main(void){printf("%zu", sizeof(MpfMergeArgs));\n'
+                   + "".join('printf(" %%zu", offsetof(MpfMergeArgs, %s));\n' % f for f in fields) + "return 0;}\n")
+    exe = tmp_path / "o"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    vals = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert vals[0] == ctypes.sizeof(_lib.MpfMergeArgs)
+    assert vals[1:] == [getattr(_lib.MpfMergeArgs, f).offset for f in fields]
+
+
 def test_pack_weights_f32_layout():
     """A-operand order of mpf_conv2d_f32 (include/mpiflow_hip.h): lane (m, g) of step s holds W[16 blk + m][4 (v % V) + j][tap v / V], v = 4 s + g."""
     from mpiflow_amd.model.engine import pack_weights_f32

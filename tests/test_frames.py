@@ -233,6 +233,44 @@ def test_png_scanlines_on_device_and_output_ring(tmp_path):
 
 
 @pytest.mark.gpu
+def test_output_ring_takes_a_pair_slab_in_one_copy(tmp_path):
+    """submit_pair_fill(slab=...): flow | frame | hole mask leave the GPU as ONE device-to-host copy of the ops.pair_slab they are views of - same files
+    as the three separate copies."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image
+    from mpiflow_amd import io_formats, ops
+    dev = torch.device("cuda:0")
+    H, W = 40, 72
+    seen = []
+
+    def fill(frame, hole):                                # the writer thread's hook sees exactly what was rendered
+        seen.append((frame.copy(), hole.copy()))
+        out = frame.copy()
+        out[hole > 0] = 7
+        return out
+    ring = io_formats.OutputRing(H, W, dev, slots=2, threads=1, host_fill=fill)
+    want = []
+    for k in range(5):
+        bgr, flow = _rgb(H, W, k), np.random.RandomState(k).randn(H, W, 2).astype(np.float32)
+        hole = (np.random.RandomState(10 + k).rand(H, W) < 0.1).astype(np.uint8)
+        slab, (f, fr, ho) = ops.pair_slab(H, W, dev)
+        f.copy_(torch.from_numpy(flow)); fr.copy_(torch.from_numpy(bgr)); ho.copy_(torch.from_numpy(hole))
+        if k % 2:
+            ring.submit_pair_fill(f, fr, ho, str(tmp_path / ("f%d.flo" % k)), str(tmp_path / ("d%d.png" % k)), slab=slab)
+        else:
+            ring.submit_pair_fill(f, fr, ho, str(tmp_path / ("f%d.flo" % k)), str(tmp_path / ("d%d.png" % k)))
+        want.append((bgr, flow, hole))
+    ring.close()
+    assert len(seen) == 5
+    for k, (bgr, flow, hole) in enumerate(want):
+        assert np.array_equal(io_formats.read_flo(str(tmp_path / ("f%d.flo" % k))), flow)
+        filled = bgr.copy()
+        filled[hole > 0] = 7
+        assert np.array_equal(np.array(Image.open(tmp_path / ("d%d.png" % k)))[:, :, ::-1], filled)
+
+
+@pytest.mark.gpu
 def test_pair_stats_kernel(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

@@ -520,8 +520,7 @@ def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
             res.append([N(t).copy() for t in done[:3]])
         for k, (Gc, Gd) in enumerate(poses):
             take(ovl.push(stacks[k % 2], img, ovl.prepare(K, pd, [Gc, Gd]), om, out=outs[k % 3], moving=(d_disp, d_inst) if with_chain else None))
-        last = ovl.flush()
-        for d in (last if merge_in_launch else [last]):
+        for d in ovl.flush():                                        # always a list: the pairs completed by the flush, oldest first
             take(d)
         assert len(res) == len(poses)
         return res
@@ -838,7 +837,7 @@ def test_overlapped_pair_renderer_equals_render_pair(dev, kernel_exp, S, H, W, n
         if done is not None:
             assert done[0] is outs[i - 1][0]
     last = ovl.flush()
-    assert last[0] is outs[-1][0] and ovl.flush() is None
+    assert isinstance(last, list) and len(last) == 1 and last[0][0] is outs[-1][0] and ovl.flush() == []
     # stacks of 4 GiB and more cannot take the overlapped launch (32-bit buffer offsets): the renderer then issues the two launches one
     # after the other - same interface, same results (forced here on a small shape)
     sep = pipeline.OverlappedPairRenderer(S, H, W, dev)
@@ -849,7 +848,7 @@ def test_overlapped_pair_renderer_equals_render_pair(dev, kernel_exp, S, H, W, n
         done = sep.push(T(inp["mpi"], dev), T(inp["image"], dev), sep.prepare(inp["K"], inp["disparity"], [G_cam, G_dyn]), T(inp["obj_mask"], dev))
         if done is not None:
             outs2.append(done)
-    outs2.append(sep.flush())
+    outs2 += sep.flush()
     for a, b in zip(outs, outs2):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
     # merge_in_launch: Stage D of pair i rides in launch i+2 (the Stage A+C role's per-pixel prologue) - push() hands back the pair enqueued
@@ -875,6 +874,84 @@ def test_overlapped_pair_renderer_equals_render_pair(dev, kernel_exp, S, H, W, n
         ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
         for k, t in zip(("flow_mix", "frame_mix", "fill_mask"), out):
             assert bits_equal(N(t), ref[k]) == 0, k
+
+
+@pytest.mark.parametrize("merge_in_launch", [False, True])
+def test_overlapped_renderer_consumes_the_object_mask_at_push(dev, kernel_exp, merge_in_launch):
+    """A streaming caller that keeps ONE object-mask tensor (and one image / stack tensor) and rewrites it for every pair: the deferred merge of a
+    pair - one push() later, two with merge_in_launch - reads the mask from the slot's own mask quads (MpfMergeArgs.obj_mask_stride = 4), so the
+    results equal render_pair's on every pair.  (Before round 5 the merge read the caller's tensor: this test then merges pair i with mask i+1 / i+2.)"""
+    from mpiflow_amd import pipeline
+    o = kernel_exp
+    S, H, W, n = 8, 32, 48, 5
+    ovl = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=merge_in_launch)
+    om_buf = torch.empty((H, W), device=dev)
+    mpi_buf, img_buf = torch.empty((S, 4, H, W), device=dev), torch.empty((3, H, W), device=dev)
+    items, got = [], []
+    for i in range(n):
+        inp = _inputs(S, H, W, seed=300 + i, kind="white" if i % 2 else "smooth")
+        inp["obj_mask"] = np.roll(inp["obj_mask"], 5 * i, axis=1).copy()          # a different mask per pair
+        G_cam, G_dyn = _poses(o, 70 + i)
+        items.append((inp, G_cam, G_dyn))
+        om_buf.copy_(T(inp["obj_mask"], dev)); mpi_buf.copy_(T(inp["mpi"], dev)); img_buf.copy_(T(inp["image"], dev))
+        done = ovl.push(mpi_buf, img_buf, ovl.prepare(inp["K"], inp["disparity"], [G_cam, G_dyn]), om_buf)
+        om_buf.fill_(float("nan"))                                               # consumed: whatever happens to the caller's tensor now is none of the renderer's business
+        if done is not None:
+            got.append(done)
+    got += ovl.flush()
+    assert len(got) == n
+    for (inp, G_cam, G_dyn), out in zip(items, got):
+        ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], inp["disparity"], inp["K"], G_cam, G_dyn)
+        for k, t in zip(("flow_mix", "frame_mix", "fill_mask"), out):
+            assert bits_equal(N(t), ref[k]) == 0, k
+        # the three products are views of one buffer (ops.pair_slab): they can leave the GPU in one copy
+        assert out[0].untyped_storage().data_ptr() == out[1].untyped_storage().data_ptr() == out[2].untyped_storage().data_ptr()
+
+
+def test_folded_merge_rejects_overlapping_buffers(dev):
+    """mpf_warp_views_blend_next_merge_prev validates what makes the folded merge race-free: the merged pair's flows are disjoint from the flows the
+    launch writes or exactly its two pose planes, its outputs overlap nothing the launch reads or writes, its object mask is not a buffer the
+    launch writes (other than the .x of d_quads_next at stride 4)."""
+    import ctypes
+    from mpiflow_amd import _lib, ops, pipeline
+    S, H, W = 4, 16, 32
+    inp = _inputs(S, H, W, seed=9)
+    r = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=True)
+    import random
+    from mpiflow_amd import host_math
+    rng = random.Random(1)
+    prep = r.prepare(inp["K"], inp["disparity"], [host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng), host_math.generate_random_pose(0.15, rng=rng)])
+    mpi, img, om = T(inp["mpi"], dev), T(inp["image"], dev), T(inp["obj_mask"], dev)
+    for _ in range(3):
+        r.push(mpi, img, prep, om)
+    torch.cuda.synchronize()
+    a, b = r.slots[0], r.slots[1]
+
+    def launch(mp):
+        return _lib.load().mpf_warp_views_blend_next_merge_prev(
+            ctypes.c_void_p(a["rgba"].data_ptr()), (_lib.MpfWarpView * 2)(*[_lib.MpfWarpView(prep["warp"][v].data_ptr(), a["quads"][v].data_ptr(), a["views"][v]["rgb"].data_ptr(), None,
+                                                                                                  a["views"][v]["objmask"].data_ptr(), None, None) for v in range(2)]), 2,
+            ctypes.c_void_p(mpi.data_ptr()), ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(prep["blend"].data_ptr()), 2, 200.0, ctypes.c_void_p(b["rgba"].data_ptr()),
+            ctypes.c_void_p(b["flows"].data_ptr()), ctypes.c_void_p(b["src_u8"].data_ptr()), ctypes.c_void_p(om.data_ptr()), ctypes.c_void_p(b["quads"][0].data_ptr()),
+            ctypes.c_void_p(b["quads"][1].data_ptr()), None, S, H, W, ctypes.byref(mp) if mp is not None else None, None)
+    out = ops.pair_slab(H, W, dev)[1]
+    v = b["views"]
+    good = ops.merge_args(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"][0], b["flows"][1], b["quads"][0], 0.99, out, obj_mask_stride=4)
+    assert launch(good) == 0
+    torch.cuda.synchronize()
+    # flows that straddle the two pose planes of d_flows_next: neither disjoint nor plane-aligned
+    bad = ops.merge_args(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"].reshape(-1)[H * W:3 * H * W].view(2, H, W), b["flows"][1], b["quads"][0], 0.99, out,
+                         obj_mask_stride=4)
+    assert launch(bad) == 10001 and b"flows" in _lib.load().mpf_last_error()
+    # an output that is the stack being written / the source frame being written
+    for victim in (b["rgba"].reshape(-1)[:2 * H * W].view(H, W, 2), b["quads"][1].reshape(-1)[:2 * H * W].view(H, W, 2)):
+        bad = ops.merge_args(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"][0], b["flows"][1], b["quads"][0], 0.99, (victim, out[1], out[2]), obj_mask_stride=4)
+        assert launch(bad) == 10001 and b"overlaps" in _lib.load().mpf_last_error()
+    # the object mask as a plain map that IS a buffer the launch writes
+    bad = ops.merge_args(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"][0], b["flows"][1], b["quads"][1].reshape(-1)[:H * W].view(H, W), 0.99, out)
+    assert launch(bad) == 10001 and b"object mask" in _lib.load().mpf_last_error()
+    with pytest.raises(AssertionError):
+        ops.merge_args(v[0]["rgb"], v[1]["rgb"], v[0]["objmask"], v[1]["objmask"], b["flows"][0], b["flows"][1], b["quads"][0], 0.99, (out[0], out[1].float(), out[2]), obj_mask_stride=4)
 
 
 @pytest.mark.parametrize("S,H,W", [(8, 32, 48), (20, 23, 37), (1, 16, 24), (2, 9, 70), (3, 1, 64), (6, 64, 1), (33, 64, 65), (272, 8, 64)])

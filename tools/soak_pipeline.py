@@ -66,8 +66,7 @@ for case in range(n_cases):
                 got.append((r, c))
             for mpi, img, om, disp, Gc, Gd in pairs:
                 take(ovl.push(mpi, img, ovl.prepare(K, pd, [Gc, Gd]), om, moving=(disp, om) if chain_mode else None))
-            last = ovl.flush()
-            for d in (last if mil else [last]):
+            for d in ovl.flush():
                 take(d)
             torch.cuda.synchronize()
             ok = len(got) == n

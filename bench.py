@@ -723,6 +723,8 @@ def main():
         if a.mode == "batch":
             out["config"]["batch_images"] = a.batch
             out["config"]["pairs_rank0_per_step"] = len(order)
+        if getattr(wl, "r", None) is not None and hasattr(wl.r, "close"):
+            wl.r.close()                                     # a CU-masked side stream (--chain-cu-stride)
         del wl
         torch.cuda.empty_cache()
         if world == 1 and not a.no_sub and a.mode == "resident":
@@ -770,8 +772,6 @@ def main():
             out["cpu_baseline"]["reference_measured_in_build_container"] = \
                 "reference render_3dphoto_dynamic (the same full dynamic pair) 64x640x960: 104.8 s on 8 threads (tests/golden/make_golden.py)"
         print(json.dumps(out))
-    if getattr(wl, "r", None) is not None and hasattr(wl.r, "close"):
-        wl.r.close()                                         # a CU-masked side stream (--chain-cu-stride)
     if masked_main is not None:
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.default_stream(dev))

@@ -889,6 +889,194 @@ MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restric
     }
 }
 
+// WAVE-PRIVATE footprints (round 5; mpf_tune("planar_lds", 2)): the 32 x 8 tile as four 32 x 2 wave strips.  Every wave computes the boxes of ITS strip
+// (<= 48 x 6 texels), stages them into its own slab of LDS and reads its taps from there: the LDS traffic of a wave is ordered by the hardware, so
+// the plane loop needs NO workgroup barrier - what the workgroup-wide box pays once per plane.  The price: the four strips' row halos overlap
+// (4 x (2 + 3) source rows instead of 8 + 3), i.e. up to 20 instead of 12 coalesced dword loads per lane and plane.  Same arithmetic, bit-identical.
+#define MPF_WT_ROWS 6
+#define MPF_WT_TEXELS (MPF_LT_PITCH * MPF_WT_ROWS)     // 288 texels = 4.5 passes of 64 lanes
+#define MPF_WT_PASSES 5
+#define MPF_WT_MAXS 96
+
+template <bool HAS_MASK, int NL, bool KS, bool AUX>
+MPF_DEV void mpf_wcw_body(const float *__restrict__ quads, const float *__restrict__ params, int S, int H, int W, float *__restrict__ rgb_out,
+                          float *__restrict__ depth_out, float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out,
+                          const unsigned tile, float4 *s_tex, uint2 *s_box, const MpfPlanarSrc *planar_src)
+{
+    constexpr int TW = 32, TH = 8;
+    const int64_t N = (int64_t)H * W;
+    const unsigned tiles_x = (W + TW - 1) / TW;
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = tx0 + (int)(tid % TW);
+    const int y = ty0 + (int)(tid / TW);
+    const bool active = (x < W) && (y < H);
+    MpfConsts c;
+    c.fx = (float)min(x, W - 1); c.fy = (float)min(y, H - 1);
+    c.W = W; c.H = H; c.Wf = (float)W; c.Hf = (float)H;
+    c.halfW = (float)W * 0.5f; c.halfH = (float)H * 0.5f;
+    c.rhalfW = 1.0f / c.halfW; c.rhalfH = 1.0f / c.halfH;
+    c.maxx = (float)(W - 1); c.maxy = (float)(H - 1);
+    c.row_bytes = (unsigned)W * 16u;
+    mpf_consts_pose(c, (MpfConstParams)params);
+    const char *qbase = reinterpret_cast<const char *>(quads);
+    char *lds = reinterpret_cast<char *>(s_tex) + wave * (2 * MPF_WT_TEXELS * 16);          // this wave's two buffers
+    uint2 *wbox = s_box + wave * MPF_WT_MAXS;
+
+    // ---- footprint boxes of this WAVE's strip (rows 2 wave, 2 wave + 1 of the tile) on every plane
+    int unfit = 0;
+    {
+        const int xa = min(tx0, W - 1), xb = min(tx0 + TW - 1, W - 1);
+        const int ya = min(ty0 + 2 * (int)wave, H - 1), yb = min(ty0 + 2 * (int)wave + 1, H - 1);
+        for (unsigned e = lane; e < (unsigned)S * 4u; e += 64u) {
+            const unsigned sp = e >> 2, k = e & 3u;
+            MpfConsts cc = c;
+            cc.fx = (float)((k & 1u) ? xb : xa);
+            cc.fy = (float)((k & 2u) ? yb : ya);
+            float w0, w1, w2, w3, X, Y, Z, qz;
+            int cx, cy;
+            mpf_geom_core<KS, false>(params, (int)sp, cc, w0, w1, w2, w3, X, Y, Z, cx, cy, qz);
+            int xmn = cx, xmx = cx, ymn = cy, ymx = cy;
+            float zmn = qz;
+#pragma unroll
+            for (int m = 1; m <= 2; m <<= 1) {          // the 4 corners sit in 4 adjacent lanes
+                xmn = min(xmn, __shfl_xor(xmn, m)); xmx = max(xmx, __shfl_xor(xmx, m));
+                ymn = min(ymn, __shfl_xor(ymn, m)); ymx = max(ymx, __shfl_xor(ymx, m));
+                zmn = fminf(zmn, __shfl_xor(zmn, m));
+            }
+            xmn = max(xmn - 1, 0); xmx = min(xmx + 2, W);
+            ymn = max(ymn - 1, 0); ymx = min(ymx + 2, H);
+            const int bw = xmx - xmn + 1, bh = ymx - ymn + 1;
+            const bool ok = (bw <= MPF_LT_PITCH) && (bh <= MPF_WT_ROWS) && (zmn > 0.0625f);
+            unfit |= ok ? 0 : 1;
+            if (k == 0)
+                wbox[sp] = make_uint2((unsigned)ymn * (unsigned)W + (unsigned)xmn, ((unsigned)ymn * MPF_LT_PITCH + (unsigned)xmn) | ((unsigned)bh << 24));
+        }
+    }
+    // a strip whose footprint does not fit on some plane: the whole workgroup takes the gather path for this tile (uniform; the only barrier)
+    if (__syncthreads_or(unfit | ((H >= 65536) | (W >= 65536)))) {
+        mpf_wc2_body<HAS_MASK, NL, TW, TH, KS, false, 0, AUX, true>(reinterpret_cast<const float *>(planar_src->rgb), quads, params, S, H, W, rgb_out, depth_out, om_out,
+                                                                    tgt_mask_out, u8_out, tile, planar_src);
+        return;
+    }
+    auto box = [&](int s) -> MpfBox {
+        const uint2 b = wbox[s];
+        const unsigned b0 = __builtin_amdgcn_readfirstlane(b.x), b1 = __builtin_amdgcn_readfirstlane(b.y);
+        MpfBox r;
+        r.goff = b0 * 16u;
+        r.lorg = (b1 & 0xFFFFFFu) * 16u;
+        r.h = b1 >> 24;
+        return r;
+    };
+    unsigned gconst[MPF_WT_PASSES];                          // a lane's staging slots: texel idx = lane + 64 k of the 48-pitch box raster
+#pragma unroll
+    for (int k = 0; k < MPF_WT_PASSES; ++k) {
+        const unsigned idx = lane + 64u * k;
+        gconst[k] = ((idx / MPF_LT_PITCH) * (unsigned)W + (idx % MPF_LT_PITCH)) * 4u;      // byte offset inside one channel plane
+    }
+    mpf_v4u L[MPF_WT_PASSES];
+    const unsigned chan_bytes = (unsigned)N * 4u;
+    auto issue = [&](int s, const MpfBox &b) {
+        const bool last = s + 1 == S;
+        __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(planar_src->rgb + (size_t)s * planar_src->rgb_stride), 0,
+                                                                       last ? planar_src->rgb_last : 0xFFFFFFFCu, 0x00020000);
+        __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(planar_src->sigma + (size_t)s * planar_src->sigma_stride), 0,
+                                                                       last ? planar_src->sigma_last : 0xFFFFFFFCu, 0x00020000);
+        const unsigned g4 = b.goff >> 2;
+#pragma unroll
+        for (int k = 0; k < MPF_WT_PASSES; ++k)
+            if (64u * k < MPF_LT_PITCH * b.h) {                // wave-uniform: passes past the box's last row are skipped
+                L[k].x = __builtin_amdgcn_raw_buffer_load_b32(rc, gconst[k], g4, 0);
+                L[k].y = __builtin_amdgcn_raw_buffer_load_b32(rc, gconst[k], g4 + chan_bytes, 0);
+                L[k].z = __builtin_amdgcn_raw_buffer_load_b32(rc, gconst[k], g4 + 2u * chan_bytes, 0);
+                L[k].w = __builtin_amdgcn_raw_buffer_load_b32(rg, gconst[k], g4, 0);
+            }
+    };
+    auto stage = [&](const MpfBox &b, const unsigned buf) {
+#pragma unroll
+        for (int k = 0; k < MPF_WT_PASSES; ++k)
+            if (64u * k < MPF_LT_PITCH * b.h && (k < MPF_WT_PASSES - 1 || lane + 64u * k < MPF_WT_TEXELS))
+                *reinterpret_cast<mpf_v4u *>(lds + buf * (MPF_WT_TEXELS * 16) + (lane + 64u * k) * 16u) = L[k];
+    };
+    auto taps = [&](const MpfBox &b, const MpfGeomL &g, const unsigned buf, MpfRaw4 &r) {
+        const char *a = lds + ((g.t << 4) + (buf * (MPF_WT_TEXELS * 16) - b.lorg));
+        r.t00 = *reinterpret_cast<const float4 *>(a);
+        r.t01 = *reinterpret_cast<const float4 *>(a + 16);
+        r.t10 = *reinterpret_cast<const float4 *>(a + MPF_LT_PITCH * 16);
+        r.t11 = *reinterpret_cast<const float4 *>(a + MPF_LT_PITCH * 16 + 16);
+    };
+
+    MpfConstParams cparams = (MpfConstParams)params;
+    MpfAcc<NL, HAS_MASK, AUX> A;
+    A.init();
+    MpfGeomL ga, gb;
+    MpfRaw4 ra, rb;
+    MpfBox bA = box(0), bB = box(min(1, S - 1));
+    issue(0, bA);
+    stage(bA, 0u);
+    if (S > 1) issue(1, bB);
+    A.nvalid += mpf_geom_l<KS, AUX>(cparams, 0, c, ga);
+    if (HAS_MASK) ra.mq = *reinterpret_cast<const float4 *>(qbase + ga.b00);
+    // no barrier anywhere below: a wave reads only what it wrote itself, and its LDS operations complete in order
+#define MPF_WCW_STEP(s_, G_, GN_, B_, BN_, BF_, BUF_, R_, RN_)                                                        \
+    {                                                                                                                 \
+        taps(B_, G_, BUF_, R_);                                                                                       \
+        A.nvalid += mpf_geom_l<KS, AUX>(cparams, (s_) + 1, c, GN_);                                                   \
+        if (HAS_MASK) RN_.mq = *reinterpret_cast<const float4 *>(qbase + GN_.b00);                                    \
+        const float dist_ = mpf_norm3_nr(GN_.X - G_.X, GN_.Y - G_.Y, GN_.Z - G_.Z);                                   \
+        A.step(G_, R_, dist_, (s_));                                                                                  \
+        stage(BN_, 1u - (BUF_));                                                                                      \
+        if ((s_) + 2 < S) { BF_ = box((s_) + 2); issue((s_) + 2, BF_); }                                              \
+    }
+    int s = 0;
+    while (s + 2 < S) {
+        MPF_WCW_STEP(s, ga, gb, bA, bB, bA, 0u, ra, rb)
+        MPF_WCW_STEP(s + 1, gb, ga, bB, bA, bB, 1u, rb, ra)
+        s += 2;
+    }
+    if (s + 1 < S) {
+        MPF_WCW_STEP(s, ga, gb, bA, bB, bA, 0u, ra, rb)
+        taps(bB, gb, 1u, rb);
+        A.step(gb, rb, 1e3f, s + 1);
+    } else {
+        taps(bA, ga, 0u, ra);
+        A.step(ga, ra, 1e3f, s);
+    }
+#undef MPF_WCW_STEP
+    if (active) {
+        const int64_t n = (int64_t)y * W + x;
+        const float fr = A.c0.final(), fg = A.c1.final(), fb = A.c2.final();
+        rgb_out[n] = fr;
+        rgb_out[N + n] = fg;
+        rgb_out[2 * N + n] = fb;
+        if (u8_out) { u8_out[3 * n] = mpf_to_u8(fb); u8_out[3 * n + 1] = mpf_to_u8(fg); u8_out[3 * n + 2] = mpf_to_u8(fr); }
+        if (AUX && depth_out) depth_out[n] = A.cd.final() / (A.cw.final() + 1e-5f);
+        if (HAS_MASK) om_out[n] = A.co.final();
+        if (AUX && tgt_mask_out) tgt_mask_out[n] = A.nvalid;
+    }
+}
+
+template <bool HAS_MASK, int NL>
+__global__ void __launch_bounds__(256, 4)
+k_warp_composite_planar_wave(const MpfPlanarSrc src, const float *__restrict__ quads, const float *__restrict__ params,
+                             int S, int H, int W, float *__restrict__ rgb_out, float *__restrict__ depth_out,
+                             float *__restrict__ om_out, float *__restrict__ tgt_mask_out, uint8_t *__restrict__ u8_out)
+{
+    constexpr int TW = 32, TH = 8;
+    const unsigned tile = mpf_strip_order(mpf_xcd_remap(blockIdx.x, gridDim.x), (W + TW - 1) / TW, (H + TH - 1) / TH);
+    const MpfConstParams cp = (MpfConstParams)params;
+    const bool pinhole = (cp[1] == 0.0f) & (cp[3] == 0.0f) & (cp[6] == 0.0f) & (cp[7] == 0.0f) & (cp[8] == 1.0f);
+    const bool aux = (depth_out != nullptr) | (tgt_mask_out != nullptr);
+    __shared__ float4 s_tex[4 * 2 * MPF_WT_TEXELS];
+    __shared__ uint2 s_box[4 * MPF_WT_MAXS];
+    if (pinhole && !aux)
+        mpf_wcw_body<HAS_MASK, NL, true, false>(quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, s_tex, s_box, &src);
+    else if (pinhole)
+        mpf_wcw_body<HAS_MASK, NL, true, true>(quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, s_tex, s_box, &src);
+    else
+        mpf_wcw_body<HAS_MASK, NL, false, true>(quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, s_tex, s_box, &src);
+}
+
 template <bool HAS_MASK, int NL>
 __global__ void __launch_bounds__(256, 4)
 k_warp_composite_lds(const float *__restrict__ rgba, const MpfViewSet vs, const unsigned V, int S, int H, int W)
@@ -931,7 +1119,8 @@ k_warp_composite_planar_lds(const MpfPlanarSrc src, const float *__restrict__ qu
         mpf_wcl_body<HAS_MASK, NL, false, true, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, s_tex, s_box, &src);
 }
 
-static int g_planar_lds = 1;        // mpf_tune("planar_lds", 0 | 1): Stage B on the reference's channel-planar tensors through LDS-staged footprints (1) or gathers (0)
+static int g_planar_lds = 1;        // mpf_tune("planar_lds", 0 | 1 | 2): Stage B on the reference's channel-planar tensors by gathers (0), through LDS-staged
+                                    // footprints of the workgroup's tile (1) or of every wave's own strip, no barrier in the plane loop (2)
 
 static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = gather shapes, 20 = LDS-staged footprints
 
@@ -999,6 +1188,11 @@ static int launch_planar(const MpfPlanarSrc &src, const float *quads, const floa
                          float *tm, uint8_t *u8, hipStream_t st)
 {
     const unsigned tiles = ((W + 31) / 32) * ((H + 7) / 8);
+    if (g_planar_lds == 2 && S <= MPF_WT_MAXS) {
+        if (quads) hipLaunchKernelGGL((k_warp_composite_planar_wave<true, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
+        else hipLaunchKernelGGL((k_warp_composite_planar_wave<false, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
+        return mpf_launch_status("k_warp_composite_planar_wave");
+    }
     if (g_planar_lds && S <= MPF_LT_MAXS && S < 256) {
         if (quads) hipLaunchKernelGGL((k_warp_composite_planar_lds<true, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
         else hipLaunchKernelGGL((k_warp_composite_planar_lds<false, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
@@ -1834,7 +2028,7 @@ extern "C" int mpf_tune(const char *key, int value)
 {
     if (key && !strcmp(key, "sbf_px")) { g_sbf_px = value; return 0; }
     if (key && !strcmp(key, "stage_b")) { g_stage_b_variant = value; return 0; }
-    if (key && !strcmp(key, "planar_lds")) { g_planar_lds = value ? 1 : 0; return 0; }
+    if (key && !strcmp(key, "planar_lds")) { g_planar_lds = (value < 0 || value > 2) ? 1 : value; return 0; }
     if (key && !strcmp(key, "ovl_depth")) { g_ovl_depth = (value == 8) ? 8 : 4; return 0; }
     if (key && !strcmp(key, "ovl_ablate")) { g_ovl_ablate = value; return 0; }
     if (key && !strcmp(key, "view_shift")) { g_view_shift = value < 0 ? 0 : value; return 0; }

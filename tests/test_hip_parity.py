@@ -977,7 +977,7 @@ def test_planar_and_split_stage_b_equal_the_interleaved_kernel(dev, kernel_exp, 
         q = ops.mask_quads(T(inp["obj_mask"], dev), complement=comp)
         from mpiflow_amd import _lib
         try:
-            for planar_lds in (1, 0):          # LDS-staged footprints (coalesced dword loads, the default) / 8-byte tap-pair gathers
+            for planar_lds in (1, 0, 2):       # LDS-staged footprints of the tile (the default) / 8-byte tap-pair gathers / wave-private footprints, no barrier
                 _lib.check(_lib.load().mpf_tune(b"planar_lds", planar_lds))
                 for quads in (q, None):
                     a = ops.warp_composite(stack, quads, Hst, k_inv, G, d, interleaved=False)

@@ -43,7 +43,7 @@ for case in range(n_cases):
         for aux in (True, False):
             ref = ops.warp_composite(inter, quads, H_st, k_inv, G, d, interleaved=2, want_depth=aux, want_tgt_mask=aux)
             outs = {}
-            for lds in (1, 0):
+            for lds in (1, 0, 2):
                 _lib.check(lib.mpf_tune(b"planar_lds", lds))
                 outs[(lds, "stack")] = ops.warp_composite(stack, quads, H_st, k_inv, G, d, interleaved=False, want_depth=aux, want_tgt_mask=aux)
                 outs[(lds, "split")] = ops.warp_composite_split(rgb3, sig1, quads, H_st, k_inv, G, d, want_depth=aux, want_tgt_mask=aux)

@@ -35,7 +35,7 @@ extern "C" {
                              round 4 (401): + mpf_moving_object_chain, mpf_warp_views_blend_next_merge_prev, mpf_stream_create_cu_subset / _destroy,
                              mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6;
                              round 5 (501): + the parity-grade producer engine mpf_pconv, mpf_pfmn_input, mpf_pencoder_input, mpf_pbilinear2x, mpf_pper_plane,
-                             mpf_pplane_masks, mpf_pmaxpool3x3s2; MpfMergeArgs + obj_mask_stride, mpf_merge_ex */
+                             mpf_pplane_masks, mpf_pmaxpool3x3s2; MpfMergeArgs + obj_mask_stride, mpf_merge_ex, mpf_src_flow_hard */
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)
@@ -123,6 +123,12 @@ int mpf_warp_composite_split(const float *d_rgb_S3HW, const float *d_sigma_SHW, 
  * render_novel_view_dynamic needs besides the warp (utils/utils.py:340-348).  d_params as for mpf_src_blend_flow (S*P records);
  * d_flows [P,2,H,W], clipped to +-flow_clip when flow_clip > 0.  Same arithmetic as mpf_src_blend_flow's flows: bit-identical. */
 int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int P, int S, int H, int W, float flow_clip, float *d_flows, void *stream);
+/* hard_flow = True (utils/mpi/mpi_rendering.py:126-130): per pixel the flow of the plane with the largest rendering weight (the first one on ties, as
+ * torch.argmax) instead of the weighted sum - one pass over the sigma planes, nothing per-plane materialised.  d_sigma: plane s at d_sigma + s *
+ * plane_stride floats (H*W for a bare [S,H,W] tensor; 4*H*W with d_sigma = stack + 3*H*W for the [S,4,H,W] stack).  Weights with mpf_src_blend_flow's
+ * arithmetic; equals mpf_homography_flow + mpf_volume_render(hard) bit for bit. */
+int mpf_src_flow_hard(const float *d_sigma, int64_t plane_stride, const float *d_params, int P, int S, int H, int W, float flow_clip, float *d_flows,
+                      void *stream);
 
 /* Stage B for SEVERAL views of one stack in one launch.  The reference renders two poses of every stack
  * (utils/utils.py:210-222 with obj_mask / cam_ext and :224-236 with 1 - obj_mask / cam_ext_dynamic) and `repeat` such

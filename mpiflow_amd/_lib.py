@@ -83,6 +83,7 @@ SIGNATURES = {
     "mpf_warp_composite": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpf_warp_composite_split": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpf_src_flow": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "mpf_src_flow_hard": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "mpf_warp_composite_views": (c_i, [c_p, c_i, ctypes.POINTER(MpfWarpView), c_i, c_i, c_i, c_i, c_p]),
     "mpf_warp_views_and_blend_next": (c_i, [c_p, ctypes.POINTER(MpfWarpView), c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "mpf_warp_views_blend_next_merge_prev": (c_i, [c_p, ctypes.POINTER(MpfWarpView), c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i,

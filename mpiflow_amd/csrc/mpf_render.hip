@@ -2008,6 +2008,91 @@ extern "C" int mpf_warp_views_blend_next_merge_prev(const float *d_rgba, const M
 #undef MPF_OVL
 }
 
+// hard_flow = True (utils/mpi/mpi_rendering.py:126-130): the flow of the arg-max-weight plane instead of the weighted sum.  One pass over the
+// sigma planes: the weights w_s = Tacc_s (1 - T_s) with the IEEE sequence of mpf_sbf_body (so the arg max is the reference's), the per-plane flow of
+// every pose in registers, the first maximal weight wins (torch.argmax returns the first maximal index).  Nothing per-plane is materialised - the
+// generic path (mpf_homography_flow + mpf_volume_render(hard)) writes and re-reads S x 2 x H x W flows per pose.
+template <int P>
+__global__ void __launch_bounds__(256)
+k_src_flow_hard(const float *__restrict__ sigma, const int64_t plane_stride, const float *__restrict__ params_global, int S, int H, int W, float flow_clip,
+                float *__restrict__ flows)
+{
+    const MpfConstParams params = (MpfConstParams)params_global;
+    constexpr int RS = MPF_PLANE_RECORD * P;
+    const int64_t N = (int64_t)H * W;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float fx = (float)(n % W), fy = (float)(n / W);
+    float ray[3], cur[3];
+    ray[0] = mpf_row3_xy1(params[0], params[1], params[2], fx, fy);               // mpi_rendering.py:234
+    ray[1] = mpf_row3_xy1(params[3], params[4], params[5], fx, fy);
+    ray[2] = mpf_row3_xy1(params[6], params[7], params[8], fx, fy);
+    const float d0 = params[MPF_PARAMS_HEADER + 9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cur[c] = ray[c] * d0;                             // :235-236
+    double acc = 1.0;
+    float best = -INFINITY, bf[P][2];
+#pragma unroll
+    for (int p = 0; p < P; ++p) bf[p][0] = bf[p][1] = 0.0f;
+    constexpr int D = 4;                                                          // sigma loads in flight
+    for (int s0 = 0; s0 < S; s0 += D) {
+        float sg[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) sg[k] = sigma[(int64_t)min(s0 + k, S - 1) * plane_stride + n];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int s = s0 + k;
+            if (s >= S) break;
+            const MpfConstParams rec = params + MPF_PARAMS_HEADER + RS * s;
+            const bool last = (s + 1 == S);
+            const float dn = last ? 0.0f : rec[RS + 9];
+            const float nx = ray[0] * dn, ny = ray[1] * dn, nz = ray[2] * dn;
+            const float dist = last ? 1e3f : mpf_norm3_nr(nx - cur[0], ny - cur[1], nz - cur[2]);
+            cur[0] = nx; cur[1] = ny; cur[2] = nz;
+            const float Tr = mpf_expf_fast(-sg[k] * dist);
+            const float alpha = 1.0f - Tr;
+            const float tacc = (float)acc;
+            const float w = tacc * alpha;
+            acc *= (double)(Tr + 1e-6f);
+            if (w > best) {                                                        // the FIRST maximal weight
+                best = w;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const MpfConstParams h = rec + MPF_PLANE_RECORD * p;
+                    const float qx = mpf_row3_xy1(h[0], h[1], h[2], fx, fy);
+                    const float qy = mpf_row3_xy1(h[3], h[4], h[5], fx, fy);
+                    const float qz = mpf_row3_xy1(h[6], h[7], h[8], fx, fy);
+                    const float rz = mpf_rcp_nr(qz);
+                    bf[p][0] = mpf_div_nr(qx, qz, rz) - fx;
+                    bf[p][1] = mpf_div_nr(qy, qz, rz) - fy;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float f = bf[p][k];
+            if (flow_clip > 0.0f) f = fminf(fmaxf(f, -flow_clip), flow_clip);       // utils/utils.py:348
+            flows[((int64_t)p * 2 + k) * N + n] = f;
+        }
+}
+
+extern "C" int mpf_src_flow_hard(const float *d_sigma, int64_t plane_stride, const float *d_params, int P, int S, int H, int W, float flow_clip, float *d_flows,
+                                 void *stream)
+{
+    MPF_REQUIRE(d_sigma && d_params && d_flows, "mpf_src_flow_hard: null pointer");
+    MPF_REQUIRE(P >= 1 && P <= 2, "mpf_src_flow_hard: P must be 1 or 2 (got %d)", P);
+    MPF_REQUIRE(S >= 1 && S < 4096 && H >= 1 && W >= 1, "mpf_src_flow_hard: bad shape S=%d H=%d W=%d", S, H, W);
+    const int64_t N = (int64_t)H * W;
+    MPF_REQUIRE(plane_stride >= N, "mpf_src_flow_hard: plane_stride (floats between consecutive sigma planes) must be at least H*W");
+    const dim3 grid((unsigned)((N + 255) / 256));
+    if (P == 1) hipLaunchKernelGGL((k_src_flow_hard<1>), grid, dim3(256), 0, (hipStream_t)stream, d_sigma, plane_stride, d_params, S, H, W, flow_clip, d_flows);
+    else hipLaunchKernelGGL((k_src_flow_hard<2>), grid, dim3(256), 0, (hipStream_t)stream, d_sigma, plane_stride, d_params, S, H, W, flow_clip, d_flows);
+    return mpf_launch_status("k_src_flow_hard");
+}
+
 extern "C" int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int P, int S, int H, int W, float flow_clip, float *d_flows, void *stream)
 {
     MPF_REQUIRE(d_sigma_SHW && d_params && d_flows, "mpf_src_flow: null pointer");

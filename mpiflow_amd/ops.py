@@ -198,6 +198,26 @@ def src_flow(sigma_S1HW, K_inv, depth_S, homs_tgt_src, flow_clip=200.0):
 
 
 @_on_device
+def src_flow_hard(sigma_or_stack, K_inv, depth_S, homs_tgt_src, flow_clip=200.0):
+    """hard_flow=True in one pass (mpf_src_flow_hard): [P,2,H,W] flows of the arg-max-weight plane.  sigma_or_stack: a bare sigma tensor [S,1,H,W] | [S,H,W],
+    or the [S,4,H,W] stack (its sigma planes are read in place)."""
+    lib = _lib.load()
+    t = _dev(sigma_or_stack, "sigma stack")
+    S, H, W = t.shape[0], t.shape[-2], t.shape[-1]
+    N = H * W
+    if t.dim() == 4 and t.shape[1] == 4:
+        ptr, stride = t.data_ptr() + 3 * N * 4, 4 * N
+    else:
+        t = t.reshape(S, H, W)
+        ptr, stride = t.data_ptr(), N
+    params, P = blend_flow_params(K_inv, depth_S, homs_tgt_src)
+    dparams = upload_params(params, t.device)
+    flows = torch.empty((P, 2, H, W), dtype=_f32, device=t.device)
+    _lib.check(lib.mpf_src_flow_hard(ctypes.c_void_p(ptr), stride, _ptr(dparams), P, S, H, W, float(flow_clip), _ptr(flows), _stream()), "mpf_src_flow_hard")
+    return flows
+
+
+@_on_device
 def warp_composite_views(rgba, views, interleaved=2):
     """Stage B for several views of one interleaved stack in ONE launch (mpf_warp_composite_views): the stack crosses the HBM
     interface once instead of once per view.  views: list of dicts(dparams=, quads= | None, out=dict(rgb, objmask?, depth?,

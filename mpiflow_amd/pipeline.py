@@ -438,13 +438,18 @@ class OverlappedPairRenderer(_PairHostSide):
         return None if self._pending is None else self._pending["slot"]
 
 
-def hard_flows(mpi_S4HW, disparity_S, K, poses):
-    """hard_flow=True (reference utils/mpi/mpi_rendering.py:126-130): the flow of the arg-max-weight plane instead of the
-    weighted sum.  Off the default path; computed with the generic kernels (per-plane flows are materialised)."""
+def hard_flows(mpi_S4HW, disparity_S, K, poses, generic=False):
+    """hard_flow=True (reference utils/mpi/mpi_rendering.py:126-130): the flow of the arg-max-weight plane instead of the weighted sum, for every pose,
+    clipped to +-200 (utils/utils.py:348).  One pass over the stack's sigma planes for all poses (mpf_src_flow_hard, two poses per launch);
+    generic=True: the materialised form behind the reference's own functions (per-plane flows written and re-read) - same bits, kept as the witness."""
     S, _, H, W = mpi_S4HW.shape
     dev = mpi_S4HW.device
     k_inv = host_math.k_inverse(K)
     d = host_math.plane_depths(disparity_S)
+    if not generic:
+        homs = [host_math.homographies(G, k_inv, K, d)[0] for G in poses]
+        out = [ops.src_flow_hard(mpi_S4HW, k_inv, d, torch.stack(homs[i:i + 2]), flow_clip=200.0) for i in range(0, len(homs), 2)]
+        return torch.cat(out)
     xyz = ops.src_xyz(k_inv, d, H, W, dev)
     out = []
     for G in poses:

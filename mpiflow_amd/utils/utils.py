@@ -138,11 +138,8 @@ def render_novel_view_dynamic(obj_mask, mpi_all_rgb_src, mpi_all_sigma_src, disp
     quads = ops.mask_quads(obj_mask.reshape(H, W).to(dev, torch.float32), False)
     v = ops.warp_composite_split(rgb_S3HW, sigma_S1HW, quads, H_st, K_src_inv, G_tgt_src, d)
     if hard_flow:
-        hs = homography_sampler or HomographySample(H, W, dev)
-        xyz_src = mpi_rendering.get_src_xyz_from_plane_disparity(hs.meshgrid, disparity_all_src, K_src_inv)
-        flow_s = ops.homography_flow(H_ts, H, W, dev).permute(0, 3, 1, 2).unsqueeze(0)
-        flow = mpi_rendering.plane_volume_rendering_flow(mpi_all_sigma_src.to(torch.float32), flow_s, xyz_src, False, hard_flow=True)
-        flow = torch.clip(flow, -200, 200)
+        # :126-130 in one pass over the sigma tensor (mpf_src_flow_hard): the arg-max-weight plane's flow, nothing per-plane materialised
+        flow = ops.src_flow_hard(sigma_S1HW.to(torch.float32), K_src_inv, d, H_ts.unsqueeze(0), flow_clip=200.0)[0:1]
     else:
         # source-frame weights: the Stage A+C kernel's flow-only body on the sigma tensor
         flow = ops.src_flow(sigma_S1HW, K_src_inv, d, H_ts.unsqueeze(0), flow_clip=200.0)[0:1]

@@ -543,6 +543,30 @@ def test_hard_flow_entry_point(dev, oracle):
           % (int(bad.sum()), H * W, int(near_tie.sum())))
 
 
+@pytest.mark.parametrize("S,H,W", [(8, 32, 48), (20, 23, 37), (1, 9, 11), (64, 40, 72), (5, 17, 300)])
+def test_fused_hard_flow_equals_the_materialised_form(dev, S, H, W):
+    """mpf_src_flow_hard (one pass over the sigma planes, nothing per-plane materialised) == the reference-shaped path (mpf_homography_flow +
+    mpf_volume_render(hard): per-plane flows written and re-read), bit for bit, for one, two and three poses, on the [S,4,H,W] stack and on a bare
+    sigma tensor; ties take the first maximal plane (a stack of equal sigmas: plane 0 wins wherever its weight is the largest)."""
+    from mpiflow_amd import host_math, ops, pipeline, synth
+    inp = synth.make_inputs(S, H, W, seed=S * 7 + W, kind="white")
+    rng = random.Random(S + H)
+    poses = [host_math.generate_random_pose(0.15, rng=rng), host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng), host_math.generate_random_pose(0.3, rng=rng)]
+    mpi = T(inp["mpi"], dev)
+    for n in (1, 2, 3):
+        got = pipeline.hard_flows(mpi, inp["disparity"], inp["K"], poses[:n])
+        want = pipeline.hard_flows(mpi, inp["disparity"], inp["K"], poses[:n], generic=True)
+        assert tuple(got.shape) == (n, 2, H, W) and torch.equal(got.view(torch.int32), want.view(torch.int32)), n
+    k_inv, d = host_math.k_inverse(inp["K"]), host_math.plane_depths(inp["disparity"])
+    H_ts, _ = host_math.homographies(poses[0], k_inv, inp["K"], d)
+    bare = ops.src_flow_hard(mpi[:, 3:4].contiguous(), k_inv, d, H_ts.unsqueeze(0))
+    assert torch.equal(bare, pipeline.hard_flows(mpi, inp["disparity"], inp["K"], poses[:1]))
+    flat = mpi.clone()
+    flat[:, 3] = 0.5                                                     # equal sigmas: weights fall monotonically after the first plane that absorbs anything
+    a, b = pipeline.hard_flows(flat, inp["disparity"], inp["K"], poses[:2]), pipeline.hard_flows(flat, inp["disparity"], inp["K"], poses[:2], generic=True)
+    assert torch.equal(a, b)
+
+
 def test_pipeline_is_deterministic_and_graph_capturable(dev):
     """Two eager runs are bit-identical, and the two fused launches replay from a captured HIP graph with the same result
     (the C ABI promises: asynchronous on the given stream, no allocation, no synchronisation)."""

@@ -514,6 +514,42 @@ def test_cli_with_network_on_hip_engine(dev, tmp_path):
     assert not np.array_equal(flows[0], flows[1])                         # the replay really saw the second image
 
 
+def test_cli_precise_engine_matches_the_torch_fp32_producer(dev, tmp_path):
+    """gen_3dphoto_dynamic.py --model-engine hip --model-dtype fp32 | fp64: the parity-grade producer (every convolution on mpf_pconv) behind the
+    reference's entry point.  Same image, same seed, same poses as --model-engine torch (the fp32 torch modules): the written flows agree to what two
+    fp32 evaluations of the network allow (tests/test_precise_engine.py), the fp32 and fp64 engines agree with each other more closely still, and
+    bf16 (a torch autocast dtype) is refused for the hip engine."""
+    import subprocess, sys, os
+    from PIL import Image
+    from mpiflow_amd import io_formats
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = tmp_path / "data"
+    for d in ("images", "disps", "masks"):
+        (base / d).mkdir(parents=True)
+    rs = np.random.RandomState(4)
+    yy, xx = np.mgrid[0:100, 0:140]
+    img = np.clip(0.5 + 0.3 * np.sin(xx / 9.0) + 0.2 * np.cos(yy / 7.0), 0, 1)
+    Image.fromarray((np.stack([img, np.roll(img, 5, 1), np.roll(img, 9, 0)], -1) * 255).astype(np.uint8)).save(base / "images" / "a.png")
+    Image.fromarray((255 * (0.1 + 0.8 * yy / 100)).astype(np.uint8)).save(base / "disps" / "a.png")
+    m = np.zeros((100, 140), np.uint8); m[30:60, 40:90] = 1
+    Image.fromarray(m).save(base / "masks" / "a.png")
+    flows = {}
+    common = [sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--base", str(base), "--width", "128", "--height", "128", "--repeat", "2", "--planes", "8",
+              "--inpaint", "none", "--mpi-from", "model", "--ckpt_path", "random:3"]
+    for name, extra in (("torch", ["--model-engine", "torch"]), ("fp32", ["--model-engine", "hip", "--model-dtype", "fp32"]), ("fp64", ["--model-engine", "hip", "--model-dtype", "fp64"])):
+        out = tmp_path / ("out_" + name)
+        r = subprocess.run(common + ["--out", str(out)] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        flows[name] = np.stack([io_formats.read_flo(str(out / "flows" / ("a_%d.flo" % k))) for k in range(2)])
+        assert flows[name].shape == (2, 128, 128, 2) and np.isfinite(flows[name]).all()
+        assert Image.open(out / "dst_images" / "a_1.png").size == (128, 128)
+    scale = float(np.abs(flows["torch"]).max())
+    d32, d64, dd = (float(np.abs(flows[a] - flows[b]).mean()) for a, b in (("fp32", "torch"), ("fp64", "torch"), ("fp32", "fp64")))
+    assert scale > 0.5 and d32 < 2e-4 * max(scale, 1.0) and d64 < 2e-4 * max(scale, 1.0) and dd <= max(d32, d64), (scale, d32, d64, dd)
+    r = subprocess.run(common + ["--out", str(tmp_path / "x"), "--model-engine", "hip", "--model-dtype", "bf16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "bf16" in (r.stderr + r.stdout)
+
+
 def test_hard_flow_entry_point(dev, oracle):
     """hard_flow=True: flow of the arg-max-weight plane (mpi_rendering.py:126-130).  A 1-ulp exp difference (the reference's exp is MKL's)
     can move the arg-max between two planes whose weights are equal to within rounding; every pixel that differs from the reference's

@@ -395,6 +395,8 @@ extern "C" int mpf_pconv(const MpfPConvArgs *args, void *stream)
     return a.dtype == MPF_DTYPE_F64 ? launch_pconv<double>(a, (hipStream_t)stream) : launch_pconv<float>(a, (hipStream_t)stream);
 }
 
+static inline bool pvec_aligned(const void *p, int dtype) { return (((uintptr_t)p) & (dtype == MPF_DTYPE_F64 ? 31u : 15u)) == 0; }
+
 extern "C" int mpf_pfmn_input(const float *d_image_3HW, const float *d_disp_HW, const float *d_plane_vals, int S, int H, int W, void *d_out, int dtype, void *stream)
 {
     MPF_REQUIRE(d_image_3HW && d_disp_HW && d_plane_vals && d_out && S >= 1 && H >= 1 && W >= 1 && MPF_DTYPE_OK(dtype), "mpf_pfmn_input: bad argument");
@@ -417,6 +419,7 @@ extern "C" int mpf_pbilinear2x(const void *d_src, int S, int h, int w, int C, vo
 {
     MPF_REQUIRE(d_src && d_dst && S >= 1 && h >= 1 && w >= 1 && C >= 4 && C % 4 == 0 && MPF_DTYPE_OK(dtype), "mpf_pbilinear2x: bad argument");
     MPF_REQUIRE((size_t)h * w * C < 0x7FFFFFFFull / 4, "mpf_pbilinear2x: plane too large");
+    MPF_REQUIRE(pvec_aligned(d_src, dtype) && pvec_aligned(d_dst, dtype), "mpf_pbilinear2x: buffers must be aligned to one 4-channel vector");
     const size_t n = (size_t)S * 4 * h * w * (C / 4);
     if (dtype == MPF_DTYPE_F64) hipLaunchKernelGGL((k_bilinear2x<double>), dim3(blocks_of(n)), dim3(256), 0, (hipStream_t)stream, (const double *)d_src, S, h, w, C / 4, (double *)d_dst);
     else hipLaunchKernelGGL((k_bilinear2x<float>), dim3(blocks_of(n)), dim3(256), 0, (hipStream_t)stream, (const float *)d_src, S, h, w, C / 4, (float *)d_dst);
@@ -426,6 +429,7 @@ extern "C" int mpf_pbilinear2x(const void *d_src, int S, int h, int w, int C, vo
 extern "C" int mpf_pper_plane(const void *d_feat_hwC, const void *d_cm, const void *d_fm, int S, int h, int w, int C, void *d_out, int dtype, void *stream)
 {
     MPF_REQUIRE(d_feat_hwC && d_cm && d_fm && d_out && S >= 1 && h >= 1 && w >= 1 && C >= 4 && C % 4 == 0 && MPF_DTYPE_OK(dtype), "mpf_pper_plane: bad argument");
+    MPF_REQUIRE(pvec_aligned(d_feat_hwC, dtype) && pvec_aligned(d_out, dtype), "mpf_pper_plane: buffers must be aligned to one 4-channel vector");
     const size_t n = (size_t)S * h * w * (C / 4 + 1);
     if (dtype == MPF_DTYPE_F64) hipLaunchKernelGGL((k_per_plane<double>), dim3(blocks_of(n)), dim3(256), 0, (hipStream_t)stream, (const double *)d_feat_hwC, (const double *)d_cm, (const double *)d_fm, S, h * w, C / 4, (double *)d_out);
     else hipLaunchKernelGGL((k_per_plane<float>), dim3(blocks_of(n)), dim3(256), 0, (hipStream_t)stream, (const float *)d_feat_hwC, (const float *)d_cm, (const float *)d_fm, S, h * w, C / 4, (float *)d_out);
@@ -460,6 +464,7 @@ extern "C" int mpf_pmaxpool3x3s2(const void *d_src_HWC, int Hin, int Win, int C,
 {
     MPF_REQUIRE(d_src_HWC && d_out && Hin >= 1 && Win >= 1 && C >= 4 && C % 4 == 0 && MPF_DTYPE_OK(dtype), "mpf_pmaxpool3x3s2: bad argument");
     MPF_REQUIRE((size_t)Hin * Win * C < 0x7FFFFFFFull, "mpf_pmaxpool3x3s2: tensor too large");
+    MPF_REQUIRE(pvec_aligned(d_src_HWC, dtype) && pvec_aligned(d_out, dtype), "mpf_pmaxpool3x3s2: buffers must be aligned to one 4-channel vector");
     const int Hout = (Hin - 1) / 2 + 1, Wout = (Win - 1) / 2 + 1, V = C / 4, n = Hout * Wout * V;
     if (dtype == MPF_DTYPE_F64) hipLaunchKernelGGL((k_maxpool3x3s2<double>), dim3(blocks_of(n)), dim3(256), 0, (hipStream_t)stream, (const double *)d_src_HWC, Hin, Win, V, Hout, Wout, (double *)d_out);
     else hipLaunchKernelGGL((k_maxpool3x3s2<float>), dim3(blocks_of(n)), dim3(256), 0, (hipStream_t)stream, (const float *)d_src_HWC, Hin, Win, V, Hout, Wout, (float *)d_out);

@@ -424,7 +424,13 @@ void k_conv3x3(const MpfConvArgs a)
 #pragma unroll
             for (int g = 0; g < PG; ++g) {
                 const int gi = wave * PG + g, gy = gi / GPR, gx = (gi - gy * GPR) * 16;
+#ifdef MPF_CONV_ABLATE_LDS
+                // timing ablation ONLY (separate build, results invalid): every k-step of a chunk re-uses the B fragment of its first one - the upper bound
+                // of any formulation that feeds several MFMAs from one LDS read (kn2row / shift-accumulate): profiles/r5/engine_lds_ablation.txt
+                u32x4 bv = *reinterpret_cast<const u32x4 *>(tile + (gy * ST * LW + gx * ST) * PIXB + tapoff[0]);
+#else
                 u32x4 bv = *reinterpret_cast<const u32x4 *>(tile + (gy * ST * LW + gx * ST) * PIXB + tapoff[ks]);
+#endif
                 h8 bf = *reinterpret_cast<h8 *>(&bv);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) acc[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[b], bf, acc[g][b], 0, 0, 0);

@@ -459,7 +459,7 @@ def overlap_record(S, H, W, dev, n_streams=2, images=4, steps=8):
             "streams": n_streams, "pairs_per_s": n / dt, "us_per_pair": dt / n * 1e6, "pairs_timed": n}
 
 
-def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64):
+def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64, model_dtype="auto"):
     """The data generator end to end (gen_3dphoto_dynamic.py, the reference's entry point gen_3dphoto_dynamic_v2.py:20-122): PNG decode,
     input stage, AdaMPI network (random weights of the reference's architecture: no checkpoint offline) on the HIP engine, blend once per
     image, `repeat` pairs per image, hole filling (cv2.inpaint's NS restated, on the writer threads), PNG + .flo files - on a synthetic
@@ -488,7 +488,7 @@ def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64):
                 os.symlink(os.path.join(base, d, "%04d.png" % (i % n_distinct)), os.path.join(base, d, "%04d.png" % i))
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         cmd = [sys.executable, os.path.join(ROOT, "gen_3dphoto_dynamic.py"), "--base", base, "--out", os.path.join(tmp, "out"), "--repeat", str(repeat),
-               "--mpi-from", "model", "--ckpt_path", "random:0", "--model-engine", "hip", "--inpaint", "builtin"]
+               "--mpi-from", "model", "--ckpt_path", "random:0", "--model-engine", "hip", "--model-dtype", model_dtype, "--inpaint", "builtin"]
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         dt = time.perf_counter() - t0
@@ -504,7 +504,7 @@ def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64):
                                      "gen_3dphoto_dynamic_v2.py:46,59,82-84), NOT the fp32 CPU parity target of the render path; its error against the fp32 model "
                                      "(random weights) is bounded by tests/test_conv_engine.py ENGINE_BARS, e.g. mean |sigmoid(rgb)| 3.2e-3 at this size "
                                      "(torch fp16 autocast: 1.2e-2); --model-engine hip --model-dtype fp32 runs the parity-grade engine (roofline_n1.precise)",
-               "pairs": n_images * repeat, "flo_files_written": n_files, "process_seconds": dt,
+               "model_dtype": model_dtype, "pairs": n_images * repeat, "flo_files_written": n_files, "process_seconds": dt,
                "pairs_per_s_whole_process": n_images * repeat / dt, "summary_line": summary[-1] if summary else None}
         if startup:
             rec["startup_line"] = startup[-1]
@@ -767,6 +767,12 @@ def main():
                 out["generator"] = generator_record()
             except Exception as e:                                   # noqa: BLE001 - a side record must never cost the headline line
                 out["generator"] = {"error": repr(e)}
+            try:                                                     # the same generator with the PARITY-GRADE producer (every convolution in fp32 on mpf_pconv): a short run
+                out["generator_precise"] = generator_record(n_images=24, n_distinct=24, model_dtype="fp32")
+                out["generator_precise"]["producer_precision"] = ("parity-grade engine: fp32 storage / products, fp32 MFMA accumulation carried in fp64 (tests/test_precise_engine.py: "
+                                                                  "closer to the fp64 mirror than torch's own fp32); ~73 ms per image, so the generator is bound by it")
+            except Exception as e:                                   # noqa: BLE001
+                out["generator_precise"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, H, W, a.cpu_pairs, chain=chain)
             out["cpu_baseline"]["reference_measured_in_build_container"] = \

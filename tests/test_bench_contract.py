@@ -165,6 +165,9 @@ def test_single_gpu_line_has_sub_records_and_names_the_dynamic_pair():
     assert g["pairs"] == 1600 and g["flo_files_written"] == 1600 and g["pairs_per_s_whole_process"] > 0 and g["pairs_per_s_steady_state"] > 0
     assert g["pairs_per_s_whole_process"] > 0.5 * g["pairs_per_s_steady_state"]
     assert "chain_join" in cfg and "side pipeline" in cfg["chain_join"]
+    gp = d["generator_precise"]                   # the same CLI with the parity-grade (fp32) producer
+    assert "error" not in gp, gp
+    assert gp["model_dtype"] == "fp32" and gp["pairs"] == 120 and gp["flo_files_written"] == 120 and 0 < gp["pairs_per_s_steady_state"] < g["pairs_per_s_steady_state"]
     pr = n1["precise"]                            # the parity-grade modes of the same network
     assert set(pr) == {"fp32", "fp64"} and all("error" not in v and v["ms_per_image"] > 0 and 0 < v["mfma"]["frac"] < 1 for v in pr.values())
     assert pr["fp32"]["ms_per_image"] < pr["fp64"]["ms_per_image"]

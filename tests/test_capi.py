@@ -48,6 +48,14 @@ def test_bad_arguments_return_error_codes(built):
     rc = lib.mpf_warp_composite(one, 1, None, one, 5000, 8, 8, one, None, None, None, None, None)
     assert rc == 10001 and b"bad shape" in lib.mpf_last_error()
     assert lib.mpf_forward_warp_workspace(640, 960) > 5 * 640 * 960 * 4
+    # round 5's entry points validate before they launch anything (no GPU needed to be told so)
+    assert lib.mpf_pconv(None, None) == 10001 and b"null argument block" in lib.mpf_last_error()
+    assert lib.mpf_merge_ex(None, 4, 4, None) == 10001
+    assert lib.mpf_src_flow_hard(one, 10, one, 1, 4, 8, 8, 0.0, one, None) == 10001 and b"plane_stride" in lib.mpf_last_error()
+    assert lib.mpf_pbilinear2x(ctypes.c_void_p(260), 1, 2, 2, 4, one, 0, None) == 10001 and b"aligned" in lib.mpf_last_error()
+    # tuning knobs: process-global ints; the bench-only ablation `chain_stop` of round 4 is gone, unknown keys are errors
+    assert lib.mpf_tune(b"fwarp_path", 2) == 0 and lib.mpf_tune(b"fwarp_path", 0) == 0 and lib.mpf_tune(b"planar_lds", 2) == 0 and lib.mpf_tune(b"planar_lds", 1) == 0
+    assert lib.mpf_tune(b"chain_stop", 1) == 10001 and b"unknown key" in lib.mpf_last_error()
     with pytest.raises(built.MpiFlowHipError):
         built.check(rc, "probe")
 

@@ -35,6 +35,17 @@ def test_planar_stage_b_soak():
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+def test_forward_warp_paths_soak():
+    """tools/soak_fwarp.py: the forward warp's three paths - the round-5 gather (default), the general radix path, round 2's sort + bucket workgroups - on
+    random sizes from one pixel up with smooth flows, white noise in a box (bench.py's c3), regions clamped onto border pixels (pile-ups streamed through
+    the gather kernel's LDS in chunks), everything onto a few targets, uniformly random targets, sentinel / tied / NaN z: same bytes, and the serial C
+    restatement's on every fourth small case."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_fwarp.py"), "120", "5"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_engine_first_layer_factorisation_soak():
     """tools/soak_engine_factor.py: the producer with its first layer synthesised in the consumers' loaders against the materialised form, random
     sizes / plane counts / parameters: equal to fp16-rounding level on logits, cumulative mask and output."""

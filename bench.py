@@ -770,7 +770,7 @@ def main():
             try:                                                     # the same generator with the PARITY-GRADE producer (every convolution in fp32 on mpf_pconv): a short run
                 out["generator_precise"] = generator_record(n_images=24, n_distinct=24, model_dtype="fp32")
                 out["generator_precise"]["producer_precision"] = ("parity-grade engine: fp32 storage / products, fp32 MFMA accumulation carried in fp64 (tests/test_precise_engine.py: "
-                                                                  "closer to the fp64 mirror than torch's own fp32); ~73 ms per image, so the generator is bound by it")
+                                                                  "closer to the fp64 mirror than torch's own fp32); ~59 ms per image, so the generator is bound by it")
             except Exception as e:                                   # noqa: BLE001
                 out["generator_precise"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:

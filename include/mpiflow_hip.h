@@ -433,8 +433,9 @@ int mpf_maxpool3x3s2_f32(const float *d_src_HWC, int Hin, int Win, int C, float 
 
 /* One convolution over S plane-images (or one image, S = 1):  input = cat(A', B) along channels, A' = srcA or its x2 nearest up-sampling
  * (up = 1; HA = Hin / 2), zero or reflection padding, ksize 1 | 3 | 7, stride 1 | 2.
- * wpack: [nblk][nsteps][64 lanes][4] of dtype, nsteps = ceil(ksize^2 * (CA+CB)/4 / 4): lane (m = l % 16, g = l / 16) of step s holds, for
- *   j = 0..3, W[physical row 16 blk + m][virtual channel 4 (v % V) + j][tap v / V] with v = 4 s + g, V = (CA+CB)/4, zero past the last tap.
+ * wpack: [nblk][nsteps][64 lanes][4] of dtype; K runs over source A's (tap, 4-channel vector) pairs, then over source B's: nsteps = nstA + nstB,
+ *   nstX = ceil(ksize^2 * (CX/4) / 4).  Lane (m = l % 16, g = l / 16) of step s of source X holds, for j = 0..3, W[physical row 16 blk + m][channel
+ *   4 (v % VX) + j of X][tap v / VX] with v = 4 s + g, VX = CX/4, zero past X's last tap.
  *   LOGICAL row L of a block (what the epilogue rows are indexed by) sits at physical row L for fp32 and at (L >> 2) + 4 (L & 3) for fp64
  *   (the C/D register layouts of the two MFMA instructions differ).  Gated epilogues: logical rows (2c, 2c+1) of the packed row sequence
  *   = (feature, gate) of channel c; bias [nblk*16] by logical row; scale / shift [nblk*8] by channel.  Affine epilogues: scale / shift

@@ -11,9 +11,9 @@
 //
 // k_pconv: implicit GEMM  out[row, pixel] = sum_{tap, c} W[row, tap, c] * in[pixel + tap, c].  A wave owns NB 16-row blocks
 // of output rows x PG groups of 16 consecutive pixels of one plane and runs the whole K loop for them (no split-K, no LDS, no
-// barrier: the sum order is fixed by construction).  K advances in vectors of 4 channels: lane (m = l % 16, g = l / 16) loads
-// the 4 channels of K-vector 4 step + g of pixel m (one 16- or 32-byte load) and the matching 4 weights of row m; the 4
-// elements feed 4 MFMAs (any permutation of K is a valid GEMM as long as both operands use it).
+// barrier: the sum order is fixed by construction).  K = source A's (tap, 4-channel vector) pairs, then source B's, four vectors per
+// K-step: lane (m = l % 16, g = l / 16) loads the 4 channels of K-vector 4 step + g at pixel m (one 16- or 32-byte buffer load) and the
+// matching 4 weights of row m; the 4 elements feed 4 MFMAs (any permutation of K is a valid GEMM as long as both operands use it).
 #include "mpf_common.h"
 
 namespace {
@@ -27,6 +27,18 @@ template <> struct Vec2<double> { typedef double type __attribute__((ext_vector_
 
 __device__ __forceinline__ Vec4<float>::type mfma16(float a, float b, Vec4<float>::type c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ Vec4<double>::type mfma16(double a, double b, Vec4<double>::type c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// one 4-channel vector through a buffer descriptor: a byte offset at or beyond num_records returns zeros - padding pixels need no select
+__device__ __forceinline__ Vec4<float>::type buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float)
+{
+    return __builtin_bit_cast(Vec4<float>::type, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+__device__ __forceinline__ Vec4<double>::type buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, double)
+{
+    struct { u32x4_t lo, hi; } r = { __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0), __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16u, soff, 0) };
+    return __builtin_bit_cast(Vec4<double>::type, r);
+}
 
 // correctly-rounded-grade library functions (ocml; the translation unit is built with -fno-fast-math)
 __device__ __forceinline__ float exp_t(float x) { return expf(x); }
@@ -55,8 +67,8 @@ __global__ __launch_bounds__(256) void k_pconv(const MpfPConvArgs a)
     const int p0 = ((int)blockIdx.x * 4 + wave) * (16 * PG);
     if (p0 >= P) return;                                              // no barrier in this kernel: a wave without pixels may leave
     const int bg = blockIdx.y, s = blockIdx.z;
-    const int VA = a.CA >> 2, VB = a.CB >> 2, V = VA + VB, ks = a.ksize;
-    const int nsteps = (ks * ks * V + 3) >> 2;
+    const int VA = a.CA >> 2, VB = a.CB >> 2, ks = a.ksize;
+    const int nstA = (ks * ks * VA + 3) >> 2, nstB = (ks * ks * VB + 3) >> 2, nsteps = nstA + nstB;      // K-steps of the two sources (K = source A's taps x vectors, then B's)
     int oy[PG], ox[PG];
     bool pv[PG];
 #pragma unroll
@@ -93,48 +105,28 @@ __global__ __launch_bounds__(256) void k_pconv(const MpfPConvArgs a)
             }
         }
     }
-    const v4 *A = reinterpret_cast<const v4 *>(a.srcA) + (a.shareA ? (size_t)0 : (size_t)s * a.HA * a.WA * VA);
-    const v4 *B = VB ? reinterpret_cast<const v4 *>(a.srcB) + (a.shareB ? (size_t)0 : (size_t)s * a.Hin * a.Win * VB) : A;
-    const v4 *wp = reinterpret_cast<const v4 *>(a.wpack) + (size_t)(bg * NB) * nsteps * 64 + lane;
     const bool reflect = a.pad_mode == 1;
-    // this lane's K-vector: v = 4 step + g = tap * V + c4, tap = ky * ks + kx; advanced incrementally (V is not a power of two)
-    int tap0 = g / V, c4 = g - tap0 * V, ky = tap0 / ks, kx = tap0 - ky * ks;
-    for (int step = 0; step < nsteps; ++step) {
-        const bool live = ky < ks;                                      // past the last tap: zero operands (the packed weights are zero there too)
-        const bool isA = c4 < VA;
-        v4 xv[PG], wv[NB];
+    constexpr unsigned VEC = 4 * sizeof(T), INVALID = 0xC0000000u;       // bytes of a 4-channel vector; an offset no plane reaches (planes are < 2 GiB)
+    // Buffer addressing throughout: the source plane and this workgroup's weight blocks behind descriptors (SGPRs), 32-bit byte offsets per lane, a padding
+    // pixel = an out-of-range offset that loads zeros, the weights' K-step as the load's scalar offset.  The fp32 MFMA runs at the fp32 VECTOR rate, i.e. on
+    // the pipe every addressing instruction needs: the first cut (64-bit pointer arithmetic, selects, the pixel addressing recomputed per K-step) spent
+    // 100 VALU instructions per 16-MFMA K-step and sat at MFMA busy 50 % + VALU 42 % (profiles/r5/precise_engine_error.txt).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(a.srcA)) + (a.shareA ? (size_t)0 : (size_t)s * a.HA * a.WA * a.CA * sizeof(T)), 0,
+        (unsigned)((size_t)a.HA * a.WA * a.CA * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(VB ? a.srcB : a.srcA)) + ((a.shareB || !VB) ? (size_t)0 : (size_t)s * a.Hin * a.Win * a.CB * sizeof(T)), 0,
+        (unsigned)(VB ? (size_t)a.Hin * a.Win * a.CB * sizeof(T) : 0), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW[NB];
 #pragma unroll
-        for (int pg = 0; pg < PG; ++pg) {
-            int iy = oy[pg] + ky, ix = ox[pg] + kx;
-            bool ok = live && pv[pg];
-            if (reflect) {                                              // nn.ReflectionPad2d(1), model/CPN/decoder.py:23
-                iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * a.Hin - 2 - iy : iy);
-                ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * a.Win - 2 - ix : ix);
-            } else {
-                ok = ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            }
-            iy = ok ? iy : 0;
-            ix = ok ? ix : 0;
-            const v4 *ptr = isA ? A + ((size_t)((iy >> a.up) * a.WA + (ix >> a.up)) * VA + (ok ? c4 : 0))
-                                : B + ((size_t)(iy * a.Win + ix) * VB + (ok ? c4 - VA : 0));
-            const v4 ld = *ptr;
-            xv[pg] = ok ? ld : zero;
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) wv[nb] = wp[(size_t)(nb * nsteps + step) * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int pg = 0; pg < PG; ++pg) acc[nb][pg] = mfma16(wv[nb][j], xv[pg][j], acc[nb][pg]);
-        c4 += 4;
-        while (c4 >= V) {
-            c4 -= V;
-            if (++kx == ks) { kx = 0; ++ky; }
-        }
+    for (int nb = 0; nb < NB; ++nb)
+        rsW[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.wpack)) + (size_t)(bg * NB + nb) * nsteps * 64 * VEC, 0,
+                                                    (unsigned)((size_t)nsteps * 64 * VEC), 0x00020000);
+    const unsigned wl = (unsigned)lane * VEC;
+    int step = 0;                                                        // K-step counter over both sources (weights, flush)
+    auto flush = [&](const int st) {
         if constexpr (TWO_LEVEL) {
-            if ((step & (FLUSH - 1)) == FLUSH - 1 || step == nsteps - 1) {
+            if ((st & (FLUSH - 1)) == FLUSH - 1 || st == nsteps - 1) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -145,7 +137,54 @@ __global__ __launch_bounds__(256) void k_pconv(const MpfPConvArgs a)
                     }
             }
         }
-    }
+    };
+    // one source: its K-vectors v = 4 st + g = tap * Vs + c4 (tap = ky * ks + kx), advanced incrementally per lane; the byte offset of the tap's pixel in
+    // every pixel group is recomputed only when the lane moves on to the next tap
+    auto segment = [&](const __amdgpu_buffer_rsrc_t rs, const int Vs, const int nst, const int up, const int pitch) {
+        const int tap0 = g / Vs;
+        int c4 = g - tap0 * Vs, ky = tap0 / ks, kx = tap0 - ky * ks;
+        unsigned poff[PG];
+        auto tap_pixels = [&]() {
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) {
+                int iy = oy[pg] + ky, ix = ox[pg] + kx;
+                bool ok = pv[pg] && ky < ks;                             // past the last tap: zero operands (the packed weights are zero there too)
+                if (reflect) {                                           // nn.ReflectionPad2d(1), model/CPN/decoder.py:23
+                    iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * a.Hin - 2 - iy : iy);
+                    ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * a.Win - 2 - ix : ix);
+                } else {
+                    ok = ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                }
+                poff[pg] = ok ? (unsigned)((iy >> up) * pitch + (ix >> up)) * ((unsigned)Vs * VEC) : INVALID;
+            }
+        };
+        tap_pixels();
+        for (int st = 0; st < nst; ++st, ++step) {
+            const unsigned cb = (unsigned)c4 * VEC, wso = (unsigned)step * (64u * VEC);
+            v4 xv[PG], wv[NB];
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) xv[pg] = buf_load4(rs, poff[pg] + cb, 0u, T());
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) wv[nb] = buf_load4(rsW[nb], wl, wso, T());
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int pg = 0; pg < PG; ++pg) acc[nb][pg] = mfma16(wv[nb][j], xv[pg][j], acc[nb][pg]);
+            flush(step);
+            c4 += 4;
+            if (c4 >= Vs) {
+                do {
+                    c4 -= Vs;
+                    if (++kx == ks) { kx = 0; ++ky; }
+                } while (c4 >= Vs);
+                tap_pixels();
+            }
+        }
+    };
+    segment(rsA, VA, nstA, a.up, a.WA);
+    if (VB) segment(rsB, VB, nstB, 0, a.Win);
     if constexpr (TWO_LEVEL) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -387,8 +426,9 @@ extern "C" int mpf_pconv(const MpfPConvArgs *args, void *stream)
     MPF_REQUIRE(a.Cst <= a.nblk * (gated ? 8 : 16), "mpf_pconv: more stored channels than packed rows");
     MPF_REQUIRE(a.act >= 0 && a.act <= 2, "mpf_pconv: activation must be 0 (none), 1 (ReLU) or 2 (leaky ReLU)");
     MPF_REQUIRE(a.residual == nullptr || a.epi == EP_AFFINE, "mpf_pconv: a residual goes with the affine epilogue");
-    MPF_REQUIRE((size_t)a.HA * a.WA * a.CA < 0x7FFFFFFFull && (size_t)a.Hin * a.Win * (a.CB ? a.CB : 4) < 0x7FFFFFFFull && (size_t)a.Hout * a.Wout < 0x7FFFFFFFull / 64,
-                "mpf_pconv: plane too large");
+    const size_t esz = a.dtype == MPF_DTYPE_F64 ? 8 : 4;
+    MPF_REQUIRE((size_t)a.HA * a.WA * a.CA * esz < 0x7FFFFFFFull && (size_t)a.Hin * a.Win * (a.CB ? a.CB : 4) * esz < 0x7FFFFFFFull && (size_t)a.Hout * a.Wout < 0x7FFFFFFFull / 64,
+                "mpf_pconv: plane too large (2 GiB of one source per plane: 32-bit buffer offsets)");
     const size_t al = a.dtype == MPF_DTYPE_F64 ? 31 : 15;
     MPF_REQUIRE((((uintptr_t)a.srcA | (uintptr_t)a.srcB | (uintptr_t)a.wpack | (uintptr_t)a.out | (uintptr_t)a.scale | (uintptr_t)a.shift | (uintptr_t)a.bias |
                   (uintptr_t)a.residual) & al) == 0, "mpf_pconv: buffers must be aligned to one 4-channel vector");

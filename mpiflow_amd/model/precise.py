@@ -41,18 +41,25 @@ def physical_rows(R, dtype):
     return L
 
 
-def pack_weights(w_rows, dtype, device=None):
-    """[R, Cv, k, k] float64 in LOGICAL row order (R a multiple of 16, Cv a multiple of 4) -> [R/16, nsteps, 64, 4] of `dtype`:
-    the A-operand order of mpf_pconv (include/mpiflow_hip.h: MpfPConvArgs)."""
+def pack_weights(w_rows, dtype, device=None, CA=None):
+    """[R, Cv, k, k] float64 in LOGICAL row order (R a multiple of 16, Cv a multiple of 4; the first CA virtual channels are source A's, the rest source
+    B's; default: one source) -> [R/16, nstA + nstB, 64, 4] of `dtype`: the A-operand order of mpf_pconv (include/mpiflow_hip.h: MpfPConvArgs) - K runs over
+    source A's (tap, 4-channel vector) pairs, four per step, then over source B's."""
     R, Cv, k, _ = w_rows.shape
-    assert R % 16 == 0 and Cv % 4 == 0
+    CA = Cv if CA is None else CA
+    assert R % 16 == 0 and Cv % 4 == 0 and CA % 4 == 0 and 0 < CA <= Cv
     phys = torch.empty_like(w_rows)
     phys[physical_rows(R, dtype)] = w_rows
-    nv = k * k * (Cv // 4)
-    nsteps = (nv + 3) // 4
-    wv = phys.permute(0, 2, 3, 1).reshape(R, nv, 4)
-    wv = torch.cat([wv, torch.zeros(R, nsteps * 4 - nv, 4, dtype=wv.dtype)], dim=1).reshape(R // 16, 16, nsteps, 4, 4)      # [blk, m, s, g, j]
-    out = wv.permute(0, 2, 3, 1, 4).reshape(R // 16, nsteps, 64, 4).to(dtype).contiguous()
+    parts = []
+    for c0, c1 in ((0, CA), (CA, Cv)):
+        if c1 == c0:
+            continue
+        nv = k * k * ((c1 - c0) // 4)
+        nst = (nv + 3) // 4
+        wv = phys[:, c0:c1].permute(0, 2, 3, 1).reshape(R, nv, 4)                                    # [row, v = tap * Vs + c4, j]
+        parts.append(torch.cat([wv, torch.zeros(R, nst * 4 - nv, 4, dtype=wv.dtype)], dim=1).reshape(R // 16, 16, nst, 4, 4))   # [blk, m, s, g, j]
+    wv = torch.cat(parts, dim=2)
+    out = wv.permute(0, 2, 3, 1, 4).reshape(R // 16, wv.shape[2], 64, 4).to(dtype).contiguous()
     return out.to(device) if device is not None else out
 
 
@@ -85,7 +92,7 @@ class PConv:
         assert w_rows.shape[1] == CA + CB and w_rows.shape[0] % 16 == 0
         self.nblk = w_rows.shape[0] // 16
         self.rows_real, self.cin_real = rows_real, cin_real
-        self.wpack = pack_weights(w_rows.double(), dtype, device)
+        self.wpack = pack_weights(w_rows.double(), dtype, device, CA=CA)
         put = lambda t: None if t is None else t.to(dtype).contiguous().to(device)      # noqa: E731
         self.scale, self.shift, self.bias = put(scale), put(shift), put(bias)
 

@@ -42,25 +42,30 @@ def test_pconv_args_struct_matches_header(tmp_path):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_pack_weights_layout(dtype):
-    """A-operand order of mpf_pconv: lane (m, g) of step s holds W[physical row 16 blk + m][4 (v % V) + j][tap v / V], v = 4 s + g; logical row L of a
-    block sits at physical row L (fp32) or (L >> 2) + 4 (L & 3) (fp64: the C/D layout of v_mfma_f64_16x16x4_f64 is row = g + 4 i)."""
+    """A-operand order of mpf_pconv: K = source A's (tap, 4-channel vector) pairs, then source B's; lane (m, g) of step s of a source with Vs vectors per tap
+    holds W[physical row 16 blk + m][4 (v % Vs) + j of that source][tap v / Vs], v = 4 s + g (zero past the source's last tap); logical row L of a block
+    sits at physical row L (fp32) or (L >> 2) + 4 (L & 3) (fp64: the C/D layout of v_mfma_f64_16x16x4_f64 is row = g + 4 i)."""
     from mpiflow_amd.model.precise import pack_weights
     g = torch.Generator().manual_seed(1)
-    for R, cv, k in [(32, 4, 7), (16, 12, 3), (48, 20, 1)]:
+    for R, cv, ca, k in [(32, 4, 4, 7), (16, 12, 12, 3), (48, 20, 8, 1), (16, 24, 4, 3)]:
         w = torch.randn(R, cv, k, k, generator=g, dtype=torch.float64)
-        got = pack_weights(w, dtype).numpy()
-        V = cv // 4
-        nsteps = (k * k * V + 3) // 4
-        assert got.shape == (R // 16, nsteps, 64, 4) and got.dtype == (np.float32 if dtype == torch.float32 else np.float64)
+        got = pack_weights(w, dtype, CA=ca).numpy()
+        segs = [(0, ca)] + ([(ca, cv)] if cv > ca else [])
+        nst = [(k * k * ((c1 - c0) // 4) + 3) // 4 for c0, c1 in segs]
+        assert got.shape == (R // 16, sum(nst), 64, 4) and got.dtype == (np.float32 if dtype == torch.float32 else np.float64)
         ref = np.zeros_like(got)
         for blk in range(R // 16):
             for L in range(16):
                 phys = L if dtype == torch.float32 else (L >> 2) + 4 * (L & 3)
-                for s_ in range(nsteps):
-                    for g_ in range(4):
-                        v = 4 * s_ + g_
-                        if v // V < k * k:
-                            ref[blk, s_, g_ * 16 + phys] = w[blk * 16 + L, 4 * (v % V):4 * (v % V) + 4, (v // V) // k, (v // V) % k].to(dtype).numpy()
+                s0 = 0
+                for (c0, c1), n in zip(segs, nst):
+                    Vs = (c1 - c0) // 4
+                    for s_ in range(n):
+                        for g_ in range(4):
+                            v = 4 * s_ + g_
+                            if v // Vs < k * k:
+                                ref[blk, s0 + s_, g_ * 16 + phys] = w[blk * 16 + L, c0 + 4 * (v % Vs):c0 + 4 * (v % Vs) + 4, (v // Vs) // k, (v // Vs) % k].to(dtype).numpy()
+                    s0 += n
         assert np.array_equal(got, ref)
 
 

@@ -88,6 +88,7 @@ def parse():
     p.add_argument("--main-cu-exclude-stride", type=int, default=0,
                    help="tuning: the pair stream is barred from every n-th compute unit (use with --chain-cu-stride n: the chain then owns those CUs)")
     p.add_argument("--chain-cu-stride", type=int, default=0, help="tuning: the chain's side stream may only use every n-th compute unit (0 = all)")
+    p.add_argument("--chain-sides", type=int, default=2, help="side streams the moving-object chains alternate over (2: a chain may take two pair launches before it delays anything)")
     p.add_argument("--merge-in-launch", type=int, default=1,
                    help="1 = Stage D of pair i is a per-pixel prologue of the Stage A+C role of launch i+2 (one launch per pair); 0 = a launch of its own after every pair launch")
     p.add_argument("--chain-ordered", type=int, default=0,
@@ -264,7 +265,7 @@ def make_moving_object_chain(H, W, K, dev, seed):
     disp = torch.rand((H, W), generator=g, device=dev)
     K3 = torch.from_numpy(np.asarray(K, dtype=np.float32)).reshape(3, 3)
     Ti = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.tensor([[0.07, -0.06, 0.08]]))
-    return moving_obj.MovingObjectChain(H, W, K3, torch.inverse(K3.double()).float(), dev, T_obj=Ti, n_buffers=3), disp
+    return moving_obj.MovingObjectChain(H, W, K3, torch.inverse(K3.double()).float(), dev, T_obj=Ti, n_buffers=4), disp
 
 
 class PipelinedWorkload:
@@ -272,7 +273,7 @@ class PipelinedWorkload:
     i+1 in one heterogeneous-grid launch.  finish() flushes the pipeline (the last pair's stand-alone Stage B)."""
     dynamic = True
 
-    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False, chain_priority=False, chain_ordered=False, merge_in_launch=True, chain_cu_stride=0):
+    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False, chain_priority=False, chain_ordered=False, merge_in_launch=True, chain_cu_stride=0, chain_sides=2):
         self.S, self.H, self.W, self.B, self.N = S, H, W, B, H * W
         K, disp = synth.intrinsics(H, W), synth.plane_disparities(S)
         rng = random.Random(pose_seed)
@@ -284,7 +285,7 @@ class PipelinedWorkload:
         if moving_object:
             # the chain as an independent side pipeline (attach_chain(ordered=False)): nothing of it is inserted into the main stream; the
             # inputs are resident since set-up (ready event recorded once), finish() joins the side stream inside the timed region
-            self.r.attach_chain(self.mo, high_priority=chain_priority, ordered=chain_ordered, cu_stride=chain_cu_stride)
+            self.r.attach_chain(self.mo, high_priority=chain_priority, ordered=chain_ordered, cu_stride=chain_cu_stride, sides=chain_sides)
         self.images, self.preps = [], []
         for i in range(B):
             self.images.append(make_image(S, H, W, dev, seed=seed0 + i))
@@ -614,7 +615,7 @@ def main():
         main_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_stream)
     if pipelined:
-        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank, moving_object=chain, chain_priority=bool(a.chain_priority), chain_ordered=bool(a.chain_ordered), merge_in_launch=bool(a.merge_in_launch), chain_cu_stride=a.chain_cu_stride)
+        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank, moving_object=chain, chain_priority=bool(a.chain_priority), chain_ordered=bool(a.chain_ordered), merge_in_launch=bool(a.merge_in_launch), chain_cu_stride=a.chain_cu_stride, chain_sides=a.chain_sides)
     else:
         wl = Workload(S, H, W, B, dev, dynamic, seed0=rank * 1000, multi_view=not a.single_view_launches, pose_seed=114514 + rank, moving_object=chain)
     torch.cuda.synchronize()
@@ -696,7 +697,7 @@ def main():
             "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.mode == "batch" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "merge_in_launch": bool(a.merge_in_launch) if pipelined else None, "chain_cu_stride": a.chain_cu_stride, "main_stream_priority": a.main_priority, "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None,
+            "config": {"workload": cfg_name, "mode": a.mode, "pipeline": "overlapped" if pipelined else "serial", "moving_object_chain": bool(chain), "merge_in_launch": bool(a.merge_in_launch) if pipelined else None, "chain_cu_stride": a.chain_cu_stride, "chain_side_streams": a.chain_sides, "main_stream_priority": a.main_priority, "chain_ordered_on_main_stream": bool(a.chain_ordered) if chain and pipelined else None,
                        "chain_join": (("per pair on the main stream (event wait before the pair is handed back)" if a.chain_ordered else
                                        "the chain is an independent side pipeline: each pair's moving-object results carry their own `ready` event and are NOT joined "
                                        "with the pair's render results per pair inside the timed region (no consumer runs in this bench); the side stream is joined once, "

@@ -235,7 +235,7 @@ class OverlappedPairRenderer(_PairHostSide):
         # the overlapped launch addresses the stack through 32-bit buffer offsets: stacks of 4 GiB and more take the two separate launches
         self.fusable = S * H * W * 16 < (1 << 32)
 
-    def attach_chain(self, chain, high_priority=False, ordered=True, cu_stride=0):
+    def attach_chain(self, chain, high_priority=False, ordered=True, cu_stride=0, sides=1):
         """chain: moving_obj.MovingObjectChain with (at least) two output sets - three with merge_in_launch.
         ordered=True: the chain splats the uint8 source frame the pair's Stage A+C role wrote and its results are stream-ordered on the
           MAIN stream when the pair is handed back - costs the main stream an event record and an event wait per pair (measured: 12 us per
@@ -248,10 +248,12 @@ class OverlappedPairRenderer(_PairHostSide):
           on the caller's stream at the push() that reuses the set (`guard_unconsumed`, default on), which covers every consumer on that
           stream.  `moving_ready` of push() names the event after which the pair's inputs may be read (None: one is recorded on the main
           stream), and flush() joins the side stream.
-        high_priority: the side stream gets the device's highest stream priority (no measurable effect at 64 x 640 x 960)."""
+        high_priority: the side stream gets the device's highest stream priority (no measurable effect at 64 x 640 x 960).
+        sides (independent chain only): number of side streams the chains alternate over - with 2, the chain of pair i may take TWO pair launches before it
+          delays anything (the chain needs `sides` more output sets than otherwise)."""
         # a pair's output set must survive until the pair has been handed back: one push() later, two with merge_in_launch - the sets are used
         # round-robin, so that takes two resp. three of them
-        need = 3 if self.merge_in_launch else 2
+        need = (3 if self.merge_in_launch else 2) + (max(1, int(sides)) - 1 if not ordered else 0)
         if len(chain.bufs) < need or (chain.H, chain.W) != (self.H, self.W):
             raise ValueError("attach_chain: the chain needs %d output sets (n_buffers) of %d x %d for this renderer" % (need, self.H, self.W))
         self.chain, self.chain_ordered, self._chain_next = chain, ordered, 0
@@ -270,6 +272,8 @@ class OverlappedPairRenderer(_PairHostSide):
             self.side = torch.cuda.ExternalStream(h.value, device=self.device)
         else:
             self.side = torch.cuda.Stream(self.device, priority=-1 if high_priority else 0)
+        self._sides = [self.side] + [torch.cuda.Stream(self.device, priority=-1 if high_priority else 0) for _ in range(max(1, int(sides)) - 1 if not ordered else 0)]
+        self._chain_count = 0
         for k, s in enumerate(self.slots):
             s["index"], s["ev_src"], s["ev_chain"], s["moving"] = k, torch.cuda.Event(), torch.cuda.Event(), None
 
@@ -327,13 +331,17 @@ class OverlappedPairRenderer(_PairHostSide):
             # doing anything, one on another stream must set `consumed`
             guard = torch.cuda.Event()
             guard.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(moving_ready)
+        side = self._sides[self._chain_count % len(self._sides)]
+        self._chain_count += 1
+        with torch.cuda.stream(side):
+            side.wait_event(moving_ready)
+            if len(self._sides) > 1 and getattr(b, "ready", None) is not None:
+                side.wait_event(b.ready)                                   # the set's previous chain may have run on another side stream
             if b.consumed is not None:
-                self.side.wait_event(b.consumed)
+                side.wait_event(b.consumed)
                 b.consumed = None
             elif guard is not None:
-                self.side.wait_event(guard)
+                side.wait_event(guard)
             self.chain.run(moving[0], moving[1], image, which=which)
             b.ready = torch.cuda.Event()
             b.ready.record()
@@ -430,7 +438,8 @@ class OverlappedPairRenderer(_PairHostSide):
             if p is not None:
                 res.append(self._finish(p))
         if self.chain is not None and not self.chain_ordered:
-            torch.cuda.current_stream().wait_stream(self.side)                # the independent chain joins the main stream here
+            for side in self._sides:
+                torch.cuda.current_stream().wait_stream(side)                 # the independent chain joins the main stream here
         return res
 
     @property

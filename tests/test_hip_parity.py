@@ -498,11 +498,12 @@ def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
     d_disp, d_inst = T(disp, dev), T(inst, dev)
     poses = [(host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng), host_math.generate_random_pose(0.15, rng=rng)) for _ in range(5)]
 
-    def stream(with_chain, high_priority=False, ordered=True, merge_in_launch=False):
+    def stream(with_chain, high_priority=False, ordered=True, merge_in_launch=False, sides=1):
         ovl = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=merge_in_launch)
         if with_chain:
-            ovl.attach_chain(moving_obj.MovingObjectChain(H, W, g["K"], g["inv_K"], dev, T_obj=torch.from_numpy(g["T_obj"])[None], n_buffers=3 if (merge_in_launch or not ordered) else 2),
-                             high_priority=high_priority, ordered=ordered)
+            ovl.attach_chain(moving_obj.MovingObjectChain(H, W, g["K"], g["inv_K"], dev, T_obj=torch.from_numpy(g["T_obj"])[None],
+                                                          n_buffers=(3 if (merge_in_launch or not ordered) else 2) + sides - 1),
+                             high_priority=high_priority, ordered=ordered, sides=sides)
         outs = [tuple(torch.empty(s, dtype=dt, device=dev) for s, dt in (((H, W, 2), torch.float32), ((H, W, 3), torch.uint8), ((H, W), torch.uint8))) for _ in range(3)]
         res = []
 
@@ -525,8 +526,9 @@ def test_chain_through_overlapped_pipeline_every_pixel_c2(dev, oracle):
         assert len(res) == len(poses)
         return res
     plain = stream(False)
-    for hp, ordered, mil in ((False, True, False), (True, True, False), (False, False, False), (False, False, True), (False, True, True)):
-        got = stream(True, high_priority=hp, ordered=ordered, merge_in_launch=mil)
+    # the last form: the independent chains alternate over TWO side streams (a chain may take two pair launches; a set's previous chain is waited for)
+    for hp, ordered, mil, sides in ((False, True, False, 1), (True, True, False, 1), (False, False, False, 1), (False, False, True, 1), (False, True, True, 1), (False, False, True, 2)):
+        got = stream(True, high_priority=hp, ordered=ordered, merge_in_launch=mil, sides=sides)
         for k, (a, b) in enumerate(zip(plain, got)):
             for x, y in zip(a, b):
                 assert bits_equal(x, y) == 0, "pair %d: render output changed with the chain attached" % k

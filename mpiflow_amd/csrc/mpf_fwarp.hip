@@ -659,29 +659,37 @@ k_fw_keys_ranges(const float *__restrict__ disp, const MpfMoProj m, const float 
     }
 }
 
-// Pass 2: ONE WAVE per bucket of 256 consecutive targets (a 64-thread workgroup: __syncthreads() is a wait for the wave's own LDS traffic, not a
-// barrier).  (1) the tiles, then the slabs, whose key range touches the bucket; (2) their keys, 64 at a time in raster order: the matching
+// Pass 2: ONE WAVE per bucket of 256 consecutive targets, four such waves per workgroup with nothing in common (private LDS slices; MPF_WAVE_SYNC is a
+// compiler fence, not a barrier).  (1) the tiles, then the slabs, whose key range touches the bucket; (2) their keys, 64 at a time in raster order: the matching
 // lanes append (source index, target, z) to the chunk; (3) per chunk: count per target, scan, stable placement by target (ballot ranking),
 // then per sorted slot "z < z of the previous visitor of the same target" - the previous visitor of a chunk's first slot of a target is the
 // carried last z (1000 for a target nobody visited yet: dlut, warping.c:11) -, the last such slot per target (LDS atomicMax) becomes the
 // target's winner so far, the last slot of every target updates its carried z and its collision flag (warping.c:24-27);  (4) the 5 output
 // bytes of every target of the bucket (warping.c:13-29), and on request the planes H = valid, M = 1 - (collision == valid)
 // (moving_obj.py:133-142) the mask kernel would otherwise re-read from the 5-byte records.
-__global__ void __launch_bounds__(64)
+// wave-level publication of LDS writes: a wave's LDS operations complete in order, so all that is needed is that the compiler neither reorders nor caches them
+#define MPF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define FWG_WAVES 4               // buckets per workgroup, one per wave: four waves on the four SIMDs of one CU take ONE 256-thread workgroup's slot from a chip-filling
+                                  // launch on another stream; as single-wave workgroups each of them could cost such a slot on a different CU
+
+__global__ void __launch_bounds__(64 * FWG_WAVES)
 k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ slab_min, const uint32_t *__restrict__ slab_max,
                     const uint32_t *__restrict__ tile_min, const uint32_t *__restrict__ tile_max, uint32_t N, uint32_t ntiles, const float *__restrict__ z,
                     const uint8_t *__restrict__ src, const float *__restrict__ src_f, uint8_t *__restrict__ warped, int zero_fill,
                     uint8_t *__restrict__ Hm, uint8_t *__restrict__ Mm)
 {
     constexpr int NT = 1 << FWG_LB;
-    __shared__ uint32_t g_src[FWG_CAP], g_tl[FWG_CAP];      // gathered, raster order
-    __shared__ float g_z[FWG_CAP];
-    __shared__ uint32_t s_src[FWG_CAP], s_tl[FWG_CAP];      // sorted by (target, raster index)
-    __shared__ float s_z[FWG_CAP];
-    __shared__ uint32_t hc[NT], cur[NT], winslot[NT], winsrc[NT], state[NT];
-    __shared__ float zlast[NT];
-    __shared__ uint32_t clist[512];                         // candidate tiles of one batch of the tile table (ordered)
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint32_t g_src_[FWG_WAVES][FWG_CAP], g_tl_[FWG_WAVES][FWG_CAP];      // gathered, raster order
+    __shared__ float g_z_[FWG_WAVES][FWG_CAP];
+    __shared__ uint32_t s_src_[FWG_WAVES][FWG_CAP], s_tl_[FWG_WAVES][FWG_CAP];      // sorted by (target, raster index)
+    __shared__ float s_z_[FWG_WAVES][FWG_CAP];
+    __shared__ uint32_t hc_[FWG_WAVES][NT], cur_[FWG_WAVES][NT], winslot_[FWG_WAVES][NT], winsrc_[FWG_WAVES][NT], state_[FWG_WAVES][NT];
+    __shared__ float zlast_[FWG_WAVES][NT];
+    __shared__ uint32_t clist_[FWG_WAVES][512];             // candidate tiles of one batch of the tile table (ordered)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *const g_src = g_src_[wave], *const g_tl = g_tl_[wave], *const s_src = s_src_[wave], *const s_tl = s_tl_[wave];
+    float *const g_z = g_z_[wave], *const s_z = s_z_[wave], *const zlast = zlast_[wave];
+    uint32_t *const hc = hc_[wave], *const cur = cur_[wave], *const winslot = winslot_[wave], *const winsrc = winsrc_[wave], *const state = state_[wave], *const clist = clist_[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t nbuckets = (N + NT - 1) >> FWG_LB;
 
@@ -689,9 +697,9 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
     auto process = [&](const uint32_t cnt) {
 #pragma unroll
         for (int k = 0; k < NT / 64; ++k) hc[lane + 64 * k] = 0;
-        __syncthreads();
+        MPF_WAVE_SYNC();
         for (uint32_t j = lane; j < cnt; j += 64) atomicAdd(&hc[g_tl[j]], 1u);
-        __syncthreads();
+        MPF_WAVE_SYNC();
         {   // exclusive scan: lane l owns targets 4l .. 4l+3
             uint32_t v[NT / 64], sum = 0;
 #pragma unroll
@@ -706,7 +714,7 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
 #pragma unroll
             for (int k = 0; k < NT / 64; ++k) { cur[lane * (NT / 64) + k] = base; base += v[k]; }
         }
-        __syncthreads();
+        MPF_WAVE_SYNC();
         for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {           // stable placement, 64 visitors (in raster order) per round
             const uint32_t j = j0 + lane;
             const bool valid = j < cnt;
@@ -723,9 +731,9 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
                 const uint32_t pos = cur[d] + rank;
                 s_src[pos] = g_src[j]; s_tl[pos] = d; s_z[pos] = g_z[j];
             }
-            __syncthreads();
+            MPF_WAVE_SYNC();
             if (valid && rank == 0) cur[d] += __popcll(mask);
-            __syncthreads();
+            MPF_WAVE_SYNC();
         }
         for (uint32_t j = lane; j < cnt; j += 64) {           // z test against the previous visitor of the same target
             const uint32_t t = s_tl[j];
@@ -733,7 +741,7 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
             const float zprev = has_pred ? s_z[j - 1] : zlast[t];
             if (s_z[j] < zprev) atomicMax(&winslot[t], j + 1);                    // warping.c:19
         }
-        __syncthreads();
+        MPF_WAVE_SYNC();
         for (uint32_t j = lane; j < cnt; j += 64) {           // the last visitor of every target in this chunk carries the state on
             const uint32_t t = s_tl[j];
             if (j + 1 < cnt && s_tl[j + 1] == t) continue;
@@ -744,10 +752,10 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
             if (wj) { winsrc[t] = s_src[wj - 1] + 1u; winslot[t] = 0u; }
             zlast[t] = s_z[j];                                                       // dlut[y,x] = z, unconditionally (warping.c:29)
         }
-        __syncthreads();
+        MPF_WAVE_SYNC();
     };
 
-    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+    for (uint32_t b = blockIdx.x * FWG_WAVES + wave; b < nbuckets; b += gridDim.x * FWG_WAVES) {
         const uint32_t lo = b << FWG_LB, hi = lo + (NT - 1);
 #pragma unroll
         for (int k = 0; k < NT / 64; ++k) {
@@ -755,7 +763,7 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
             zlast[t] = 1000.0f; winslot[t] = 0u; winsrc[t] = 0u; state[t] = 0u;
         }
         uint32_t cnt = 0;
-        __syncthreads();
+        MPF_WAVE_SYNC();
         // candidate tiles, 512 table entries per batch (8 independent loads per lane in flight); typically a bucket sees 1-3 candidates
         for (uint32_t t0 = 0; t0 < ntiles; t0 += 512) {
             uint32_t mn[8], mx[8];
@@ -774,7 +782,7 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
                 if (hit) clist[nct + __popcll(bm & lt)] = t0 + 64 * k + lane;
                 nct += __popcll(bm);
             }
-            __syncthreads();
+            MPF_WAVE_SYNC();
             for (uint32_t c0 = 0; c0 < nct; c0 += 4) {       // 4 candidate tiles = 64 slabs per round
                 const uint32_t ci = c0 + (lane >> 4);
                 const uint32_t slab = ci < nct ? clist[ci] * 16 + (lane & 15u) : 0u;
@@ -782,7 +790,7 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
                 unsigned long long sm = __ballot(shit);
                 while (sm) {                                   // the touching slabs in raster order, four at a time (their 8 loads in flight together)
                     if (cnt > FWG_CAP - 256) {                 // the next four slabs might not fit: fold the chunk into the carried state
-                        __syncthreads();
+                        MPF_WAVE_SYNC();
                         process(cnt);
                         cnt = 0;
                     }
@@ -814,9 +822,9 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
                     }
                 }
             }
-            __syncthreads();
+            MPF_WAVE_SYNC();
         }
-        __syncthreads();
+        MPF_WAVE_SYNC();
         if (cnt) process(cnt);
         // the 5 bytes of every target of the bucket
 #pragma unroll
@@ -850,7 +858,7 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
                 Mm[t] = (uint8_t)((st & 1u) && !(st & 2u));                         // 1 - (collision == valid)
             }
         }
-        __syncthreads();
+        MPF_WAVE_SYNC();
     }
 }
 
@@ -987,7 +995,7 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
                                      ntiles, keys[0], slab_min, slab_max, tile_min, tile_max);
         else hipLaunchKernelGGL((k_fw_keys_ranges<false>), dim3(fw_cap(ntiles)), dim3(256), 0, st, (const float *)nullptr, no_proj, (const float *)nullptr, MpfMoOut{}, d_idx,
                                 d_idy, h, w, N, ntiles, keys[0], slab_min, slab_max, tile_min, tile_max);
-        hipLaunchKernelGGL(k_fw_gather_resolve, dim3(fw_cap(nbuckets)), dim3(64), 0, st, keys[0], slab_min, slab_max, tile_min, tile_max, N, ntiles, d_z, d_src, src_f,
+        hipLaunchKernelGGL(k_fw_gather_resolve, dim3(fw_cap((nbuckets + FWG_WAVES - 1) / FWG_WAVES)), dim3(64 * FWG_WAVES), 0, st, keys[0], slab_min, slab_max, tile_min, tile_max, N, ntiles, d_z, d_src, src_f,
                            d_warped, zero_fill ? 1 : 0, planes_H, planes_M);
         if (planes_written) *planes_written = planes_H != nullptr;
         return mpf_launch_status("forward_warp kernels");

@@ -788,17 +788,13 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
                 const uint32_t slab = ci < nct ? clist[ci] * 16 + (lane & 15u) : 0u;
                 const bool shit = ci < nct && slab_min[slab] <= hi && slab_max[slab] >= lo;
                 unsigned long long sm = __ballot(shit);
-                while (sm) {                                   // the touching slabs in raster order, four at a time (their 8 loads in flight together)
-                    if (cnt > FWG_CAP - 256) {                 // the next four slabs might not fit: fold the chunk into the carried state
-                        MPF_WAVE_SYNC();
-                        process(cnt);
-                        cnt = 0;
-                    }
-                    uint32_t key[4];
-                    float zz[4];
-                    uint32_t nn[4];
+                while (sm) {                                   // the touching slabs in raster order, EIGHT at a time (their 16 loads in flight together:
+                                                               // a bucket of c3's white-noise box sees ~165 of them, each a dependent round trip under load)
+                    uint32_t key[8];
+                    float zz[8];
+                    uint32_t nn[8];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 8; ++q) {
                         uint32_t n = 0xFFFFFFFFu;
                         if (sm) {
                             const int first = __ffsll((long long)sm) - 1;
@@ -811,14 +807,22 @@ k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restric
                         zz[q] = ok ? z[n] : 0.0f;
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool match = (key[q] >> FWG_LB) == b && nn[q] < N;
-                        const unsigned long long mm = __ballot(match);
-                        if (match) {
-                            const uint32_t pos = cnt + __popcll(mm & lt);
-                            g_src[pos] = nn[q]; g_tl[pos] = key[q] & (NT - 1); g_z[pos] = zz[q];
+                    for (int half = 0; half < 2; ++half) {
+                        if (cnt > FWG_CAP - 256) {             // the next four slabs might not fit: fold the chunk into the carried state
+                            MPF_WAVE_SYNC();
+                            process(cnt);
+                            cnt = 0;
                         }
-                        cnt += __popcll(mm);
+#pragma unroll
+                        for (int q = 4 * half; q < 4 * half + 4; ++q) {
+                            const bool match = (key[q] >> FWG_LB) == b && nn[q] < N;
+                            const unsigned long long mm = __ballot(match);
+                            if (match) {
+                                const uint32_t pos = cnt + __popcll(mm & lt);
+                                g_src[pos] = nn[q]; g_tl[pos] = key[q] & (NT - 1); g_z[pos] = zz[q];
+                            }
+                            cnt += __popcll(mm);
+                        }
                     }
                 }
             }

@@ -265,7 +265,7 @@ def make_moving_object_chain(H, W, K, dev, seed):
     disp = torch.rand((H, W), generator=g, device=dev)
     K3 = torch.from_numpy(np.asarray(K, dtype=np.float32)).reshape(3, 3)
     Ti = host_math.transformation_from_parameters(torch.zeros(1, 1, 3), torch.tensor([[0.07, -0.06, 0.08]]))
-    return moving_obj.MovingObjectChain(H, W, K3, torch.inverse(K3.double()).float(), dev, T_obj=Ti, n_buffers=4), disp
+    return moving_obj.MovingObjectChain(H, W, K3, torch.inverse(K3.double()).float(), dev, T_obj=Ti, n_buffers=6), disp
 
 
 class PipelinedWorkload:

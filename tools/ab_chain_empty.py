@@ -41,7 +41,7 @@ import runpy
 runpy.run_path(os.path.join(%r, "bench.py"), run_name="__main__")
 ''' % (ROOT, ROOT)
 for rnd in range(2):
-    for mode in ("full", "full_noguard", "empty3_noguard", "empty0_noguard"):
+    for mode in ("full", "full_noguard"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CHAIN_MODE=mode), capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])

@@ -259,7 +259,7 @@ class Workload:
 def make_moving_object_chain(H, W, K, dev, seed):
     """SURVEY 8(d)'s c3 adds "forward-warp on disp = rs.rand(H, W)": the moving-object chain of moving_obj.py:29-150 on device-resident
     inputs (mpiflow_amd.moving_obj.MovingObjectChain: projection fused into the forward splat's first sort pass, splat, masks - one C call,
-    5 launches), a fixed object pose of the reference's magnitude (moving_obj.py:81-98; the angles are zeroed there).  -> (chain, disp)"""
+    3 launches), a fixed object pose of the reference's magnitude (moving_obj.py:81-98; the angles are zeroed there).  -> (chain, disp)"""
     from mpiflow_amd import moving_obj
     g = torch.Generator(device=dev).manual_seed(4242 + seed)
     disp = torch.rand((H, W), generator=g, device=dev)
@@ -736,7 +736,7 @@ def main():
                 out["roofline_stage_b"], out["roofline_stage_ac"] = c3["stage_b"], c3["stage_ac"]
             else:
                 sub.append(sub_record("c3 pipelined: Stage B of pair i + Stage A+C of pair i+1 per launch", 64, 640, 960, 4, dev, True, 5, pipelined=True))
-            sub.append(sub_record("c3 + moving-object chain (SURVEY 8(d)'s full c3), serial: pair kernels one after the other + the chain's 5 launches on the same stream",
+            sub.append(sub_record("c3 + moving-object chain (SURVEY 8(d)'s full c3), serial: pair kernels one after the other + the chain's 3 launches on the same stream",
                                   64, 640, 960, 4, dev, True, 5, moving_object=True))
             alone = sub_record("c3 render only, pipelined (no moving-object chain: the `value` of rounds 1-3)", 64, 640, 960, 8, dev, True, 10, pipelined=True)
             sub.append(alone)

@@ -44,7 +44,7 @@ def projection_matrices(K, T_obj):
 
 class MovingObjectChain:
     """moving_obj.py:29-150 for a STREAM of frames of one size: matrices prepared once per object pose, `n_buffers` preallocated
-    output sets used round-robin (a set is rewritten n_buffers run() calls later), one C call = 5 launches per frame, no
+    output sets used round-robin (a set is rewritten n_buffers run() calls later), one C call = 3 launches per frame, no
     allocation.  pipeline.OverlappedPairRenderer runs it on a side stream underneath the pair launches."""
 
     def __init__(self, H, W, K, inv_K, device, T_obj=None, n_buffers=2):

@@ -554,13 +554,14 @@ def n1_record(dev, S=64, H=384, W=1280, iters=10):
            "layers": [{"name": r["name"], "GB": r["bytes"] / 1e9, "GFLOP": r["flops"] / 1e9} for r in rows]}
     del hp
     torch.cuda.empty_cache()
-    # the PARITY-GRADE modes of the same network (mpiflow_amd.model.precise.PrecisePredictor: every convolution on mpf_pconv, fp32 with fp64 carries
-    # or fp64 throughout; materialised fp32 / fp64 NHWC activations; eager launches).  Rooflines: the dense fp32 / fp64 MFMA rates (157 / 79 TFLOP/s).
+    # the PARITY-GRADE modes of the same network (mpiflow_amd.model.precise.PrecisePredictor: every convolution on mpf_pconv; materialised fp32 / fp64 NHWC
+    # activations; eager launches).  fp32 = what --model-dtype fp32 runs: products from bf16 pieces on the matrix cores (six bf16 MFMA flops per algorithmic
+    # flop, so its ceiling is a sixth of the dense bf16 rate); fp32_mfma / fp64: the dense fp32 / fp64 MFMA rates (157 / 79 TFLOP/s).
     from mpiflow_amd.model.precise import PrecisePredictor
     rec["precise"] = {}
-    for name, dt, peak in (("fp32", torch.float32, 157.3e12), ("fp64", torch.float64, 78.6e12)):
+    for name, dt, x3, peak in (("fp32", torch.float32, True, MFMA_F16_PEAK / 6), ("fp32_mfma", torch.float32, False, 157.3e12), ("fp64", torch.float64, False, 78.6e12)):
         try:
-            pp = PrecisePredictor(m, dtype=dt)
+            pp = PrecisePredictor(m, dtype=dt, x3=x3)
             pp(img, dsp)
             torch.cuda.synchronize()
             e0.record()
@@ -570,8 +571,10 @@ def n1_record(dev, S=64, H=384, W=1280, iters=10):
             torch.cuda.synchronize()
             tp = e0.elapsed_time(e1) / 2 * 1e-3
             _, ptot = pp.accounting()
-            rec["precise"][name] = {"workload": "the same image on the parity-grade engine, %s (tests/test_precise_engine.py: fp64 = the torch modules in double to 1e-10; fp32 closer to "
-                                                "them than torch's own fp32)" % name, "ms_per_image": tp * 1e3, "launches": len(pp.layers()) + 20,
+            what = {"fp32": "fp32 tensors, products from the three bf16 pieces of each factor on v_mfma_f32_16x16x32_bf16, fp32 blocks of 64 products carried in fp64",
+                    "fp32_mfma": "fp32 tensors, products on v_mfma_f32_16x16x4_f32, fp32 blocks of 64 products carried in fp64", "fp64": "fp64 throughout"}[name]
+            rec["precise"][name] = {"workload": "the same image on the parity-grade engine: %s (tests/test_precise_engine.py: fp64 = the torch modules in double to 1e-10; both fp32 "
+                                                "forms closer to them than torch's own fp32)" % what, "ms_per_image": tp * 1e3, "launches": len(pp.layers()) + 20,
                                     "algorithmic_flops_per_image": ptot["flops"], "materialised_bytes_per_image": ptot["bytes"],
                                     "mfma": {"bound": "mfma", "achieved": ptot["flops"] / tp / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ptot["flops"] / tp / peak}}
             del pp
@@ -770,8 +773,9 @@ def main():
                 out["generator"] = {"error": repr(e)}
             try:                                                     # the same generator with the PARITY-GRADE producer (every convolution in fp32 on mpf_pconv): a short run
                 out["generator_precise"] = generator_record(n_images=24, n_distinct=24, model_dtype="fp32")
-                out["generator_precise"]["producer_precision"] = ("parity-grade engine: fp32 storage / products, fp32 MFMA accumulation carried in fp64 (tests/test_precise_engine.py: "
-                                                                  "closer to the fp64 mirror than torch's own fp32); ~59 ms per image, so the generator is bound by it")
+                out["generator_precise"]["producer_precision"] = ("parity-grade engine (--model-dtype fp32): fp32 tensors, products from bf16 pieces on the matrix cores, fp32 blocks of "
+                                                                  "64 products carried in fp64 (tests/test_precise_engine.py: closer to the fp64 mirror than torch's own fp32); "
+                                                                  "~43 ms per image, so the generator is bound by it")
             except Exception as e:                                   # noqa: BLE001
                 out["generator_precise"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:

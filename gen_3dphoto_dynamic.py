@@ -66,11 +66,13 @@ def parse(argv=None):
     p.add_argument("--mpi-from", choices=["model", "npz", "disparity"], default="model",
                    help="model: the AdaMPI network from --ckpt_path, as the reference always does; npz: precomputed stacks base/mpis/NAME.npz; "
                         "disparity: a hard-assignment stand-in built from the disparity map (NOT the reference's producer - for smoke runs)")
-    p.add_argument("--model-dtype", choices=["auto", "fp16", "bf16", "fp32", "fp64"], default="auto",
+    p.add_argument("--model-dtype", choices=["auto", "fp16", "bf16", "fp32", "fp32-mfma", "fp64"], default="auto",
                    help="arithmetic of the network.  --model-engine hip: auto | fp16 = the fast engine (fp16 storage, fp32 accumulate, 7.7 ms per image); fp32 = the "
-                        "PARITY-GRADE engine, every convolution on mpf_pconv in the arithmetic of the reference's CPU path (fp32 storage / products / accumulation on "
-                        "v_mfma_f32_16x16x4_f32); fp64 = the same kernels in double (equals the torch modules run in double to 1e-10).  --model-engine torch: "
-                        "auto | fp32 = plain fp32, fp16 | bf16 = torch autocast")
+                        "PARITY-GRADE engine, every convolution on mpf_pconv in the arithmetic class of the reference's CPU path: fp32 tensors, every product from the "
+                        "three bf16 pieces each fp32 factor is exactly the sum of (on the bf16 matrix cores; 2^-24 relative per product), fp32 accumulation in blocks of "
+                        "64 products carried in fp64 - closer to the network in exact arithmetic than torch's own fp32; fp32-mfma = the same engine with the products on "
+                        "v_mfma_f32_16x16x4_f32 (a third slower); fp64 = the same kernels in double (equals the torch modules run in double to 1e-10).  "
+                        "--model-engine torch: auto | fp32 = plain fp32, fp16 | bf16 = torch autocast")
     p.add_argument("--model-engine", choices=["hip", "torch"], default="hip",
                    help="hip (default): the whole network on this repo's HIP kernels - the per-plane feature-mask UNet and gated decoder (> 98 %% of "
                         "the flops) on the fp16 MFMA convolution engine (fp16 storage, fp32 accumulate: the precision of the reference's own GPU run, which "
@@ -197,9 +199,9 @@ def main(argv=None):
     amp = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(opt.model_dtype) if opt.model_engine == "torch" else None
     if opt.model_engine == "hip" and opt.model_dtype == "bf16":
         raise SystemExit("gen_3dphoto_dynamic: --model-engine hip computes in fp16 (auto), fp32 or fp64; bf16 is a torch autocast dtype (--model-engine torch)")
-    if opt.model_engine == "torch" and opt.model_dtype == "fp64":
-        raise SystemExit("gen_3dphoto_dynamic: --model-dtype fp64 is the HIP precise engine's (--model-engine hip)")
-    precise_dtype = {"fp32": torch.float32, "fp64": torch.float64}.get(opt.model_dtype) if opt.model_engine == "hip" else None
+    if opt.model_engine == "torch" and opt.model_dtype in ("fp64", "fp32-mfma"):
+        raise SystemExit("gen_3dphoto_dynamic: --model-dtype %s is the HIP precise engine's (--model-engine hip)" % opt.model_dtype)
+    precise_dtype = {"fp32": torch.float32, "fp32-mfma": torch.float32, "fp64": torch.float64}.get(opt.model_dtype) if opt.model_engine == "hip" else None
     if opt.mpi_from == "model":                                            # the reference's only producer (:52-60, :92-93)
         from mpiflow_amd.model import MPIPredictor
         if opt.ckpt_path.startswith("random:"):
@@ -244,7 +246,7 @@ def main(argv=None):
                 self.hip_model = None
                 if use_hip_model and precise_dtype is not None:
                     from mpiflow_amd.model.precise import PrecisePredictor
-                    self.hip_model = PrecisePredictor(model, dtype=precise_dtype)      # the accuracy mode: fp32 / fp64 on mpf_pconv
+                    self.hip_model = PrecisePredictor(model, dtype=precise_dtype, x3=opt.model_dtype == "fp32")      # the accuracy mode: fp32 / fp64 on mpf_pconv
                 elif use_hip_model:
                     from mpiflow_amd.model.engine import HipPredictor
                     self.hip_model = HipPredictor(model, graph=True)

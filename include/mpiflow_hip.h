@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPF_VERSION 501   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
+#define MPF_VERSION 502   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
                              round 4 (401): + mpf_moving_object_chain, mpf_warp_views_blend_next_merge_prev, mpf_stream_create_cu_subset / _destroy,
                              mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6;
                              round 5 (501): + the parity-grade producer engine mpf_pconv, mpf_pfmn_input, mpf_pencoder_input, mpf_pbilinear2x, mpf_pper_plane,
@@ -426,6 +426,11 @@ int mpf_maxpool3x3s2_f32(const float *d_src_HWC, int Hin, int Win, int C, float 
  * `gen_3dphoto_dynamic.py --model-engine hip --model-dtype fp32|fp64` (mpiflow_amd/model/precise.py: PrecisePredictor). */
 #define MPF_DTYPE_F32 0
 #define MPF_DTYPE_F64 1
+#define MPF_DTYPE_F32X3      2 /* mpf_pconv only: fp32 tensors; every product a b from the three bf16 pieces each factor is exactly the sum of (six of the nine
+                                * piece products: a relative 2^-24 per product dropped) on v_mfma_f32_16x16x32_bf16; accumulation as MPF_DTYPE_F32.  1 x 1 and 3 x 3.
+                                * wpack: [nblk][steps][3 pieces][64 lanes][8] bf16, a step = two K-steps of the fp32 packing, every source padded to an even count */
+#define MPF_DTYPE_F32X3_TILE 3 /* the same arithmetic for 3 x 3 / stride 1 / padding 1 layers with CA + CB <= 56 and nblk <= 3: the input tile of both sources is
+                                * split once into LDS.  wpack: K-vector 4 t + g = (tap, 8-channel vector of the CONCATENATED channels, zero-padded to 8) */
 #define MPF_PCONV_EP_AFFINE       0   /* out [S,Hout,Wout,Cst] = act(acc * scale[row] + shift[row] (+ residual))   (ConvBNReLU model/CPN/unet.py:6-15; the encoder's conv + BN) */
 #define MPF_PCONV_EP_AFFINE_MAP   1   /* same, row 0 only, out [S,Hout,Wout]   (the feature-mask logits, model/CPN/unet.py:66) */
 #define MPF_PCONV_EP_GATED        2   /* g = accF * sigmoid(accM) (biases = initial accumulators); out NHWC = elu(g * scale[c] + shift[c])   (model/CPN/decoder.py:10-71) */
@@ -448,7 +453,7 @@ typedef struct MpfPConvArgs {
     const void *bias;                 /* dtype [nblk*16], gated epilogues only */
     const void *residual;             /* dtype [S,Hout,Wout,Cst] or NULL (EP_AFFINE) */
     void *out;
-    int dtype;                        /* MPF_DTYPE_F32 | MPF_DTYPE_F64 */
+    int dtype;                        /* MPF_DTYPE_F32 | MPF_DTYPE_F64 | MPF_DTYPE_F32X3 | MPF_DTYPE_F32X3_TILE (tensors fp32 for the last two) */
     int S, Hin, Win, Hout, Wout;      /* Hin x Win: the virtual conv input (after up-sampling) */
     int HA, WA, CA, CB;
     int up, shareA, shareB;

@@ -15,6 +15,10 @@
 // K-step: lane (m = l % 16, g = l / 16) loads the 4 channels of K-vector 4 step + g at pixel m (one 16- or 32-byte buffer load) and the
 // matching 4 weights of row m; the 4 elements feed 4 MFMAs (any permutation of K is a valid GEMM as long as both operands use it).
 #include "mpf_common.h"
+#include <type_traits>
+#ifndef MPF_X3_ABLATE
+#define MPF_X3_ABLATE 0
+#endif
 
 namespace {
 
@@ -55,6 +59,67 @@ __device__ __forceinline__ T act_apply(T y, int act, T slope)
     if (act == 1) return y > (T)0 ? y : (T)0;
     if (act == 2) return y > (T)0 ? y : y * slope;
     return y;
+}
+
+// The epilogue of every convolution kernel.  lane (m, g): acc[nb][pg][i] = LOGICAL row 4g + i of block bg * NB + nb at pixel pix[pg] of the plane (P pixels; a
+// value >= P: no pixel).  The host permutes the rows of a block for the fp64 instruction, whose C/D layout is row = g + 4 i: mpiflow_amd/model/precise.py
+template <typename T, int NB, int PG>
+__device__ __forceinline__ void pconv_epilogue(const MpfPConvArgs &a, const typename Vec4<T>::type (&acc)[NB][PG], const int (&pix)[PG], const int g, const int bg,
+                                               const int s, const int P)
+{
+    typedef typename Vec4<T>::type v4;
+    typedef typename Vec2<T>::type v2;
+    const T *scale = reinterpret_cast<const T *>(a.scale), *shift = reinterpret_cast<const T *>(a.shift);
+    T *out = reinterpret_cast<T *>(a.out);
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+        const int p = pix[pg];
+        if (p >= P) continue;
+        const size_t opix = (size_t)s * P + p;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int blk = bg * NB + nb;
+            const v4 c = acc[nb][pg];
+            if (a.epi == EP_AFFINE || a.epi == EP_AFFINE_MAP) {
+                const int ch = blk * 16 + 4 * g;
+                const v4 sc = *reinterpret_cast<const v4 *>(scale + ch), sh = *reinterpret_cast<const v4 *>(shift + ch);
+                v4 y;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = c[i] * sc[i] + sh[i];       // eval-mode BatchNorm folded with the conv bias (two roundings, as written)
+                if (a.epi == EP_AFFINE_MAP) {
+                    if (ch == 0) out[opix] = act_apply<T>(y[0], a.act, (T)a.slope);       // single-channel map [S,H,W]
+                } else if (ch < a.Cst) {
+                    if (a.residual) {
+                        const v4 r = *reinterpret_cast<const v4 *>(reinterpret_cast<const T *>(a.residual) + opix * a.Cst + ch);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] += r[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = act_apply<T>(y[i], a.act, (T)a.slope);
+                    *reinterpret_cast<v4 *>(out + opix * a.Cst + ch) = y;
+                }
+            } else {
+                // logical rows (4g, 4g+1) = (feature, gate) of channel 8 blk + 2g, rows (4g+2, 4g+3) of channel 8 blk + 2g + 1; the biases were the
+                // accumulators' initial values.  model/CPN/decoder.py:66-70: conv2d(x) * sigmoid(mask_conv2d(x))
+                const int ch = blk * 8 + 2 * g;
+                T y[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) y[j] = c[2 * j] * sigmoid_t<T>(c[2 * j + 1]);
+                if (a.epi == EP_GATED) {                                // + BatchNorm + ELU (model/CPN/decoder.py:36-40)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const T t = y[j] * scale[ch + j] + shift[ch + j];
+                        y[j] = t > (T)0 ? t : expm1_t(t);
+                    }
+                    if (ch < a.Cst) *reinterpret_cast<v2 *>(out + opix * a.Cst + ch) = v2{y[0], y[1]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (ch + j < a.Cst) out[((size_t)s * a.Cst + ch + j) * P + p] = y[j];   // planar [S, Cst, H, W]
+                }
+            }
+        }
+    }
 }
 
 template <typename T, int NB, int PG>
@@ -193,59 +258,407 @@ __global__ __launch_bounds__(256) void k_pconv(const MpfPConvArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[nb][pg][i] = (T)carry[nb][pg][i];       // ONE rounding of the whole sum to fp32
     }
-    // lane (m, g): acc[nb][pg][i] = LOGICAL row 4g + i of block bg * NB + nb, pixel p0 + 16 pg + m (the host permutes the rows of a block for the
-    // fp64 instruction, whose C/D layout is row = g + 4 i: mpiflow_amd/model/precise.py)
-    const T *scale = reinterpret_cast<const T *>(a.scale), *shift = reinterpret_cast<const T *>(a.shift);
-    T *out = reinterpret_cast<T *>(a.out);
+    int pix[PG];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) pix[pg] = p0 + 16 * pg + m;
+    pconv_epilogue<T, NB, PG>(a, acc, pix, g, bg, s, P);
+}
+
+// ---- fp32-grade products on the bf16 matrix cores ("x3") -------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate and on the vector pipe (157 TFLOP/s, shared with every addressing instruction);
+// v_mfma_f32_16x16x32_bf16 is sixteen times faster and has the matrix pipe to itself.  An fp32 number is EXACTLY the sum of three bf16
+// numbers (a1 = bf16(a), a2 = bf16(a - a1), a3 = a - a1 - a2: both subtractions are exact in fp32 and the last residual has at most
+// 8 significant bits), bf16 x bf16 products are exact in the instruction's fp32 accumulation, so
+//     a b = a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1) + (a2 b3 + a3 b2) + a3 b3
+// with the terms of relative size 1, 2^-8, 2^-16, 2^-24, 2^-32.  TERMS = 6 drops the last three (a relative 2^-24 per product, the size of
+// the rounding of an fp32 product, signed and unbiased because the split rounds to nearest), TERMS = 8 only a3 b3.  The leading products go
+// into one accumulator, the small ones into a second one, both are added into the fp64 carries every FLUSH steps (64 leading products):
+// the same two-level sum as k_pconv<float>.  Weights are split on the host (pack_weights_x3), activations in the loader: 9 VALU
+// instructions per pair of elements (v_cvt_pk_bf16_f32 x3, two shifts / masks x2, v_pk_add_f32 x2), shared by the NB row blocks.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ Vec4<float>::type mfma_bf16(const u32x4_t a, const u32x4_t b, const Vec4<float>::type c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// two fp32 values -> their three bf16 pieces, packed (low half = the first value)
+struct Pieces { unsigned p[3]; };
+__device__ __forceinline__ Pieces split3(const float a0, const float a1)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    Pieces r;
+    const f2 a = {a0, a1};
+    r.p[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_t));
+    const f2 ra = a - f2{__builtin_bit_cast(float, r.p[0] << 16), __builtin_bit_cast(float, r.p[0] & 0xffff0000u)};      // exact (v_pk_add_f32)
+    r.p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, bf16x2_t));
+    const f2 rb = ra - f2{__builtin_bit_cast(float, r.p[1] << 16), __builtin_bit_cast(float, r.p[1] & 0xffff0000u)};     // exact, at most 8 significant bits left
+    r.p[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rb, bf16x2_t));
+    return r;
+}
+
+template <int NB, int PG, int TERMS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_pconv_x3(const MpfPConvArgs a)       // <= 256 registers: the MFMAs take their accumulators in VGPRs (no AGPR copies around the carries)
+{
+    typedef Vec4<float>::type v4;
+    typedef Vec4<double>::type v4d;
+    constexpr unsigned VEC = 16, INVALID = 0xC0000000u, WSTEP = 3 * 64 * 16;      // WSTEP: bytes of one step of one row block = three pieces x 64 lanes x 8 bf16
+    constexpr int MAXTAP = 9;
+    // the four waves of a workgroup (different pixels, the SAME NB row blocks) share the weights: every step's NB x 3 fragments go global -> LDS once per
+    // workgroup (LDS-DMA, no registers), two buffers, one barrier per step.  Per-wave fragment loads made the kernel L1-bound: 10 KB of operands per 24 MFMAs
+    // = 104 B / clock / CU against the ~57 the vector-memory path delivers (profiles/r5/precise_x3.txt)
+    __shared__ __attribute__((aligned(16))) char wlds[2 * NB * WSTEP];
+    // the byte offset of every tap's pixel, per lane and pixel group: computed once per source, looked up per step (the bounds / reflection logic of
+    // k_pconv's cursor ran on every step - divergent, ~40 instructions - and the VALU is what this kernel has least of)
+    __shared__ unsigned ptab[4][MAXTAP + 1][PG][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;
+    const int P = a.Hout * a.Wout;
+    const int p0 = ((int)blockIdx.x * 4 + wave) * (16 * PG);             // a wave past the last pixel stays for the barriers and the weight copies
+    const int bg = blockIdx.y, s = blockIdx.z;
+    const int VA = a.CA >> 2, VB = a.CB >> 2, ks = a.ksize, ntap = ks * ks;
+    // a step = 32 K elements = TWO of k_pconv's K-steps: lane (m, g) holds the 4 channels of K-vector 4 (2 t) + g, then those of K-vector 4 (2 t + 1) + g;
+    // every source is padded to an even number of the old steps (zero weights; the cursor is past the last tap there and loads zeros)
+    const int n2A = (((ntap * VA + 3) >> 2) + 1) >> 1, n2B = (((ntap * VB + 3) >> 2) + 1) >> 1, nsteps = n2A + n2B;
+    int oy[PG], ox[PG];
+    bool pv[PG];
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
         const int p = p0 + 16 * pg + m;
-        if (p >= P) continue;
-        const size_t opix = (size_t)s * P + p;
+        pv[pg] = p < P;
+        const int pc = pv[pg] ? p : 0;
+        oy[pg] = pc / a.Wout;
+        ox[pg] = pc - oy[pg] * a.Wout;
+        oy[pg] = oy[pg] * a.stride - a.pad;
+        ox[pg] = ox[pg] * a.stride - a.pad;
+    }
+    const v4 zero = {0.f, 0.f, 0.f, 0.f};
+    // accH: the leading products a1 b1 of TWO steps (64 products), then added into the fp64 carries - the two-level sum of k_pconv<float>; the first of the
+    // two steps starts from the instruction's zero operand, so the accumulators are never cleared.  accL: everything else - 2^-8 of the leading sum and
+    // below, so its own fp32 roundings are 2^-32 of the result - runs through the whole K loop and is added once.
+    v4 accH[NB][PG], accL[NB][PG];
+    v4d carry[NB][PG];
+    const bool gated = a.epi == EP_GATED || a.epi == EP_GATED_PLANAR;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int blk = bg * NB + nb;
-            const v4 c = acc[nb][pg];
-            if (a.epi == EP_AFFINE || a.epi == EP_AFFINE_MAP) {
-                const int ch = blk * 16 + 4 * g;
-                const v4 sc = *reinterpret_cast<const v4 *>(scale + ch), sh = *reinterpret_cast<const v4 *>(shift + ch);
-                v4 y;
+    for (int nb = 0; nb < NB; ++nb) {
+        v4 init = zero;
+        if (gated) init = *reinterpret_cast<const v4 *>(reinterpret_cast<const float *>(a.bias) + (bg * NB + nb) * 16 + 4 * g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = c[i] * sc[i] + sh[i];       // eval-mode BatchNorm folded with the conv bias (two roundings, as written)
-                if (a.epi == EP_AFFINE_MAP) {
-                    if (ch == 0) out[opix] = act_apply<T>(y[0], a.act, (T)a.slope);       // single-channel map [S,H,W]
-                } else if (ch < a.Cst) {
-                    if (a.residual) {
-                        const v4 r = *reinterpret_cast<const v4 *>(reinterpret_cast<const T *>(a.residual) + opix * a.Cst + ch);
+        for (int pg = 0; pg < PG; ++pg) {
+            carry[nb][pg] = v4d{(double)init[0], (double)init[1], (double)init[2], (double)init[3]};
+            accH[nb][pg] = zero;
+            accL[nb][pg] = zero;
+        }
+    }
+    const bool reflect = a.pad_mode == 1;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(a.srcA)) + (a.shareA ? (size_t)0 : (size_t)s * a.HA * a.WA * a.CA * 4), 0, (unsigned)((size_t)a.HA * a.WA * a.CA * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(VB ? a.srcB : a.srcA)) + ((a.shareB || !VB) ? (size_t)0 : (size_t)s * a.Hin * a.Win * a.CB * 4), 0,
+        (unsigned)(VB ? (size_t)a.Hin * a.Win * a.CB * 4 : 0), 0x00020000);
+    // weights: fragment f = nb * 3 + piece of step t lives at ((bg NB + nb) nsteps + t) WSTEP + piece KB; wave w copies fragments w, w + 4, ...
+    const char *wg = reinterpret_cast<const char *>(a.wpack) + (size_t)bg * NB * nsteps * WSTEP + (unsigned)lane * 16u;
+    int wreq = 0;                                                        // the next step whose weights have not been requested
+    auto weights_upto = [&](const int t) {
+        for (; wreq <= t && wreq < nsteps; ++wreq) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) y[i] += r[i];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = act_apply<T>(y[i], a.act, (T)a.slope);
-                    *reinterpret_cast<v4 *>(out + opix * a.Cst + ch) = y;
-                }
-            } else {
-                // logical rows (4g, 4g+1) = (feature, gate) of channel 8 blk + 2g, rows (4g+2, 4g+3) of channel 8 blk + 2g + 1; the biases were the
-                // accumulators' initial values.  model/CPN/decoder.py:66-70: conv2d(x) * sigmoid(mask_conv2d(x))
-                const int ch = blk * 8 + 2 * g;
-                T y[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) y[j] = c[2 * j] * sigmoid_t<T>(c[2 * j + 1]);
-                if (a.epi == EP_GATED) {                                // + BatchNorm + ELU (model/CPN/decoder.py:36-40)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const T t = y[j] * scale[ch + j] + shift[ch + j];
-                        y[j] = t > (T)0 ? t : expm1_t(t);
-                    }
-                    if (ch < a.Cst) *reinterpret_cast<v2 *>(out + opix * a.Cst + ch) = v2{y[0], y[1]};
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (ch + j < a.Cst) out[((size_t)s * a.Cst + ch + j) * P + p] = y[j];   // planar [S, Cst, H, W]
+            for (int j = 0; j < (NB * 3 + 3) / 4; ++j) {
+                const int f = wave + 4 * j;                              // wave-uniform
+                if ((NB * 3) % 4 == 0 || f < NB * 3) {
+                    const int nb = f / 3, q = f - 3 * nb;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wg + ((size_t)(nb * nsteps + wreq) * WSTEP + (unsigned)q * 1024u)),
+                                                     (__attribute__((address_space(3))) void *)(wlds + ((wreq & 1) * NB * 3 + f) * 1024), 16, 0, 0);
                 }
             }
         }
+    };
+    struct Pixels { v4 x0[PG], x1[PG]; };
+    // FIRST: the first of the two steps between flushes (leading accumulators start from zero)
+    auto compute = [&](const Pixels &o, const int step, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        u32x4_t xp[PG][3];
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+#if MPF_X3_ABLATE == 2                                                   // timing ablation ONLY (tools/build_ablate_x3.sh): no split
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xp[pg][q] = u32x4_t{__builtin_bit_cast(unsigned, o.x0[pg][q]), __builtin_bit_cast(unsigned, o.x0[pg][3]), __builtin_bit_cast(unsigned, o.x1[pg][q]), __builtin_bit_cast(unsigned, o.x1[pg][3])};
+#else
+            const Pieces q0 = split3(o.x0[pg][0], o.x0[pg][1]), q1 = split3(o.x0[pg][2], o.x0[pg][3]), q2 = split3(o.x1[pg][0], o.x1[pg][1]), q3 = split3(o.x1[pg][2], o.x1[pg][3]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xp[pg][q] = u32x4_t{q0.p[q], q1.p[q], q2.p[q], q3.p[q]};
+#endif
+        }
+        const char *wb = wlds + (step & 1) * (NB * WSTEP) + lane * 16;
+        // by weight piece (its NB fragments are read from LDS once); the terms of the FIRST activation piece first - it is ready after one conversion, the
+        // matrix pipe starts while the vector pipe still splits; NB x PG independent accumulators between dependent issues
+#pragma unroll
+        for (int qa = 2; qa >= 0; --qa) {
+            u32x4_t w[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) w[nb] = *reinterpret_cast<const u32x4_t *>(wb + (nb * 3 + qa) * 1024);
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) {
+                if (qa + qb > (TERMS == 8 ? 3 : 2)) continue;            // six terms: pieces (a, b) with a + b <= 2; eight: all but (2, 2)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int pg = 0; pg < PG; ++pg) {
+#if MPF_X3_ABLATE == 1                                                   // timing ablation ONLY: no MFMA (one VALU op keeps the operands alive)
+                        if (qa + qb == 0) accH[nb][pg][0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, FIRST ? 0.f : accH[nb][pg][0]) ^ w[nb][0] ^ xp[pg][qb][0]);
+                        else if (qa + qb == 2 && qa == 1) accL[nb][pg][0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, accL[nb][pg][0]) ^ w[nb][1] ^ xp[pg][qb][1] ^ xp[pg][2][2] ^ w[nb][3]);
+#else
+                        if (qa + qb == 0) accH[nb][pg] = mfma_bf16(w[nb], xp[pg][qb], FIRST ? zero : accH[nb][pg]);
+                        else accL[nb][pg] = mfma_bf16(w[nb], xp[pg][qb], accL[nb][pg]);
+#endif
+                    }
+            }
+        }
+    };
+    auto flush = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) carry[nb][pg][i] += (double)accH[nb][pg][i];
+    };
+    int step = 0;
+    // one source: its K-vectors v = tap * Vs + c4, four per old step, two old steps per step.  The pixels and the weights of step t + 1 are requested before
+    // step t is computed (two register sets / two LDS buffers, the loop unrolled by two); the barrier at the top of a step (hipcc drains vmcnt before it) makes
+    // step t's weights visible to every wave and says that every wave is done reading the buffer step t + 1's weights go to.  The pixel request past a
+    // source's last step reads zeros and is dropped.
+    auto segment = [&](const __amdgpu_buffer_rsrc_t rs, const int Vs, const int n2, const int up, const int pitch) {
+        // tap table of this source (a wave reads only what it wrote: no barrier; the previous source's last lookups are done - their loads were issued)
+        for (int t = 0; t <= ntap; ++t) {
+            const int ky = t / ks, kx = t - ky * ks;
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) {
+                int iy = oy[pg] + ky, ix = ox[pg] + kx;
+                bool ok = pv[pg] && t < ntap;                            // past the last tap: zero operands (the packed weights are zero there too)
+                if (reflect) {                                           // nn.ReflectionPad2d(1), model/CPN/decoder.py:23
+                    iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * a.Hin - 2 - iy : iy);
+                    ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * a.Win - 2 - ix : ix);
+                } else {
+                    ok = ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                }
+                ptab[wave][t][pg][lane] = ok ? (unsigned)((iy >> up) * pitch + (ix >> up)) * ((unsigned)Vs * VEC) : INVALID;
+            }
+        }
+        int tp = g / Vs, c4 = g - tp * Vs;
+        auto request = [&](v4 (&x)[PG]) {
+            const int tc = tp < ntap ? tp : ntap;
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) x[pg] = buf_load4(rs, ptab[wave][tc][pg][lane] + (unsigned)c4 * VEC, 0u, float());
+            c4 += 4;
+            if (Vs >= 4) {                                               // uniform
+                const bool wrap = c4 >= Vs;
+                c4 -= wrap ? Vs : 0;
+                tp += wrap ? 1 : 0;
+            } else {
+                while (c4 >= Vs) { c4 -= Vs; ++tp; }
+            }
+        };
+        Pixels A, B;
+        request(A.x0);
+        request(A.x1);
+        weights_upto(step);
+        for (int st = 0; st < n2; st += 2) {
+#if MPF_X3_ABLATE != 3                                                   // timing ablation ONLY: no barrier
+            __syncthreads();
+#endif
+            request(B.x0);
+            request(B.x1);
+            weights_upto(step + 1);
+            compute(A, step++, std::true_type());
+            if (st + 1 < n2) {
+#if MPF_X3_ABLATE != 3
+                __syncthreads();
+#endif
+                request(A.x0);
+                request(A.x1);
+                weights_upto(step + 1);
+                compute(B, step++, std::false_type());
+            }
+            flush();
+        }
+    };
+    segment(rsA, VA, n2A, a.up, a.WA);
+    if (VB) segment(rsB, VB, n2B, 0, a.Win);
+    if (p0 >= P) return;
+    v4 acc[NB][PG];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[nb][pg][i] = (float)(carry[nb][pg][i] + (double)accL[nb][pg][i]);        // ONE rounding of the whole sum to fp32
+    int pix[PG];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) pix[pg] = p0 + 16 * pg + m;
+    pconv_epilogue<float, NB, PG>(a, acc, pix, g, bg, s, P);
+}
+
+// The few-channel layers at full resolution (the UNet's first / last levels, the decoder's last level: a third of the forward) have a dozen K steps per wave
+// and spend them loading, bounds-checking and splitting every input element nine times - once per tap.  k_pconv_x3_tile: 3 x 3, stride 1, padding 1, at most
+// 56 input channels and 3 row blocks.  A workgroup owns an 8 x 16 pixel tile of one plane: its 10 x 18 halo of BOTH sources (concatenated, the first one
+// optionally x2 nearest up-sampled, padding resolved) is loaded and split ONCE into LDS as [pixel][8-channel vector][piece][8 bf16]; the K loop - K-vector
+// 4 t + g = (tap, 8-channel vector) - reads its three activation pieces with one ds_read_b128 each and has no bounds logic left.  Weights per
+// wave from global memory (registers, two steps ahead) in the K order of this kernel (pack_weights_x3_tile).
+constexpr int TILE_H = 8, TILE_W = 16, HALO_W = TILE_W + 2, HALO_PIX = (TILE_H + 2) * HALO_W;
+__host__ __device__ constexpr int tile_pix_bytes(int V8) { return V8 * 48 + (V8 % 2 == 0 ? 16 : 0); }      // 4 x odd dwords: 16 consecutive pixels' 16-byte reads cover the 64 banks once
+
+template <int NB, int TERMS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_pconv_x3_tile(const MpfPConvArgs a)
+{
+    typedef Vec4<float>::type v4;
+    typedef Vec4<double>::type v4d;
+    constexpr int PG = 2;
+    constexpr unsigned WSTEP = 3 * 64 * 16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *const tile = lds;                                              // [HALO_PIX][PIXB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;
+    const int P = a.Hout * a.Wout;
+    const int tx0 = blockIdx.x * TILE_W, ty0 = blockIdx.y * TILE_H;
+    const int nbg = a.nblk / NB, s = blockIdx.z / nbg, bg = blockIdx.z - s * nbg;
+    const int VA = a.CA >> 2, VT = (a.CA + a.CB) >> 2, V8 = (VT + 1) >> 1, PIXB = tile_pix_bytes(V8);
+    const int nsteps = (9 * V8 + 3) >> 2;
+    // ---- weights: per wave, global / L2 -> registers, requested two steps ahead (three register sets, the K loop unrolled by three): with a dozen steps per
+    // tile a workgroup-shared LDS copy costs one barrier + one exposed L2 latency per step (measured: 2.5 x the MFMA time of the layer)
+    __amdgpu_buffer_rsrc_t rsW[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        rsW[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.wpack)) + (size_t)(bg * NB + nb) * nsteps * WSTEP, 0,
+                                                    (unsigned)((size_t)nsteps * WSTEP), 0x00020000);
+    struct Weights { u32x4_t w[NB][3]; };
+    auto weights = [&](Weights &o, const int t) {                        // past the last step: out of the descriptor's range, zeros
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) o.w[nb][q] = __builtin_amdgcn_raw_buffer_load_b128(rsW[nb], (unsigned)lane * 16u + (unsigned)q * 1024u, (unsigned)t * WSTEP, 0);
+    };
+    Weights W0, W1, W2;
+    weights(W0, 0);
+    weights(W1, 1);
+    // ---- the halo tile, one source after the other (a uniform buffer descriptor per pass; a padding pixel / a zero vector = an out-of-range offset);
+    // when the vector count is odd the pass of the last source also writes the zero vector that completes the last 8-channel vector
+    {
+        const bool reflect = a.pad_mode == 1;
+        auto stage = [&](const __amdgpu_buffer_rsrc_t rs, const int Vsrc, const int Viter, const int vbase, const int up, const int pitch) {
+            const int items = HALO_PIX * Viter;
+            const unsigned inv = (65536u + (unsigned)Viter - 1u) / (unsigned)Viter;      // i / Viter for i < 4096, Viter <= 15 (i * Viter < 2^16)
+            constexpr int BATCH = 4;                                     // loads in flight per thread: the staging is latency, not bandwidth
+            for (int i0 = tid; i0 < items; i0 += 256 * BATCH) {
+                v4 x[BATCH];
+                int dst[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int i = i0 + 256 * k;
+                    const int px = (int)(((unsigned)i * inv) >> 16), v = i - px * Viter, hy = px / HALO_W, hx = px - hy * HALO_W;
+                    int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+                    if (reflect) {                                       // nn.ReflectionPad2d(1); rows / columns past the image's mirror line belong to no output pixel
+                        iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * a.Hin - 2 - iy : iy);
+                        ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * a.Win - 2 - ix : ix);
+                    }
+                    const bool ok = i < items && v < Vsrc && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                    x[k] = buf_load4(rs, ok ? (unsigned)(((iy >> up) * pitch + (ix >> up)) * Vsrc + v) * 16u : 0xC0000000u, 0u, float());
+                    dst[k] = i < items ? px * PIXB + ((vbase + v) >> 1) * 48 + ((vbase + v) & 1) * 8 : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    if (dst[k] < 0) continue;
+                    const Pieces q0 = split3(x[k][0], x[k][1]), q1 = split3(x[k][2], x[k][3]);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2 *>(tile + dst[k] + q * 16) = make_uint2(q0.p[q], q1.p[q]);
+                }
+            }
+        };
+        const int VB = VT - VA, odd = VT & 1;
+        stage(__builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.srcA)) + (a.shareA ? (size_t)0 : (size_t)s * a.HA * a.WA * a.CA * 4), 0,
+                                                (unsigned)((size_t)a.HA * a.WA * a.CA * 4), 0x00020000), VA, VA + (VB ? 0 : odd), 0, a.up, a.WA);
+        if (VB)
+            stage(__builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.srcB)) + (a.shareB ? (size_t)0 : (size_t)s * a.Hin * a.Win * a.CB * 4), 0,
+                                                    (unsigned)((size_t)a.Hin * a.Win * a.CB * 4), 0x00020000), VB, VB + odd, VA, 0, a.Win);
     }
+    const v4 zero = {0.f, 0.f, 0.f, 0.f};
+    v4 accH[NB][PG], accL[NB][PG];
+    v4d carry[NB][PG];
+    const bool gated = a.epi == EP_GATED || a.epi == EP_GATED_PLANAR;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        v4 init = zero;
+        if (gated) init = *reinterpret_cast<const v4 *>(reinterpret_cast<const float *>(a.bias) + (bg * NB + nb) * 16 + 4 * g);
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+            carry[nb][pg] = v4d{(double)init[0], (double)init[1], (double)init[2], (double)init[3]};
+            accH[nb][pg] = zero;
+            accL[nb][pg] = zero;
+        }
+    }
+    // lane (m, g) of wave w: output pixels (ty0 + 2 w + pg, tx0 + m); K-vector 4 t + g = tap * V8 + c8
+    const int tap0 = g / V8;
+    int c8 = g - tap0 * V8, tap = tap0;
+    const char *xb = tile + ((2 * wave) * HALO_W + m) * PIXB;
+    __syncthreads();                                                     // the tile is in LDS; no barrier from here on
+    int parity = 0;                                                      // accH: two steps (64 leading products) between flushes, the first from the zero operand
+    auto compute = [&](const Weights &o) {
+        const int tc = tap < 9 ? tap : 8, ky = tc / 3, kx = tc - 3 * ky;           // past the last tap the weights are zero: any finite operand will do
+        const char *xl = xb + (ky * HALO_W + kx) * PIXB + c8 * 48;
+        u32x4_t xp[PG][3];
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xp[pg][q] = *reinterpret_cast<const u32x4_t *>(xl + pg * (HALO_W * PIXB) + q * 16);
+#pragma unroll
+        for (int qa = 2; qa >= 0; --qa)
+#pragma unroll
+            for (int qb = 2; qb >= 0; --qb) {
+                if (qa + qb > (TERMS == 8 ? 3 : 2)) continue;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int pg = 0; pg < PG; ++pg) {
+                        if (qa + qb == 0) accH[nb][pg] = mfma_bf16(o.w[nb][qa], xp[pg][qb], accH[nb][pg]);
+                        else accL[nb][pg] = mfma_bf16(o.w[nb][qa], xp[pg][qb], accL[nb][pg]);
+                    }
+            }
+        if (parity) {                                                    // uniform
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int pg = 0; pg < PG; ++pg) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) carry[nb][pg][i] += (double)accH[nb][pg][i];
+                    accH[nb][pg] = zero;
+                }
+        }
+        parity ^= 1;
+        c8 += 4;
+        while (c8 >= V8) { c8 -= V8; ++tap; }
+    };
+    for (int step = 0; step < nsteps; step += 3) {
+        weights(W2, step + 2);
+        compute(W0);
+        if (step + 1 < nsteps) {
+            weights(W0, step + 3);
+            compute(W1);
+        }
+        if (step + 2 < nsteps) {
+            weights(W1, step + 4);
+            compute(W2);
+        }
+    }
+    v4 acc[NB][PG];
+    int pix[PG];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+        const int oy = ty0 + 2 * wave + pg, ox = tx0 + m;
+        pix[pg] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : P;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[nb][pg][i] = (float)(carry[nb][pg][i] + ((double)accH[nb][pg][i] + (double)accL[nb][pg][i]));
+    }
+    pconv_epilogue<float, NB, PG>(a, acc, pix, g, bg, s, P);
 }
 
 // ---- the tensors the reference builds with expand / cat / Upsample / adaptive_avg_pool2d, materialised ---------------------------
@@ -397,17 +810,55 @@ int launch_pconv(const MpfPConvArgs &a, hipStream_t st)
     return mpf_launch_status("k_pconv");
 }
 
+template <int TERMS>
+int launch_pconv_x3(const MpfPConvArgs &a, hipStream_t st)
+{
+    const int P = a.Hout * a.Wout;
+    if (a.nblk % 4 == 0) {
+        hipLaunchKernelGGL((k_pconv_x3<4, 2, TERMS>), dim3((P + 127) / 128, a.nblk / 4, a.S), dim3(256), 0, st, a);
+    } else if (a.nblk % 3 == 0) {
+        hipLaunchKernelGGL((k_pconv_x3<3, 2, TERMS>), dim3((P + 127) / 128, a.nblk / 3, a.S), dim3(256), 0, st, a);
+    } else if (a.nblk % 2 == 0) {
+        hipLaunchKernelGGL((k_pconv_x3<2, 2, TERMS>), dim3((P + 127) / 128, a.nblk / 2, a.S), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_pconv_x3<1, 4, TERMS>), dim3((P + 255) / 256, a.nblk, a.S), dim3(256), 0, st, a);
+    }
+    return mpf_launch_status("k_pconv_x3");
+}
+
+template <int NB>
+int launch_pconv_x3_tile_nb(const MpfPConvArgs &a, hipStream_t st)
+{
+    const int V8 = ((a.CA + a.CB) / 4 + 1) / 2;
+    const size_t lds = (size_t)HALO_PIX * tile_pix_bytes(V8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPF_HIP(hipFuncSetAttribute((const void *)k_pconv_x3_tile<NB, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_pconv_x3_tile<NB, 6>), dim3((a.Wout + TILE_W - 1) / TILE_W, (a.Hout + TILE_H - 1) / TILE_H, a.S * (a.nblk / NB)), dim3(256), lds, st, a);
+    return mpf_launch_status("k_pconv_x3_tile");
+}
+
+int launch_pconv_x3_tile(const MpfPConvArgs &a, hipStream_t st)
+{
+    if (a.nblk == 1) return launch_pconv_x3_tile_nb<1>(a, st);
+    if (a.nblk == 2) return launch_pconv_x3_tile_nb<2>(a, st);
+    return launch_pconv_x3_tile_nb<3>(a, st);
+}
+
 inline size_t blocks_of(size_t n) { return (n + 255) / 256; }
 
 }  // namespace
 
 #define MPF_DTYPE_OK(d) ((d) == MPF_DTYPE_F32 || (d) == MPF_DTYPE_F64)
+#define MPF_PCONV_DTYPE_OK(d) (MPF_DTYPE_OK(d) || (d) == MPF_DTYPE_F32X3 || (d) == MPF_DTYPE_F32X3_TILE)
 
 extern "C" int mpf_pconv(const MpfPConvArgs *args, void *stream)
 {
     MPF_REQUIRE(args != nullptr, "mpf_pconv: null argument block");
     const MpfPConvArgs &a = *args;
-    MPF_REQUIRE(MPF_DTYPE_OK(a.dtype), "mpf_pconv: dtype must be MPF_DTYPE_F32 or MPF_DTYPE_F64");
+    MPF_REQUIRE(MPF_PCONV_DTYPE_OK(a.dtype), "mpf_pconv: dtype must be MPF_DTYPE_F32, MPF_DTYPE_F64, MPF_DTYPE_F32X3 or MPF_DTYPE_F32X3_TILE");
     MPF_REQUIRE(a.srcA && a.wpack && a.out, "mpf_pconv: null source / weights / output");
     MPF_REQUIRE(a.ksize == 1 || a.ksize == 3 || a.ksize == 7, "mpf_pconv: kernel size must be 1, 3 or 7");
     MPF_REQUIRE((a.stride == 1 || a.stride == 2) && a.pad >= 0 && a.pad <= a.ksize / 2 && (a.up == 0 || a.up == 1), "mpf_pconv: bad stride / padding / upsampling");
@@ -432,6 +883,13 @@ extern "C" int mpf_pconv(const MpfPConvArgs *args, void *stream)
     const size_t al = a.dtype == MPF_DTYPE_F64 ? 31 : 15;
     MPF_REQUIRE((((uintptr_t)a.srcA | (uintptr_t)a.srcB | (uintptr_t)a.wpack | (uintptr_t)a.out | (uintptr_t)a.scale | (uintptr_t)a.shift | (uintptr_t)a.bias |
                   (uintptr_t)a.residual) & al) == 0, "mpf_pconv: buffers must be aligned to one 4-channel vector");
+    if (a.dtype == MPF_DTYPE_F32X3_TILE) {
+        MPF_REQUIRE(a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.nblk <= 3 && a.CA + a.CB <= 56 && (size_t)a.S * a.nblk <= 65535,
+                    "mpf_pconv: the tile form is 3 x 3, stride 1, padding 1, at most 56 input channels and 3 row blocks");
+        return launch_pconv_x3_tile(a, (hipStream_t)stream);
+    }
+    MPF_REQUIRE(a.dtype != MPF_DTYPE_F32X3 || a.ksize <= 3, "mpf_pconv: the split-bf16 kernels are 1 x 1 and 3 x 3 (tap table in LDS)");
+    if (a.dtype == MPF_DTYPE_F32X3) return launch_pconv_x3<6>(a, (hipStream_t)stream);
     return a.dtype == MPF_DTYPE_F64 ? launch_pconv<double>(a, (hipStream_t)stream) : launch_pconv<float>(a, (hipStream_t)stream);
 }
 

@@ -21,6 +21,8 @@ from .. import _lib
 
 EP_AFFINE, EP_AFFINE_MAP, EP_GATED, EP_GATED_PLANAR = 0, 1, 2, 3
 DTYPE_CODE = {torch.float32: 0, torch.float64: 1}
+X3_CODE, X3_TILE_CODE = 2, 3      # MPF_DTYPE_F32X3 / MPF_DTYPE_F32X3_TILE: fp32 tensors, products from bf16 pieces on the matrix cores
+X3_TILE = True                    # tools/bench_precise.py switches the tile form off for A/B timings
 ACT = {None: 0, "relu": 1, "leaky": 2}
 
 
@@ -63,6 +65,52 @@ def pack_weights(w_rows, dtype, device=None, CA=None):
     return out.to(device) if device is not None else out
 
 
+def pack_weights_x3(w_rows, device=None, CA=None):
+    """The A operand of mpf_pconv's MPF_DTYPE_F32X3 kernels (v_mfma_f32_16x16x32_bf16): the fp32 packing with every source padded to an EVEN number of
+    K-steps, two K-steps per instruction, every fp32 weight as the three bf16 numbers it is exactly the sum of ->
+    [R/16, steps, 3 pieces, 64 lanes, 8] bfloat16."""
+    R, Cv, k, _ = w_rows.shape
+    CA = Cv if CA is None else CA
+    parts = []
+    for c0, c1 in ((0, CA), (CA, Cv)):
+        if c1 == c0:
+            continue
+        w32 = pack_weights(w_rows[:, c0:c1], torch.float32)                                         # [blk, nst, 64, 4], rounded to fp32 as the engine's weights are
+        if w32.shape[1] % 2:
+            w32 = torch.cat([w32, torch.zeros(w32.shape[0], 1, 64, 4)], dim=1)
+        parts.append(w32.reshape(w32.shape[0], -1, 2, 64, 4).permute(0, 1, 3, 2, 4).reshape(w32.shape[0], -1, 64, 8))
+    out = _split_bf16x3(torch.cat(parts, dim=1)).permute(1, 2, 0, 3, 4).contiguous()
+    return out.to(device) if device is not None else out
+
+
+def _split_bf16x3(w):
+    """fp32 tensor -> [3, ...] bfloat16 with p1 + p2 + p3 == w exactly."""
+    p1 = w.to(torch.bfloat16)
+    r1 = w - p1.float()
+    p2 = r1.to(torch.bfloat16)
+    r2 = r1 - p2.float()
+    p3 = r2.to(torch.bfloat16)
+    assert bool((p1.double() + p2.double() + p3.double() == w.double()).all()), "an fp32 weight is not the sum of its three bf16 pieces"
+    return torch.stack([p1, p2, p3])
+
+
+def pack_weights_x3_tile(w_rows, device=None):
+    """The A operand of k_pconv_x3_tile (MPF_DTYPE_F32X3_TILE): 3 x 3 weights [R, Cv, 3, 3] over the CONCATENATED channels of both sources (Cv a multiple
+    of 4, zero-padded to a multiple of 8 here); K-vector 4 t + g = (tap, 8-channel vector), tap-major -> [R/16, steps, 3 pieces, 64 lanes, 8] bfloat16."""
+    R, Cv, k, _ = w_rows.shape
+    assert k == 3 and R % 16 == 0 and Cv % 4 == 0
+    V8 = (Cv // 4 + 1) // 2
+    w = torch.zeros(R, V8 * 8, 3, 3, dtype=torch.float64)
+    w[:, :Cv] = w_rows
+    nkv = 9 * V8
+    nst = (nkv + 3) // 4
+    kv = w.permute(0, 2, 3, 1).reshape(R, nkv, 8)                                                   # [row, tap * V8 + c8, j]
+    kv = torch.cat([kv, torch.zeros(R, nst * 4 - nkv, 8, dtype=kv.dtype)], dim=1).reshape(R // 16, 16, nst, 4, 8)   # [blk, m, t, g, j]
+    w32 = kv.permute(0, 2, 3, 1, 4).reshape(R // 16, nst, 64, 8).float()
+    out = _split_bf16x3(w32).permute(1, 2, 0, 3, 4).contiguous()
+    return out.to(device) if device is not None else out
+
+
 def _virtual_weights(w, segments):
     """conv weight [Cout, Cin_real, k, k] -> [Cout, sum(padded), k, k] with zero columns at the padding channels of every segment
     (segments: (padded, real) channel counts in concatenation order)."""
@@ -85,20 +133,30 @@ class PConv:
     """One packed convolution of the precise engine + its launch."""
 
     def __init__(self, device, dtype, w_rows, *, epi, scale=None, shift=None, bias=None, ksize=3, stride=1, pad=1, pad_mode=0, up=0, Cst, act=None, slope=0.0,
-                 CA, CB=0, name="", rows_real=0, cin_real=0):
+                 CA, CB=0, name="", rows_real=0, cin_real=0, x3=False):
         self.name, self.dtype, self.epi = name, dtype, epi
         self.ksize, self.stride, self.pad, self.pad_mode, self.up = ksize, stride, pad, pad_mode, up
         self.CA, self.CB, self.Cst, self.act, self.slope = CA, CB, Cst, ACT[act], float(slope)
         assert w_rows.shape[1] == CA + CB and w_rows.shape[0] % 16 == 0
         self.nblk = w_rows.shape[0] // 16
         self.rows_real, self.cin_real = rows_real, cin_real
-        self.wpack = pack_weights(w_rows.double(), dtype, device, CA=CA)
+        if x3 and dtype != torch.float32:
+            raise ValueError("the split-bf16 kernels compute on fp32 tensors")
+        if ksize > 3:
+            x3 = False                                                   # the 7 x 7 stem (one launch, S = 1) stays on the fp32 instruction
+        # the few-channel 3 x 3 layers: the input tile split once into LDS (k_pconv_x3_tile) instead of once per tap
+        self.tile = bool(x3 and ksize == 3 and stride == 1 and pad == 1 and CA + CB <= 56 and self.nblk <= 3 and X3_TILE)
+        self.code = X3_TILE_CODE if self.tile else X3_CODE if x3 else DTYPE_CODE[dtype]
+        if self.tile:
+            self.wpack = pack_weights_x3_tile(w_rows.double(), device)
+        else:
+            self.wpack = pack_weights_x3(w_rows.double(), device, CA=CA) if x3 else pack_weights(w_rows.double(), dtype, device, CA=CA)
         put = lambda t: None if t is None else t.to(dtype).contiguous().to(device)      # noqa: E731
         self.scale, self.shift, self.bias = put(scale), put(shift), put(bias)
 
     # -- builders (parameters folded in float64 on the host, rounded once to the engine's dtype) -----------------------------------------
     @classmethod
-    def affine(cls, device, dtype, conv, bn, segments, *, act, slope=0.0, up=0, as_map=False, name=""):
+    def affine(cls, device, dtype, conv, bn, segments, *, act, slope=0.0, up=0, as_map=False, name="", x3=False):
         """Conv2d [+ bias] + BatchNorm(eval) + activation, zero padding: ConvBNReLU (model/CPN/unet.py:6-15), the encoder's conv + bn
         (model/CPN/encoder.py via torchvision's BasicBlock) and the bottleneck's conv + bn + LeakyReLU (model/CPN/decoder.py:85-88)."""
         cout, k = conv.out_channels, conv.kernel_size[0]
@@ -112,10 +170,10 @@ class PConv:
         scale[:cout], shift[:cout] = sc, sh
         return cls(device, dtype, w, epi=EP_AFFINE_MAP if as_map else EP_AFFINE, scale=scale, shift=shift, ksize=k, stride=conv.stride[0], pad=conv.padding[0],
                    pad_mode=0, up=up, Cst=1 if as_map else pad4(cout), act=act, slope=slope, CA=segments[0][0], CB=segments[1][0] if len(segments) > 1 else 0,
-                   name=name, rows_real=cout, cin_real=conv.in_channels)
+                   name=name, rows_real=cout, cin_real=conv.in_channels, x3=x3)
 
     @classmethod
-    def gated(cls, device, dtype, gconv, bn, segments, *, up=0, planar=False, name=""):
+    def gated(cls, device, dtype, gconv, bn, segments, *, up=0, planar=False, name="", x3=False):
         """GatedConv (+ BatchNorm + ELU when bn is given), reflection padding (model/CPN/decoder.py:10-71): logical rows (2c, 2c+1) = (feature, gate) of
         channel c."""
         cf, cm = gconv.conv2d, gconv.mask_conv2d
@@ -132,7 +190,7 @@ class PConv:
             scale[:cout], shift[:cout] = _bn_affine64(bn)
         return cls(device, dtype, w, epi=EP_GATED_PLANAR if planar else EP_GATED, scale=scale, shift=shift, bias=bias, ksize=3, stride=1, pad=1, pad_mode=1, up=up,
                    Cst=cout if planar else pad4(cout), CA=segments[0][0], CB=segments[1][0] if len(segments) > 1 else 0, name=name, rows_real=2 * cout,
-                   cin_real=cf.in_channels)
+                   cin_real=cf.in_channels, x3=x3)
 
     # -- launch -----------------------------------------------------------------------------------------------------------------------------
     def __call__(self, S, Hin, Win, srcA, srcB=None, residual=None, shareA=False, shareB=False):
@@ -154,7 +212,7 @@ class PConv:
         a = _lib.MpfPConvArgs()
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())      # noqa: E731
         a.srcA, a.srcB, a.wpack, a.scale, a.shift, a.bias, a.residual, a.out = p(srcA), p(srcB), p(self.wpack), p(self.scale), p(self.shift), p(self.bias), p(residual), p(out)
-        a.dtype = DTYPE_CODE[self.dtype]
+        a.dtype = self.code
         a.S, a.Hin, a.Win, a.Hout, a.Wout = S, Hin, Win, Hout, Wout
         a.HA, a.WA, a.CA, a.CB = HA, WA, self.CA, self.CB
         a.up, a.shareA, a.shareB = self.up, int(shareA), int(shareB)
@@ -183,16 +241,19 @@ class PrecisePredictor:
 
     DEC = [12, 24, 48, 96, 192]
 
-    def __init__(self, model, dtype=torch.float32, keep_dtype=False):
+    def __init__(self, model, dtype=torch.float32, keep_dtype=False, x3=None):
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.MpiFlowHipError("PrecisePredictor needs the model on the GPU; there is no CPU path")
         if dtype not in DTYPE_CODE:
             raise ValueError("dtype must be torch.float32 or torch.float64")
-        self.model, self.dtype, self.dev, self.keep_dtype = model.eval(), dtype, dev, keep_dtype
+        x3 = (dtype == torch.float32) if x3 is None else bool(x3)
+        if x3 and dtype != torch.float32:
+            raise ValueError("x3 (products from bf16 pieces on the matrix cores) goes with dtype torch.float32")
+        self.model, self.dtype, self.dev, self.keep_dtype, self.x3 = model.eval(), dtype, dev, keep_dtype, x3
         self.code = DTYPE_CODE[dtype]
-        A = lambda *a, **k: PConv.affine(dev, dtype, *a, **k)          # noqa: E731
-        G = lambda *a, **k: PConv.gated(dev, dtype, *a, **k)           # noqa: E731
+        A = lambda *a, **k: PConv.affine(dev, dtype, *a, x3=x3, **k)          # noqa: E731
+        G = lambda *a, **k: PConv.gated(dev, dtype, *a, x3=x3, **k)           # noqa: E731
         # ---- single-image part: ResNet-18 encoder + bottleneck
         e = model.encoder.encoder
         self.e_conv1 = A(e.conv1, e.bn1, [(4, 4)], act="relu", name="enc.conv1")
@@ -237,6 +298,7 @@ class PrecisePredictor:
                 self.up1[i] = G(b1.gated_conv, b1.bn, [(dec[0], dec[0])], up=1, name="up1_0")
         self.disp0 = G(d.convs[key("dispconv", 0)], None, [(dec[0], dec[0])], planar=True, name="disp0")
         self._plane_disp = model.plane_disparities(torch.zeros(1, device=dev))[0].contiguous()
+        self._side = torch.cuda.Stream(device=dev)
         self.debug = None                                              # set to a dict to keep intermediate tensors (tests)
 
     # -- small kernels ----------------------------------------------------------------------------------------------------------------------
@@ -352,9 +414,16 @@ class PrecisePredictor:
         with torch.cuda.device(self.dev):
             img, dsp = src_imgs[0].float().contiguous(), src_depths[0, 0].float().contiguous()
             pd = self._plane_disp
-            feats, top = self.encoder(img, dsp)
+            # the single-image part (ResNet-18 + bottleneck: ~30 launches of a few dozen workgroups) runs beside the S-plane UNet on a second stream
+            main = torch.cuda.current_stream(self.dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                feats, top = self.encoder(img, dsp)
             lg = self.logits(img, dsp, pd)
             masks = self.plane_masks(lg)
+            main.wait_stream(self._side)
+            for t in feats + [top]:
+                t.record_stream(main)
             raw = self.decoder(feats, top, masks)
         if self.debug is not None:
             self.debug.update(feats=feats, top=top, logits=lg, masks=masks)

@@ -515,7 +515,7 @@ def test_cli_with_network_on_hip_engine(dev, tmp_path):
 
 
 def test_cli_precise_engine_matches_the_torch_fp32_producer(dev, tmp_path):
-    """gen_3dphoto_dynamic.py --model-engine hip --model-dtype fp32 | fp64: the parity-grade producer (every convolution on mpf_pconv) behind the
+    """gen_3dphoto_dynamic.py --model-engine hip --model-dtype fp32 | fp32-mfma | fp64: the parity-grade producer (every convolution on mpf_pconv) behind the
     reference's entry point.  Same image, same seed, same poses as --model-engine torch (the fp32 torch modules): the written flows agree to what two
     fp32 evaluations of the network allow (tests/test_precise_engine.py), the fp32 and fp64 engines agree with each other more closely still, and
     bf16 (a torch autocast dtype) is refused for the hip engine."""
@@ -536,7 +536,8 @@ def test_cli_precise_engine_matches_the_torch_fp32_producer(dev, tmp_path):
     flows = {}
     common = [sys.executable, os.path.join(root, "gen_3dphoto_dynamic.py"), "--base", str(base), "--width", "128", "--height", "128", "--repeat", "2", "--planes", "8",
               "--inpaint", "none", "--mpi-from", "model", "--ckpt_path", "random:3"]
-    for name, extra in (("torch", ["--model-engine", "torch"]), ("fp32", ["--model-engine", "hip", "--model-dtype", "fp32"]), ("fp64", ["--model-engine", "hip", "--model-dtype", "fp64"])):
+    for name, extra in (("torch", ["--model-engine", "torch"]), ("fp32", ["--model-engine", "hip", "--model-dtype", "fp32"]),
+                        ("fp32-mfma", ["--model-engine", "hip", "--model-dtype", "fp32-mfma"]), ("fp64", ["--model-engine", "hip", "--model-dtype", "fp64"])):
         out = tmp_path / ("out_" + name)
         r = subprocess.run(common + ["--out", str(out)] + extra, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -546,6 +547,8 @@ def test_cli_precise_engine_matches_the_torch_fp32_producer(dev, tmp_path):
     scale = float(np.abs(flows["torch"]).max())
     d32, d64, dd = (float(np.abs(flows[a] - flows[b]).mean()) for a, b in (("fp32", "torch"), ("fp64", "torch"), ("fp32", "fp64")))
     assert scale > 0.5 and d32 < 2e-4 * max(scale, 1.0) and d64 < 2e-4 * max(scale, 1.0) and dd <= max(d32, d64), (scale, d32, d64, dd)
+    dm = float(np.abs(flows["fp32-mfma"] - flows["fp64"]).mean())                   # the two fp32 forms (bf16-piece products / fp32 products) are different kernels
+    assert dm <= max(d32, d64) and not np.array_equal(flows["fp32-mfma"], flows["fp32"]), (dm, d32, d64)
     r = subprocess.run(common + ["--out", str(tmp_path / "x"), "--model-engine", "hip", "--model-dtype", "bf16"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "bf16" in (r.stderr + r.stdout)
 

@@ -69,6 +69,44 @@ def test_pack_weights_layout(dtype):
         assert np.array_equal(got, ref)
 
 
+def test_pack_weights_x3_layouts():
+    """The split-bf16 kernels' A operands: three bf16 pieces that sum EXACTLY to the fp32 weight; MPF_DTYPE_F32X3: step t of a source = its fp32 K-steps
+    2t and 2t+1 side by side (sources padded to an even count); MPF_DTYPE_F32X3_TILE: K-vector 4 t + g = (tap, 8-channel vector of the concatenated,
+    zero-padded channels)."""
+    from mpiflow_amd.model.precise import pack_weights, pack_weights_x3, pack_weights_x3_tile
+    g = torch.Generator().manual_seed(2)
+    for R, cv, ca, k in [(32, 20, 8, 3), (16, 12, 12, 3), (48, 36, 36, 1), (16, 8, 4, 3)]:
+        w = torch.randn(R, cv, k, k, generator=g, dtype=torch.float64) * torch.logspace(-6, 3, cv, dtype=torch.float64)[None, :, None, None]
+        got = pack_weights_x3(w, CA=ca)
+        assert got.dtype == torch.bfloat16 and got.shape[2:] == (3, 64, 8)
+        total = got.double().sum(2)                                                            # [blk, step, lane, 8]
+        s0 = 0
+        for c0, c1 in [(0, ca)] + ([(ca, cv)] if cv > ca else []):
+            w32 = pack_weights(w[:, c0:c1], torch.float32)                                     # [blk, nst, 64, 4]
+            if w32.shape[1] % 2:
+                w32 = torch.cat([w32, torch.zeros(w32.shape[0], 1, 64, 4)], dim=1)
+            n2 = w32.shape[1] // 2
+            ref = torch.cat([w32[:, 0::2], w32[:, 1::2]], dim=-1).double()                     # [blk, n2, 64, 8]
+            assert torch.equal(total[:, s0:s0 + n2], ref)
+            s0 += n2
+        assert s0 == got.shape[1]
+    for R, cv in [(32, 48), (16, 12), (48, 20), (16, 8)]:
+        w = torch.randn(R, cv, 3, 3, generator=g, dtype=torch.float64)
+        got = pack_weights_x3_tile(w)
+        V8 = (cv // 4 + 1) // 2
+        assert got.shape == (R // 16, (9 * V8 + 3) // 4, 3, 64, 8)
+        total = got.double().sum(2)
+        for blk, t, lane in [(0, 0, 0), (R // 16 - 1, got.shape[1] - 1, 63), (0, 1, 37), (R // 16 - 1, got.shape[1] // 2, 21)]:
+            m, gg = lane % 16, lane // 16
+            kv = 4 * t + gg
+            tap, c8 = kv // V8, kv % V8
+            ref = torch.zeros(8, dtype=torch.float64)
+            if tap < 9:
+                n = min(8, cv - 8 * c8)
+                ref[:n] = w[blk * 16 + m, 8 * c8:8 * c8 + n, tap // 3, tap % 3].float().double()
+            assert torch.equal(total[blk, t, lane], ref), (R, cv, blk, t, lane)
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
 
 def _gpu():
@@ -79,6 +117,11 @@ def _gpu():
 
 def _tol(dtype):
     return 1e-12 if dtype == torch.float64 else 3e-6
+
+
+# (tensor dtype, x3): fp32 tensors with the products on v_mfma_f32_16x16x4_f32, fp32 tensors with every product from bf16 pieces on v_mfma_f32_16x16x32_bf16
+# (what --model-dtype fp32 runs; the same 3e-6 bar), fp64 throughout
+MODES = [pytest.param(torch.float32, False, id="fp32-mfma"), pytest.param(torch.float32, True, id="fp32-x3"), pytest.param(torch.float64, False, id="fp64")]
 
 
 def _nhwc(t_NCHW, dtype, dev, pad_to=None):
@@ -101,7 +144,7 @@ def _randomize(mod, g):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("dtype,x3", MODES)
 @pytest.mark.parametrize("k,stride,up,cin,cout,S,h,w,act,res", [
     (7, 2, 0, 4, 64, 1, 40, 56, "relu", False),        # the ResNet stem
     (3, 1, 0, 64, 64, 1, 20, 28, "relu", True),        # BasicBlock conv2 + identity
@@ -109,9 +152,12 @@ def _randomize(mod, g):
     (3, 1, 1, 16, 32, 1, 12, 20, "leaky", False),      # bottleneck: x2 nearest in front of the conv
     (1, 1, 1, 32, 48, 1, 12, 20, "leaky", False),
     (3, 2, 0, 16, 32, 3, 18, 30, "relu", False),       # feature-mask UNet, stride 2, three planes, ragged pixel count
-    (3, 1, 0, 5, 16, 2, 9, 21, "relu", False),         # 5 real channels in an 8-channel tensor, one row block
+    (3, 1, 0, 5, 16, 2, 9, 21, "relu", False),         # 5 real channels in an 8-channel tensor, one row block (x3: the LDS-tile kernel, ragged tiles)
+    (3, 1, 0, 16, 32, 2, 17, 35, "relu", False),       # l2: two row blocks (x3: tile kernel), tiles cut on both edges
+    (3, 1, 0, 128, 128, 2, 6, 10, "relu", False),      # eight row blocks (x3: four per workgroup), 60 pixels per plane
+    (3, 1, 0, 20, 80, 1, 5, 7, "relu", False),         # five vectors per tap, five row blocks (x3: one per workgroup, four pixel groups)
 ])
-def test_pconv_affine_matches_torch_fp64(dtype, k, stride, up, cin, cout, S, h, w, act, res):
+def test_pconv_affine_matches_torch_fp64(dtype, x3, k, stride, up, cin, cout, S, h, w, act, res):
     from mpiflow_amd.model.precise import PConv, pad4
     dev = _gpu()
     g = torch.Generator().manual_seed(k * 100 + cin + cout)
@@ -127,7 +173,7 @@ def test_pconv_affine_matches_torch_fp64(dtype, k, stride, up, cin, cout, S, h, 
     if r is not None:
         ref = ref + r
     ref = {"relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.1), None: lambda t: t}[act](ref)
-    layer = PConv.affine(dev, dtype, conv, bn, [(pad4(cin), cin)], act=act, slope=0.1, up=up, name="t")
+    layer = PConv.affine(dev, dtype, conv, bn, [(pad4(cin), cin)], act=act, slope=0.1, up=up, name="t", x3=x3)
     out = layer(S, h, w, _nhwc(x, dtype, dev, pad4(cin)), residual=None if r is None else _nhwc(r, dtype, dev))
     torch.cuda.synchronize()
     got = out[..., :cout].permute(0, 3, 1, 2).double().cpu()
@@ -138,15 +184,17 @@ def test_pconv_affine_matches_torch_fp64(dtype, k, stride, up, cin, cout, S, h, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("dtype,x3", MODES)
 @pytest.mark.parametrize("ca,cb_real,cout,up,S,h,w,bnorm,planar", [
     (12, 0, 12, 1, 2, 16, 24, True, False),            # up1_0: x2 nearest, no skip
     (24, 66, 24, 1, 3, 8, 12, True, False),            # up1_1: x2 nearest ++ per-plane skip (66 real channels in 68)
     (48, 0, 24, 0, 2, 10, 14, True, False),            # up0_1
     (12, 0, 4, 0, 2, 9, 13, False, True),              # disp0: planar raw output, odd sizes
     (516, 0, 192, 0, 2, 3, 5, True, False),            # up0_4: 514 real channels
+    (32, 14, 12, 1, 2, 12, 20, True, False),           # two sources in the LDS-tile kernel (x3): x2 nearest ++ a 14-of-16-channel skip, 48 channels
+    (12, 6, 20, 0, 2, 11, 19, True, False),            # odd vector count (12 + 8 channels = 5 vectors: the zero half of the last 8-channel vector), three row blocks
 ])
-def test_pconv_gated_matches_torch_fp64(dtype, ca, cb_real, cout, up, S, h, w, bnorm, planar):
+def test_pconv_gated_matches_torch_fp64(dtype, x3, ca, cb_real, cout, up, S, h, w, bnorm, planar):
     from mpiflow_amd.model.adampi import GatedConv
     from mpiflow_amd.model.precise import PConv, pad4
     dev = _gpu()
@@ -167,7 +215,8 @@ def test_pconv_gated_matches_torch_fp64(dtype, ca, cb_real, cout, up, S, h, w, b
         if bn is not None:
             ref = F.elu(bn.double()(ref))
     segs = [(ca, ca_real)] + ([(pad4(cb_real), cb_real)] if cb_real else [])
-    layer = PConv.gated(dev, dtype, gc, bn, segs, up=up, planar=planar, name="t")
+    layer = PConv.gated(dev, dtype, gc, bn, segs, up=up, planar=planar, name="t", x3=x3)
+    assert layer.tile == (x3 and ca + (pad4(cb_real) if cb_real else 0) <= 56 and layer.nblk <= 3)
     out = layer(S, h, w, _nhwc(xa, dtype, dev, ca), None if xb is None else _nhwc(xb, dtype, dev, pad4(cb_real)))
     torch.cuda.synchronize()
     got = (out if planar else out[..., :cout].permute(0, 3, 1, 2)).double().cpu()
@@ -288,17 +337,21 @@ FP32_BARS = {(8, 128, 256, 5): dict(rgb=(1e-5, 3e-4, 1.5e-3), sigma=(5e-6, 2.5e-
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("x3", [pytest.param(True, id="x3"), pytest.param(False, id="mfma-f32")])
 @pytest.mark.parametrize("S,H,W,seed", CASES)
-def test_fp32_engine_is_in_the_reference_error_class(S, H, W, seed):
+def test_fp32_engine_is_in_the_reference_error_class(S, H, W, seed, x3):
     """fp32 engine vs the fp64 mirror: absolute bars on mean / p99.9 / max, and never more than 1.5x the error of the reference's own arithmetic
-    (the torch modules in fp32 on the CPU) against the same mirror.  The fp16 engine (engine.HipPredictor) sits ~600x above these means."""
+    (the torch modules in fp32 on the CPU) against the same mirror - for both forms of the fp32 engine: products from bf16 pieces on the matrix cores
+    (x3, what --model-dtype fp32 runs) and products on v_mfma_f32_16x16x4_f32.  The fp16 engine (engine.HipPredictor) sits ~600x above these means."""
     from mpiflow_amd.model.precise import PrecisePredictor
     dev = _gpu()
     m, md, img, dsp = _mirror64(S, H, W, seed)
     with torch.no_grad():
         r64, c64, _ = md(img.double(), dsp.double(), raw=True)
         r32, c32, _ = m(img, dsp, raw=True)
-    raw, cum, _ = PrecisePredictor(m.to(dev), dtype=torch.float32)(img.to(dev), dsp.to(dev))
+    pp = PrecisePredictor(m.to(dev), dtype=torch.float32, x3=x3)
+    assert pp.x3 == x3 and any(L.tile for L in pp.layers()) == x3
+    raw, cum, _ = pp(img.to(dev), dsp.to(dev))
     torch.cuda.synchronize()
     assert raw.dtype == torch.float32 and bool(torch.isfinite(raw).all())
     assert float((cum.cpu().double() - c64[0]).abs().max()) < 2e-5
@@ -309,7 +362,7 @@ def test_fp32_engine_is_in_the_reference_error_class(S, H, W, seed):
         report[name] = dict(engine=e, torch_fp32=t)
         assert all(a <= b for a, b in zip(e, bars[name])), (name, e, bars[name])
         assert e[0] <= 1.5 * t[0] and e[1] <= 1.5 * t[1] and e[2] <= 2.5 * t[2], (name, e, t)
-    print("precise fp32 engine vs fp64 mirror", (S, H, W), report)
+    print("precise fp32 engine (%s) vs fp64 mirror" % ("x3" if x3 else "mfma-f32"), (S, H, W), report)
 
 
 @pytest.mark.gpu
@@ -342,7 +395,7 @@ def test_render_of_the_precise_stacks_matches_the_mirror():
     ref64, ref32 = render(r64[0], c64[0]), render(r32[0], c32[0])
     mdev = m.to(dev)
     got64 = render(*PrecisePredictor(mdev, dtype=torch.float64)(img.to(dev), dsp.to(dev))[:2])
-    got32 = render(*PrecisePredictor(mdev, dtype=torch.float32)(img.to(dev), dsp.to(dev))[:2])
+    got32 = render(*PrecisePredictor(mdev, dtype=torch.float32)(img.to(dev), dsp.to(dev))[:2])          # the default fp32 form: split-bf16 products
     for k in ("rgb_cam", "rgb_dyn", "flow_mix", "m_cam", "m_dyn"):
         assert float((got64[k] - ref64[k]).abs().max()) <= 1e-4, (k, float((got64[k] - ref64[k]).abs().max()))
     # masks: the thresholded products of the render
@@ -380,3 +433,12 @@ def test_precise_engine_rejects_bad_arguments():
     assert _lib.load().mpf_pconv(ctypes.byref(a), None) == 10001              # MPF_ERR_BAD_ARGUMENT, nothing launched
     a.dtype = 7
     assert _lib.load().mpf_pconv(ctypes.byref(a), None) == 10001
+    with pytest.raises(ValueError):
+        PrecisePredictor(MPIPredictor(128, 128, 4).randomize_(0).to(dev), dtype=torch.float64, x3=True)      # the split-bf16 kernels compute on fp32 tensors
+    # a layer the tile form does not cover, forced into it: refused by the C entry point, nothing launched
+    L = pp.up1[4]
+    assert not L.tile and L.code == 2
+    L.code = 3
+    with pytest.raises(_lib.MpiFlowHipError, match="tile form"):
+        L(4, 8, 8, torch.zeros(4, 4, 4, L.CA, device=dev), torch.zeros(4, 8, 8, L.CB, device=dev))
+    L.code = 2

@@ -1,5 +1,8 @@
 """Time and error of the parity-grade producer engine (mpiflow_amd/model/precise.py) at the generator's size, per layer.
-usage: python tools/bench_precise.py [fp32|fp64|both] [S H W]"""
+usage: python tools/bench_precise.py [fp32|x3|x3-notile|fp64|both|all] [S H W]
+(fp32: the v_mfma_f32_16x16x4_f32 kernels; x3: fp32 tensors, products from three bf16 pieces on the matrix cores - what --model-dtype fp32 runs;
+x3-notile: without the LDS-tile kernel of the few-channel layers; "all" also prints every fp32-class mode's error against the fp64 engine, which is the
+torch modules in double to 1e-9: tests/test_precise_engine.py)"""
 import os
 import sys
 import time
@@ -16,10 +19,13 @@ dev = torch.device("cuda:0")
 m = MPIPredictor(W, H, S).randomize_(1).eval().to(dev)
 g = torch.Generator().manual_seed(3)
 img, dsp = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 1, H, W, generator=g).to(dev)
-for name, dt in (("fp32", torch.float32), ("fp64", torch.float64)):
-    if which not in (name, "both"):
+outs = {}
+import mpiflow_amd.model.precise as P                           # noqa: E402
+for name, dt, x3 in (("fp32", torch.float32, False), ("x3", torch.float32, True), ("x3-notile", torch.float32, True), ("fp64", torch.float64, False)):
+    if not (which == name or which == "all" or (which == "both" and not x3)):
         continue
-    pp = PrecisePredictor(m, dtype=dt)
+    P.X3_TILE = name != "x3-notile"
+    pp = PrecisePredictor(m, dtype=dt, x3=x3, keep_dtype=True)
     pp(img, dsp)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -32,7 +38,6 @@ for name, dt in (("fp32", torch.float32), ("fp64", torch.float64)):
     print("%s: %.1f ms per %dx%dx%d image; %.2f TFLOP (real channels) -> %.1f TFLOP/s; %.1f GB materialised -> %.2f TB/s; peak memory %.1f GB"
           % (name, ms, S, H, W, tot["flops"] / 1e12, tot["flops"] / ms / 1e9, tot["bytes"] / 1e9, tot["bytes"] / ms / 1e9, torch.cuda.max_memory_allocated() / 1e9))
     # per-layer times (events around each launch, one more forward)
-    import mpiflow_amd.model.precise as P
     times = {}
     orig = P.PConv.__call__
 
@@ -52,5 +57,17 @@ for name, dt in (("fp32", torch.float32), ("fp64", torch.float64)):
         t = sum(a.elapsed_time(b) for a, b in ev)
         if t > 0.3:
             print("   %-24s %7.2f ms  %6.1f TFLOP/s  %5.2f TB/s" % (k, t, acc[k]["flops"] / t / 1e9, acc[k]["bytes"] / t / 1e9))
-    del pp
+    outs[name] = (raw.double(), cum.double())
+    del pp, raw, cum
     torch.cuda.empty_cache()
+if "fp64" in outs and len(outs) > 1:
+    act = lambda rc: (torch.sigmoid(rc[0][:, :3]), torch.relu(rc[0][:, 3] * rc[1]) + 1e-4)          # noqa: E731   model/CPN/decoder.py:166-173
+    ref = act(outs["fp64"])
+    for name, rc in outs.items():
+        if name == "fp64":
+            continue
+        for what, x, r in zip(("sigmoid(rgb)", "sigma"), act(rc), ref):
+            d = (x - r).abs().flatten()
+            k = max(1, int(d.numel() * 0.999))
+            p999 = float(d[torch.randperm(d.numel(), device=d.device)[:4000000]].kthvalue(min(k, 3996000)).values) if d.numel() > 4000000 else float(d.kthvalue(k).values)
+            print("%-5s %-13s vs fp64 engine: mean %.2e  p99.9 %.2e  max %.2e" % (name, what, float(d.mean()), p999, float(d.max())))

@@ -1,6 +1,7 @@
 """The producer network's PARITY-GRADE engine: MPIPredictor.forward (reference model/AdaMPI.py:55-78) on this repo's HIP kernels in the
-arithmetic of the reference's CPU path - fp32 storage, fp32 products, fp32 accumulation (`dtype=torch.float32`, v_mfma_f32_16x16x4_f32) -
-or in fp64 throughout (`dtype=torch.float64`, v_mfma_f64_16x16x4_f64), the mode the tests use to show that the engine computes the
+arithmetic class of the reference's CPU path - fp32 storage, fp32-grade products, fp32 accumulation in blocks of 64 products carried in fp64
+(`dtype=torch.float32`; `x3=True`, the default: every product from the three bf16 pieces each fp32 factor is exactly the sum of, on
+v_mfma_f32_16x16x32_bf16; `x3=False`: products on v_mfma_f32_16x16x4_f32) - or in fp64 throughout (`dtype=torch.float64`, v_mfma_f64_16x16x4_f64), the mode the tests use to show that the engine computes the
 reference's network itself (error ~1e-12 against the torch modules run in double) and not an approximation of it.
 
 Every convolution is one launch of `mpf_pconv` (mpiflow_amd/csrc/mpf_pconv.hip): the RGBD ResNet-18 encoder and the decoder's bottleneck

@@ -17,19 +17,21 @@ timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCL
 timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE $F --output-format csv -d $OUT/c -o b -- python /tmp/run_precise_once.py > $OUT/c.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
+def kname(n):
+    m = re.search(r"(k_\w+(?:<[^>]*>)?)", n)
+    return m.group(1) if m else n[:40]
 rows = collections.OrderedDict()
 for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        key = (r["Kernel_Name"].split("(")[0][-40:], r["Grid_Size"], r["Dispatch_Id"] if False else "")
-        rows.setdefault((r["Kernel_Name"].split("(")[0][-40:], r["Grid_Size"]), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rows.setdefault((kname(r["Kernel_Name"]), r["Grid_Size"]), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in rows.items():
     g = sum(d["GRBM_GUI_ACTIVE"]) / len(d["GRBM_GUI_ACTIVE"]) / 8.0 if "GRBM_GUI_ACTIVE" in d else 0
     if g * len(d.get("GRBM_GUI_ACTIVE", [])) < 2e6: continue
     mf = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(d["SQ_VALU_MFMA_BUSY_CYCLES"])
     va = sum(d["SQ_ACTIVE_INST_VALU"]) / len(d["SQ_ACTIVE_INST_VALU"]) * 4
     w = sum(d["SQ_WAVES"]) / len(d["SQ_WAVES"])
-    print("%-42s grid %-10s n=%d %8.1f us  MFMA busy %5.1f %%  VALU issue %5.1f %%  per wave: VALU %.0f SALU %.0f VMEM %.0f MFMA %.0f" % (k[0], k[1], len(d["SQ_WAVES"]), g / 2400.0, 100 * mf / (g * 1024), 100 * va / (g * 1024),
+    print("%-30s grid %-10s n=%d %8.1f us  MFMA busy %5.1f %%  VALU issue %5.1f %%  per wave: VALU %.0f SALU %.0f VMEM %.0f MFMA %.0f" % (k[0], k[1], len(d["SQ_WAVES"]), g / 2400.0, 100 * mf / (g * 1024), 100 * va / (g * 1024),
           sum(d["SQ_INSTS_VALU"]) / len(d["SQ_INSTS_VALU"]) / w, sum(d["SQ_INSTS_SALU"]) / len(d["SQ_INSTS_SALU"]) / w, sum(d["SQ_INSTS_VMEM_RD"]) / len(d["SQ_INSTS_VMEM_RD"]) / w, sum(d["SQ_INSTS_MFMA"]) / len(d["SQ_INSTS_MFMA"]) / w), end="")
     av = lambda n: sum(d[n]) / len(d[n]) if d.get(n) else float("nan")
     wc = av("SQ_WAVE_CYCLES")

@@ -64,6 +64,16 @@ def test_encoder_kernels_soak():
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+def test_precise_engine_matrix_core_form_soak():
+    """tools/soak_precise.py: the parity-grade engine's fp32 form on the bf16 matrix cores at random plane counts / sizes / parameters: the forward twice on
+    one input is bit-identical (fixed sum order; an LDS hand-off or barrier race in k_pconv_x3 / k_pconv_x3_tile would show), finite, and within fp32 bars of
+    the fp32-instruction form (other kernels, no LDS)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_precise.py"), "10", "4"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_pair_vs_oracle_soak(oracle):
     """The fused pair against the CPU oracle (kernel-exp mode: same IEEE op sequence) on random small problems: every plane count from 1 to 40,
     frames from one pixel to 60 x 90, random stacks / images / soft masks, poses from the reference sampler's range up to 6 x beyond it (planes

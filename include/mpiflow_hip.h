@@ -431,6 +431,8 @@ int mpf_maxpool3x3s2_f32(const float *d_src_HWC, int Hin, int Win, int C, float 
                                 * wpack: [nblk][steps][3 pieces][64 lanes][8] bf16, a step = two K-steps of the fp32 packing, every source padded to an even count */
 #define MPF_DTYPE_F32X3_TILE 3 /* the same arithmetic for 3 x 3 / stride 1 / padding 1 layers with CA + CB <= 56 and nblk <= 3: the input tile of both sources is
                                 * split once into LDS.  wpack: K-vector 4 t + g = (tap, 8-channel vector of the CONCATENATED channels, zero-padded to 8) */
+#define MPF_DTYPE_F32X3_CHUNK 4 /* the same arithmetic for 3 x 3 / stride 1 / padding 1 layers of any width: per 32-channel chunk of the concatenated sources the input tile is
+                                * split once into LDS, nine steps (one per tap) per chunk.  wpack: step = chunk * 9 + tap, K-vector g = 8-channel vector g of the chunk */
 #define MPF_PCONV_EP_AFFINE       0   /* out [S,Hout,Wout,Cst] = act(acc * scale[row] + shift[row] (+ residual))   (ConvBNReLU model/CPN/unet.py:6-15; the encoder's conv + BN) */
 #define MPF_PCONV_EP_AFFINE_MAP   1   /* same, row 0 only, out [S,Hout,Wout]   (the feature-mask logits, model/CPN/unet.py:66) */
 #define MPF_PCONV_EP_GATED        2   /* g = accF * sigmoid(accM) (biases = initial accumulators); out NHWC = elu(g * scale[c] + shift[c])   (model/CPN/decoder.py:10-71) */

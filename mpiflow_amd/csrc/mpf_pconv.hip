@@ -665,6 +665,162 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     pconv_epilogue<float, NB, PG>(a, acc, pix, g, bg, s, P);
 }
 
+// The many-channel 3 x 3 / stride 1 layers (the UNet's middle levels, the decoder above the last level): k_pconv_x3 loads, bounds-checks and splits every input
+// element once per TAP and per row group - the split is half of its vector instructions, and on this kernel matrix time and vector time ADD UP
+// (profiles/r5/precise_x3.txt).  k_pconv_x3_chunk is k_pconv_x3_tile with a loop over 32-channel chunks of the concatenated sources: a workgroup owns an 8 x 16 pixel
+// tile and NB row blocks; per chunk the 10 x 18 halo is loaded and split ONCE into LDS ([pixel][4 x 8-channel vector][piece][8 bf16]), then nine steps - one per tap,
+// lane group g = 8-channel vector g of the chunk, so the tap offset is a scalar and there is no per-lane cursor at all - read activations (3 ds_read_b128 per pixel
+// group) and weights (LDS-DMA, two buffers, as k_pconv_x3) from LDS.  Channels are zero-padded to a multiple of 32 (pack_weights_x3_chunk: step = chunk * 9 + tap).
+constexpr int CHUNK_PIXB = 4 * 48 + 16;                                  // 52 dwords = 4 x odd
+
+template <int NB, int TERMS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_pconv_x3_chunk(const MpfPConvArgs a)
+{
+    typedef Vec4<float>::type v4;
+    typedef Vec4<double>::type v4d;
+    constexpr int PG = 2;
+    constexpr unsigned WSTEP = 3 * 64 * 16;
+    __shared__ __attribute__((aligned(16))) char wlds[2 * NB * WSTEP];
+    __shared__ __attribute__((aligned(16))) char tile[HALO_PIX * CHUNK_PIXB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;
+    const int P = a.Hout * a.Wout;
+    const int tx0 = blockIdx.x * TILE_W, ty0 = blockIdx.y * TILE_H;
+    const int nbg = a.nblk / NB, s = blockIdx.z / nbg, bg = blockIdx.z - s * nbg;
+    const int VA = a.CA >> 2, VT = (a.CA + a.CB) >> 2, nchunk = (VT + 7) >> 3, nsteps = nchunk * 9;
+    const char *wg = reinterpret_cast<const char *>(a.wpack) + (size_t)bg * NB * nsteps * WSTEP + (unsigned)lane * 16u;
+    auto weights = [&](const int t) {                                    // fragment f = nb * 3 + piece of step t; wave w copies fragments w, w + 4, ...
+        if (t >= nsteps) return;
+#pragma unroll
+        for (int j = 0; j < (NB * 3 + 3) / 4; ++j) {
+            const int f = wave + 4 * j;
+            if ((NB * 3) % 4 == 0 || f < NB * 3) {
+                const int nb = f / 3, q = f - 3 * nb;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wg + ((size_t)(nb * nsteps + t) * WSTEP + (unsigned)q * 1024u)),
+                                                 (__attribute__((address_space(3))) void *)(wlds + ((t & 1) * NB * 3 + f) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    const v4 zero = {0.f, 0.f, 0.f, 0.f};
+    v4 accH[NB][PG], accL[NB][PG];
+    v4d carry[NB][PG];
+    const bool gated = a.epi == EP_GATED || a.epi == EP_GATED_PLANAR;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        v4 init = zero;
+        if (gated) init = *reinterpret_cast<const v4 *>(reinterpret_cast<const float *>(a.bias) + (bg * NB + nb) * 16 + 4 * g);
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+            carry[nb][pg] = v4d{(double)init[0], (double)init[1], (double)init[2], (double)init[3]};
+            accH[nb][pg] = zero;
+            accL[nb][pg] = zero;
+        }
+    }
+    // ---- staging of one chunk: item = (halo pixel, 4-channel vector j of the chunk); the pixel part of the addressing is the same for every chunk
+    const bool reflect = a.pad_mode == 1;
+    const float *srcA = reinterpret_cast<const float *>(a.srcA) + (a.shareA ? (size_t)0 : (size_t)s * a.HA * a.WA * a.CA);
+    const float *srcB = reinterpret_cast<const float *>(a.CB ? a.srcB : a.srcA) + ((a.shareB || !a.CB) ? (size_t)0 : (size_t)s * a.Hin * a.Win * a.CB);
+    constexpr int NIT = (HALO_PIX * 8 + 255) / 256;                      // 6 items per thread and chunk
+    auto stage = [&](const int c) {
+        v4 x[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            // the pixel part of the addressing is recomputed per chunk: twelve registers held across the K loop cost more (spills at four row blocks)
+            const int i = tid + 256 * k, px = i >> 3, hy = px / HALO_W, hx = px - hy * HALO_W, v = 8 * c + (i & 7);
+            int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+            if (reflect) {                                               // nn.ReflectionPad2d(1)
+                iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * a.Hin - 2 - iy : iy);
+                ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * a.Win - 2 - ix : ix);
+            }
+            const bool ok = px < HALO_PIX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && v < VT;
+            x[k] = zero;
+            if (ok) x[k] = v < VA ? reinterpret_cast<const v4 *>(srcA)[(unsigned)((iy >> a.up) * a.WA + (ix >> a.up)) * (unsigned)VA + (unsigned)v]
+                                  : reinterpret_cast<const v4 *>(srcB)[(unsigned)(iy * a.Win + ix) * (unsigned)(VT - VA) + (unsigned)(v - VA)];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + 256 * k, px = i >> 3, j = i & 7;
+            if (NIT * 256 != HALO_PIX * 8 && px >= HALO_PIX) continue;
+            const Pieces q0 = split3(x[k][0], x[k][1]), q1 = split3(x[k][2], x[k][3]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2 *>(tile + px * CHUNK_PIXB + (j >> 1) * 48 + (j & 1) * 8 + q * 16) = make_uint2(q0.p[q], q1.p[q]);
+        }
+    };
+    // lane (m, g) of wave w: output pixels (ty0 + 2 w + pg, tx0 + m); step t = chunk * 9 + tap, K-vector g of the step = 8-channel vector g of the chunk
+    const char *xb = tile + ((2 * wave) * HALO_W + m) * CHUNK_PIXB + g * 48;
+    auto compute = [&](const int t, const int tap, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const char *xl = xb + (ky * HALO_W + kx) * CHUNK_PIXB;
+        u32x4_t xp[PG][3];
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xp[pg][q] = *reinterpret_cast<const u32x4_t *>(xl + pg * (HALO_W * CHUNK_PIXB) + q * 16);
+        const char *wb = wlds + (t & 1) * (NB * WSTEP) + lane * 16;
+#pragma unroll
+        for (int qa = 2; qa >= 0; --qa) {
+            u32x4_t w[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) w[nb] = *reinterpret_cast<const u32x4_t *>(wb + (nb * 3 + qa) * 1024);
+#pragma unroll
+            for (int qb = 2; qb >= 0; --qb) {
+                if (qa + qb > (TERMS == 8 ? 3 : 2)) continue;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int pg = 0; pg < PG; ++pg) {
+                        if (qa + qb == 0) accH[nb][pg] = mfma_bf16(w[nb], xp[pg][qb], FIRST ? zero : accH[nb][pg]);
+                        else accL[nb][pg] = mfma_bf16(w[nb], xp[pg][qb], accL[nb][pg]);
+                    }
+            }
+        }
+    };
+    auto flush = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) carry[nb][pg][i] += (double)accH[nb][pg][i];
+    };
+    weights(0);
+    for (int c = 0; c < nchunk; ++c) {
+        if (c) __syncthreads();                                          // every wave is done with the previous chunk's tile
+        stage(c);
+        // the barrier at the top of a step: this step's weights (and, at tap 0, the tile) are in LDS; the other weight buffer is free.
+        // accH: taps (0,1) (2,3) (4,5) (6,7) in pairs - 64 leading products per flush, the first of a pair from the zero operand - tap 8 alone
+        int t = c * 9;
+#pragma unroll 1
+        for (int tp = 0; tp < 4; ++tp) {
+            __syncthreads();
+            weights(t + 1);
+            compute(t, 2 * tp, std::true_type());
+            ++t;
+            __syncthreads();
+            weights(t + 1);
+            compute(t, 2 * tp + 1, std::false_type());
+            ++t;
+            flush();
+        }
+        __syncthreads();
+        weights(t + 1);
+        compute(t, 8, std::true_type());
+        flush();
+    }
+    v4 acc[NB][PG];
+    int pix[PG];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+        const int oy = ty0 + 2 * wave + pg, ox = tx0 + m;
+        pix[pg] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : P;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[nb][pg][i] = (float)(carry[nb][pg][i] + (double)accL[nb][pg][i]);
+    }
+    pconv_epilogue<float, NB, PG>(a, acc, pix, g, bg, s, P);
+}
+
 // ---- the tensors the reference builds with expand / cat / Upsample / adaptive_avg_pool2d, materialised ---------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_fmn_input(const float *__restrict__ image, const float *__restrict__ disp, const float *__restrict__ plane_vals, int S, int N,
@@ -844,6 +1000,21 @@ int launch_pconv_x3_tile_nb(const MpfPConvArgs &a, hipStream_t st)
     return mpf_launch_status("k_pconv_x3_tile");
 }
 
+template <int NB>
+int launch_pconv_x3_chunk_nb(const MpfPConvArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_pconv_x3_chunk<NB, 6>), dim3((a.Wout + TILE_W - 1) / TILE_W, (a.Hout + TILE_H - 1) / TILE_H, a.S * (a.nblk / NB)), dim3(256), 0, st, a);
+    return mpf_launch_status("k_pconv_x3_chunk");
+}
+
+int launch_pconv_x3_chunk(const MpfPConvArgs &a, hipStream_t st)
+{
+    if (a.nblk % 4 == 0) return launch_pconv_x3_chunk_nb<4>(a, st);
+    if (a.nblk % 3 == 0) return launch_pconv_x3_chunk_nb<3>(a, st);
+    if (a.nblk % 2 == 0) return launch_pconv_x3_chunk_nb<2>(a, st);
+    return launch_pconv_x3_chunk_nb<1>(a, st);
+}
+
 int launch_pconv_x3_tile(const MpfPConvArgs &a, hipStream_t st)
 {
     if (a.nblk == 1) return launch_pconv_x3_tile_nb<1>(a, st);
@@ -856,13 +1027,13 @@ inline size_t blocks_of(size_t n) { return (n + 255) / 256; }
 }  // namespace
 
 #define MPF_DTYPE_OK(d) ((d) == MPF_DTYPE_F32 || (d) == MPF_DTYPE_F64)
-#define MPF_PCONV_DTYPE_OK(d) (MPF_DTYPE_OK(d) || (d) == MPF_DTYPE_F32X3 || (d) == MPF_DTYPE_F32X3_TILE)
+#define MPF_PCONV_DTYPE_OK(d) (MPF_DTYPE_OK(d) || (d) == MPF_DTYPE_F32X3 || (d) == MPF_DTYPE_F32X3_TILE || (d) == MPF_DTYPE_F32X3_CHUNK)
 
 extern "C" int mpf_pconv(const MpfPConvArgs *args, void *stream)
 {
     MPF_REQUIRE(args != nullptr, "mpf_pconv: null argument block");
     const MpfPConvArgs &a = *args;
-    MPF_REQUIRE(MPF_PCONV_DTYPE_OK(a.dtype), "mpf_pconv: dtype must be MPF_DTYPE_F32, MPF_DTYPE_F64, MPF_DTYPE_F32X3 or MPF_DTYPE_F32X3_TILE");
+    MPF_REQUIRE(MPF_PCONV_DTYPE_OK(a.dtype), "mpf_pconv: dtype must be MPF_DTYPE_F32, MPF_DTYPE_F64 or one of the MPF_DTYPE_F32X3 forms");
     MPF_REQUIRE(a.srcA && a.wpack && a.out, "mpf_pconv: null source / weights / output");
     MPF_REQUIRE(a.ksize == 1 || a.ksize == 3 || a.ksize == 7, "mpf_pconv: kernel size must be 1, 3 or 7");
     MPF_REQUIRE((a.stride == 1 || a.stride == 2) && a.pad >= 0 && a.pad <= a.ksize / 2 && (a.up == 0 || a.up == 1), "mpf_pconv: bad stride / padding / upsampling");
@@ -891,6 +1062,11 @@ extern "C" int mpf_pconv(const MpfPConvArgs *args, void *stream)
         MPF_REQUIRE(a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.nblk <= 3 && a.CA + a.CB <= 56 && (size_t)a.S * a.nblk <= 65535,
                     "mpf_pconv: the tile form is 3 x 3, stride 1, padding 1, at most 56 input channels and 3 row blocks");
         return launch_pconv_x3_tile(a, (hipStream_t)stream);
+    }
+    if (a.dtype == MPF_DTYPE_F32X3_CHUNK) {
+        MPF_REQUIRE(a.ksize == 3 && a.stride == 1 && a.pad == 1 && (size_t)a.S * a.nblk <= 65535,
+                    "mpf_pconv: the chunk form is 3 x 3, stride 1, padding 1");
+        return launch_pconv_x3_chunk(a, (hipStream_t)stream);
     }
     MPF_REQUIRE(a.dtype != MPF_DTYPE_F32X3 || a.ksize <= 3, "mpf_pconv: the split-bf16 kernels are 1 x 1 and 3 x 3 (tap table in LDS)");
     if (a.dtype == MPF_DTYPE_F32X3) return launch_pconv_x3<6>(a, (hipStream_t)stream);

@@ -22,8 +22,9 @@ from .. import _lib
 
 EP_AFFINE, EP_AFFINE_MAP, EP_GATED, EP_GATED_PLANAR = 0, 1, 2, 3
 DTYPE_CODE = {torch.float32: 0, torch.float64: 1}
-X3_CODE, X3_TILE_CODE = 2, 3      # MPF_DTYPE_F32X3 / MPF_DTYPE_F32X3_TILE: fp32 tensors, products from bf16 pieces on the matrix cores
-X3_TILE = True                    # tools/bench_precise.py switches the tile form off for A/B timings
+X3_CODE, X3_TILE_CODE, X3_CHUNK_CODE = 2, 3, 4      # MPF_DTYPE_F32X3 / _TILE / _CHUNK: fp32 tensors, products from bf16 pieces on the matrix cores
+X3_TILE = True                    # tools/bench_precise.py switches the LDS-tile forms off for A/B timings
+X3_CHUNK = True
 ACT = {None: 0, "relu": 1, "leaky": 2}
 
 
@@ -112,6 +113,20 @@ def pack_weights_x3_tile(w_rows, device=None):
     return out.to(device) if device is not None else out
 
 
+def pack_weights_x3_chunk(w_rows, device=None):
+    """The A operand of k_pconv_x3_chunk (MPF_DTYPE_F32X3_CHUNK): 3 x 3 weights [R, Cv, 3, 3] over the CONCATENATED channels of both sources (Cv a multiple of 4,
+    zero-padded to a multiple of 32 here); step = chunk * 9 + tap, lane (m, g) holds row m, channels 32 chunk + 8 g .. + 7 -> [R/16, steps, 3, 64, 8] bfloat16."""
+    R, Cv, k, _ = w_rows.shape
+    assert k == 3 and R % 16 == 0 and Cv % 4 == 0
+    nch = (Cv + 31) // 32
+    w = torch.zeros(R, nch * 32, 3, 3, dtype=torch.float64)
+    w[:, :Cv] = w_rows
+    kv = w.reshape(R // 16, 16, nch, 4, 8, 9).permute(0, 2, 5, 3, 1, 4)                             # [blk, chunk, tap, g, m, j]
+    w32 = kv.reshape(R // 16, nch * 9, 64, 8).float()
+    out = _split_bf16x3(w32).permute(1, 2, 0, 3, 4).contiguous()
+    return out.to(device) if device is not None else out
+
+
 def _virtual_weights(w, segments):
     """conv weight [Cout, Cin_real, k, k] -> [Cout, sum(padded), k, k] with zero columns at the padding channels of every segment
     (segments: (padded, real) channel counts in concatenation order)."""
@@ -147,11 +162,18 @@ class PConv:
             x3 = False                                                   # the 7 x 7 stem (one launch, S = 1) stays on the fp32 instruction
         # the few-channel 3 x 3 layers: the input tile split once into LDS (k_pconv_x3_tile) instead of once per tap
         self.tile = bool(x3 and ksize == 3 and stride == 1 and pad == 1 and CA + CB <= 56 and self.nblk <= 3 and X3_TILE)
+        # every other 3 x 3 / stride 1 layer: the tile split once per 32-channel chunk (k_pconv_x3_chunk) - where the launch has the pixels for it (decided
+        # per call, `_form`; both packings are built on first use); strides and 1 x 1 kernels stay on k_pconv_x3
+        self.chunk = bool(x3 and not self.tile and ksize == 3 and stride == 1 and pad == 1 and X3_CHUNK)
         self.code = X3_TILE_CODE if self.tile else X3_CODE if x3 else DTYPE_CODE[dtype]
+        self._device, self._packs, self.force_chunk = device, {}, None       # force_chunk: True / False overrides the per-call choice (tests)
         if self.tile:
             self.wpack = pack_weights_x3_tile(w_rows.double(), device)
         else:
             self.wpack = pack_weights_x3(w_rows.double(), device, CA=CA) if x3 else pack_weights(w_rows.double(), dtype, device, CA=CA)
+        if self.chunk:
+            self._w_rows = w_rows.double().clone()
+            self._packs[X3_CODE] = self.wpack
         put = lambda t: None if t is None else t.to(dtype).contiguous().to(device)      # noqa: E731
         self.scale, self.shift, self.bias = put(scale), put(shift), put(bias)
 
@@ -193,6 +215,19 @@ class PConv:
                    Cst=cout if planar else pad4(cout), CA=segments[0][0], CB=segments[1][0] if len(segments) > 1 else 0, name=name, rows_real=2 * cout,
                    cin_real=cf.in_channels, x3=x3)
 
+    def _form(self, S, Hout, Wout):
+        """(dtype code, packed weights) of this launch.  The chunked LDS-tile kernel works on 8 x 16 pixel tiles, one 32-channel chunk after the other: it wins
+        (-10 ... -40 %) where there are tiles enough to fill the GPU and the plane is not mostly tile padding - not on the single-image encoder (a 12 x 40 plane
+        of 512 channels is 6 tiles x 16 sequential chunks) and not at 1/32 resolution (up0_4: 0.94 vs 0.66 ms)."""
+        if not self.chunk:
+            return self.code, self.wpack
+        tiles = ((Hout + 7) // 8) * ((Wout + 15) // 16)
+        auto = S * tiles * (self.nblk / 4.0) >= 1024 and Hout * Wout >= 0.8 * tiles * 128
+        code = X3_CHUNK_CODE if (auto if self.force_chunk is None else self.force_chunk) else X3_CODE
+        if code not in self._packs:
+            self._packs[code] = pack_weights_x3_chunk(self._w_rows, self._device)
+        return code, self._packs[code]
+
     # -- launch -----------------------------------------------------------------------------------------------------------------------------
     def __call__(self, S, Hin, Win, srcA, srcB=None, residual=None, shareA=False, shareB=False):
         """Hin x Win: the conv's (virtual) input size, after the x2 nearest up-sampling of srcA when up = 1."""
@@ -212,8 +247,9 @@ class PConv:
             out = torch.empty(S, Hout, Wout, self.Cst, dtype=self.dtype, device=dev)
         a = _lib.MpfPConvArgs()
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())      # noqa: E731
-        a.srcA, a.srcB, a.wpack, a.scale, a.shift, a.bias, a.residual, a.out = p(srcA), p(srcB), p(self.wpack), p(self.scale), p(self.shift), p(self.bias), p(residual), p(out)
-        a.dtype = self.code
+        code, wpack = self._form(S, Hout, Wout)
+        a.srcA, a.srcB, a.wpack, a.scale, a.shift, a.bias, a.residual, a.out = p(srcA), p(srcB), p(wpack), p(self.scale), p(self.shift), p(self.bias), p(residual), p(out)
+        a.dtype = self.last_code = code
         a.S, a.Hin, a.Win, a.Hout, a.Wout = S, Hin, Win, Hout, Wout
         a.HA, a.WA, a.CA, a.CB = HA, WA, self.CA, self.CB
         a.up, a.shareA, a.shareB = self.up, int(shareA), int(shareB)

@@ -73,7 +73,7 @@ def test_pack_weights_x3_layouts():
     """The split-bf16 kernels' A operands: three bf16 pieces that sum EXACTLY to the fp32 weight; MPF_DTYPE_F32X3: step t of a source = its fp32 K-steps
     2t and 2t+1 side by side (sources padded to an even count); MPF_DTYPE_F32X3_TILE: K-vector 4 t + g = (tap, 8-channel vector of the concatenated,
     zero-padded channels)."""
-    from mpiflow_amd.model.precise import pack_weights, pack_weights_x3, pack_weights_x3_tile
+    from mpiflow_amd.model.precise import pack_weights, pack_weights_x3, pack_weights_x3_chunk, pack_weights_x3_tile
     g = torch.Generator().manual_seed(2)
     for R, cv, ca, k in [(32, 20, 8, 3), (16, 12, 12, 3), (48, 36, 36, 1), (16, 8, 4, 3)]:
         w = torch.randn(R, cv, k, k, generator=g, dtype=torch.float64) * torch.logspace(-6, 3, cv, dtype=torch.float64)[None, :, None, None]
@@ -105,6 +105,17 @@ def test_pack_weights_x3_layouts():
                 n = min(8, cv - 8 * c8)
                 ref[:n] = w[blk * 16 + m, 8 * c8:8 * c8 + n, tap // 3, tap % 3].float().double()
             assert torch.equal(total[blk, t, lane], ref), (R, cv, blk, t, lane)
+        # MPF_DTYPE_F32X3_CHUNK: step = chunk * 9 + tap, lane (m, g) = row m, channels 32 chunk + 8 g .. + 7, zero-padded to a multiple of 32
+        got = pack_weights_x3_chunk(w)
+        nch = (cv + 31) // 32
+        assert got.shape == (R // 16, nch * 9, 3, 64, 8)
+        total = got.double().sum(2)
+        for blk, t, lane in [(0, 0, 0), (R // 16 - 1, nch * 9 - 1, 63), (0, 4, 37), (R // 16 - 1, (nch * 9) // 2, 21)]:
+            m, gg, c, tap = lane % 16, lane // 16, t // 9, t % 9
+            ref = torch.zeros(8, dtype=torch.float64)
+            n = max(0, min(8, cv - 32 * c - 8 * gg))
+            ref[:n] = w[blk * 16 + m, 32 * c + 8 * gg:32 * c + 8 * gg + n, tap // 3, tap % 3].float().double()
+            assert torch.equal(total[blk, t, lane], ref), ("chunk", R, cv, blk, t, lane)
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
@@ -174,13 +185,17 @@ def test_pconv_affine_matches_torch_fp64(dtype, x3, k, stride, up, cin, cout, S,
         ref = ref + r
     ref = {"relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.1), None: lambda t: t}[act](ref)
     layer = PConv.affine(dev, dtype, conv, bn, [(pad4(cin), cin)], act=act, slope=0.1, up=up, name="t", x3=x3)
-    out = layer(S, h, w, _nhwc(x, dtype, dev, pad4(cin)), residual=None if r is None else _nhwc(r, dtype, dev))
-    torch.cuda.synchronize()
-    got = out[..., :cout].permute(0, 3, 1, 2).double().cpu()
-    assert got.shape == ref.shape
-    assert float((got - ref).abs().max()) <= _tol(dtype) * float(ref.abs().max()), (float((got - ref).abs().max()), float(ref.abs().max()))
-    if out.shape[-1] > cout:
-        assert float(out[..., cout:].abs().max()) == 0.0                      # padding channels are written as zeros (the next layer's weights there are zero too)
+    assert layer.chunk == (x3 and k == 3 and stride == 1 and not layer.tile)
+    for force in ((False, True) if layer.chunk else (None,)):             # the many-channel 3 x 3 layers: the general kernel AND the chunked LDS-tile kernel
+        layer.force_chunk = force
+        out = layer(S, h, w, _nhwc(x, dtype, dev, pad4(cin)), residual=None if r is None else _nhwc(r, dtype, dev))
+        torch.cuda.synchronize()
+        assert layer.last_code == (4 if force else 3 if layer.tile else 2 if x3 and k <= 3 else (0 if dtype == torch.float32 else 1))      # the 7 x 7 stem stays on the fp32 instruction
+        got = out[..., :cout].permute(0, 3, 1, 2).double().cpu()
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= _tol(dtype) * float(ref.abs().max()), (force, float((got - ref).abs().max()), float(ref.abs().max()))
+        if out.shape[-1] > cout:
+            assert float(out[..., cout:].abs().max()) == 0.0                  # padding channels are written as zeros (the next layer's weights there are zero too)
 
 
 @pytest.mark.gpu
@@ -216,32 +231,36 @@ def test_pconv_gated_matches_torch_fp64(dtype, x3, ca, cb_real, cout, up, S, h, 
             ref = F.elu(bn.double()(ref))
     segs = [(ca, ca_real)] + ([(pad4(cb_real), cb_real)] if cb_real else [])
     layer = PConv.gated(dev, dtype, gc, bn, segs, up=up, planar=planar, name="t", x3=x3)
-    assert layer.tile == (x3 and ca + (pad4(cb_real) if cb_real else 0) <= 56 and layer.nblk <= 3)
-    out = layer(S, h, w, _nhwc(xa, dtype, dev, ca), None if xb is None else _nhwc(xb, dtype, dev, pad4(cb_real)))
-    torch.cuda.synchronize()
-    got = (out if planar else out[..., :cout].permute(0, 3, 1, 2)).double().cpu()
-    assert got.shape == ref.shape
-    assert float((got - ref).abs().max()) <= _tol(dtype) * max(1.0, float(ref.abs().max())), (float((got - ref).abs().max()), float(ref.abs().max()))
+    assert layer.tile == (x3 and ca + (pad4(cb_real) if cb_real else 0) <= 56 and layer.nblk <= 3) and layer.chunk == (x3 and not layer.tile)
+    for force in ((False, True) if layer.chunk else (None,)):
+        layer.force_chunk = force
+        out = layer(S, h, w, _nhwc(xa, dtype, dev, ca), None if xb is None else _nhwc(xb, dtype, dev, pad4(cb_real)))
+        torch.cuda.synchronize()
+        assert layer.last_code == (4 if force else 3 if layer.tile else 2 if x3 else (0 if dtype == torch.float32 else 1))
+        got = (out if planar else out[..., :cout].permute(0, 3, 1, 2)).double().cpu()
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= _tol(dtype) * max(1.0, float(ref.abs().max())), (force, float((got - ref).abs().max()), float(ref.abs().max()))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("x3", [pytest.param(True, id="x3"), pytest.param(False, id="mfma-f32")])
 def test_pconv_random_shapes_match_torch_fp64(x3):
-    """48 random layers - plane sizes that are no multiple of any tile (down to 2 x 2), 1 - 4 planes, one or two sources with channel counts that are no multiple of 8,
+    """72 random layers - plane sizes that are no multiple of any tile (down to 2 x 2), 1 - 4 planes, one or two sources with channel counts that are no multiple of 8,
     x2 nearest in front, stride 2 and 1 x 1 kernels (the general kernel), zero and reflection padding, 1 - 9 row blocks, every epilogue - against torch in double.
-    Covers what the fixed cases do not: every NB / PG variant of k_pconv_x3, partial tiles on all four edges of k_pconv_x3_tile, odd vector counts in both."""
+    Covers what the fixed cases do not: every NB / PG variant of k_pconv_x3, partial tiles on all four edges of k_pconv_x3_tile / k_pconv_x3_chunk (forced where the
+    plane is too small for the per-call choice to take it), partial last chunks, a chunk that straddles the two sources, odd vector counts."""
     from mpiflow_amd.model.adampi import GatedConv
     from mpiflow_amd.model.precise import PConv, pad4
     dev = _gpu()
     rs = np.random.RandomState(11)
     g = torch.Generator().manual_seed(12)
-    kinds = {"tile": 0, "general": 0}
-    for case in range(48):
+    kinds = {"tile": 0, "chunk": 0, "general": 0}
+    for case in range(72):
         gated = bool(rs.randint(2))
         up = int(rs.randint(2))
         S = int(rs.randint(1, 5))
         h, w = (int(rs.randint(1, 12)) * 2, int(rs.randint(1, 20)) * 2) if up else (int(rs.randint(2, 23)), int(rs.randint(2, 39)))
-        ca_real = int(rs.choice([3, 4, 5, 8, 12, 13, 16, 24, 30, 48, 70]))
+        ca_real = int(rs.choice([3, 4, 5, 8, 12, 13, 16, 24, 30, 48, 70, 100, 132]))
         cb_real = int(rs.choice([0, 0, 2, 6, 14, 20, 36]))
         cout = int(rs.choice([1, 4, 12, 16, 24, 33, 48, 64, 100, 130])) if not gated else int(rs.choice([2, 4, 12, 20, 24, 40, 66]))
         if gated:
@@ -268,14 +287,16 @@ def test_pconv_random_shapes_match_torch_fp64(x3):
                 act = [None, "relu", "leaky"][rs.randint(3)]
                 ref = {"relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.1), None: lambda t: t}[act](bn.double()(mod.double()(xin)))
                 layer = PConv.affine(dev, torch.float32, mod, bn, segs, act=act, slope=0.1, up=up, name="fuzz%d" % case, x3=x3)
-        kinds["tile" if layer.tile else "general"] += 1
+        if layer.chunk:
+            layer.force_chunk = case % 3 != 0                                 # small planes would always take the general kernel
+        kinds["tile" if layer.tile else "chunk" if layer.chunk and layer.force_chunk else "general"] += 1
         out = layer(S, h, w, _nhwc(xa, torch.float32, dev, pad4(ca_real)), None if xb is None else _nhwc(xb, torch.float32, dev, pad4(cb_real)))
         torch.cuda.synchronize()
         got = (out if gated and bn is None else out[..., :cout].permute(0, 3, 1, 2)).double().cpu()
         assert got.shape == ref.shape, (case, got.shape, ref.shape)
         err, scale = float((got - ref).abs().max()), max(1.0, float(ref.abs().max()))
-        assert err <= 3e-6 * scale, (case, dict(gated=gated, up=up, S=S, h=h, w=w, ca=ca_real, cb=cb_real, cout=cout, k=k, stride=stride, tile=layer.tile), err, scale)
-    assert (kinds["tile"] >= 8) == x3 and kinds["general"] >= 8, kinds
+        assert err <= 3e-6 * scale, (case, dict(gated=gated, up=up, S=S, h=h, w=w, ca=ca_real, cb=cb_real, cout=cout, k=k, stride=stride, tile=layer.tile, code=layer.last_code), err, scale)
+    assert (kinds["tile"] >= 8) == x3 and (kinds["chunk"] >= 8) == x3 and kinds["general"] >= 8, kinds
 
 
 @pytest.mark.gpu
@@ -491,8 +512,14 @@ def test_precise_engine_rejects_bad_arguments():
         PrecisePredictor(MPIPredictor(128, 128, 4).randomize_(0).to(dev), dtype=torch.float64, x3=True)      # the split-bf16 kernels compute on fp32 tensors
     # a layer the tile form does not cover, forced into it: refused by the C entry point, nothing launched
     L = pp.up1[4]
-    assert not L.tile and L.code == 2
-    L.code = 3
+    assert not L.tile and L.chunk and L.code == 2
+    L.chunk, L.code = False, 3
     with pytest.raises(_lib.MpiFlowHipError, match="tile form"):
         L(4, 8, 8, torch.zeros(4, 4, 4, L.CA, device=dev), torch.zeros(4, 8, 8, L.CB, device=dev))
-    L.code = 2
+    L.chunk, L.code = True, 2
+    S1 = pp.e_blocks[2][2]                                                 # a stride-2 1 x 1 down-sample branch, forced into the chunk form
+    assert S1 is not None and not S1.chunk and S1.stride == 2
+    S1.code = 4
+    with pytest.raises(_lib.MpiFlowHipError, match="chunk form"):
+        S1(1, 8, 8, torch.zeros(8, 8, S1.CA, device=dev))
+    S1.code = 2

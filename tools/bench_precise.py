@@ -1,7 +1,7 @@
 """Time and error of the parity-grade producer engine (mpiflow_amd/model/precise.py) at the generator's size, per layer.
-usage: python tools/bench_precise.py [fp32|x3|x3-notile|fp64|both|all] [S H W]
+usage: python tools/bench_precise.py [fp32|x3|x3-nochunk|x3-notile|fp64|both|all] [S H W]
 (fp32: the v_mfma_f32_16x16x4_f32 kernels; x3: fp32 tensors, products from three bf16 pieces on the matrix cores - what --model-dtype fp32 runs;
-x3-notile: without the LDS-tile kernel of the few-channel layers; "all" also prints every fp32-class mode's error against the fp64 engine, which is the
+x3-nochunk: without the chunked LDS-tile kernel of the many-channel layers, x3-notile: without either LDS-tile kernel; "all" also prints every fp32-class mode's error against the fp64 engine, which is the
 torch modules in double to 1e-9: tests/test_precise_engine.py)"""
 import os
 import sys
@@ -21,10 +21,11 @@ g = torch.Generator().manual_seed(3)
 img, dsp = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 1, H, W, generator=g).to(dev)
 outs = {}
 import mpiflow_amd.model.precise as P                           # noqa: E402
-for name, dt, x3 in (("fp32", torch.float32, False), ("x3", torch.float32, True), ("x3-notile", torch.float32, True), ("fp64", torch.float64, False)):
+for name, dt, x3 in (("fp32", torch.float32, False), ("x3", torch.float32, True), ("x3-nochunk", torch.float32, True), ("x3-notile", torch.float32, True), ("fp64", torch.float64, False)):
     if not (which == name or which == "all" or (which == "both" and not x3)):
         continue
     P.X3_TILE = name != "x3-notile"
+    P.X3_CHUNK = name not in ("x3-notile", "x3-nochunk")
     pp = PrecisePredictor(m, dtype=dt, x3=x3, keep_dtype=True)
     pp(img, dsp)
     torch.cuda.synchronize()

@@ -279,6 +279,15 @@ __global__ __launch_bounds__(256) void k_pconv(const MpfPConvArgs a)
 // into one accumulator, the small ones into a second one, both are added into the fp64 carries every FLUSH steps (64 leading products):
 // the same two-level sum as k_pconv<float>.  Weights are split on the host (pack_weights_x3), activations in the loader: 9 VALU
 // instructions per pair of elements (v_cvt_pk_bf16_f32 x3, two shifts / masks x2, v_pk_add_f32 x2), shared by the NB row blocks.
+// The barrier of the kernels that copy weights global -> LDS (LDS-DMA): a copy is ordered for other waves' reads only by the ISSUING wave's vmcnt wait followed by a
+// barrier.  __syncthreads()'s fence emits that wait only where the compiler believes a copy is pending - it lost track of one issued under a wave-dependent
+// condition (k_pconv_x3_chunk<1>: a bare s_barrier, stale weights, caught by the forced-form test) - so the wait is spelled out.
+#define MPF_COPY_BARRIER()                                  \
+    do {                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
+        __syncthreads();                                    \
+    } while (0)
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         weights_upto(step);
         for (int st = 0; st < n2; st += 2) {
 #if MPF_X3_ABLATE != 3                                                   // timing ablation ONLY: no barrier
-            __syncthreads();
+            MPF_COPY_BARRIER();
 #endif
             request(B.x0);
             request(B.x1);
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             compute(A, step++, std::true_type());
             if (st + 1 < n2) {
 #if MPF_X3_ABLATE != 3
-                __syncthreads();
+                MPF_COPY_BARRIER();
 #endif
                 request(A.x0);
                 request(A.x1);
@@ -756,12 +765,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int pg = 0; pg < PG; ++pg)
 #pragma unroll
             for (int q = 0; q < 3; ++q) xp[pg][q] = *reinterpret_cast<const u32x4_t *>(xl + pg * (HALO_W * CHUNK_PIXB) + q * 16);
-        const char *wb = wlds + (t & 1) * (NB * WSTEP) + lane * 16;
+        // weight fragments by inline assembly: after a global_load_lds the compiler puts s_waitcnt vmcnt(0) in front of every LDS read it can see that may alias the
+        // copy's destination - that would wait for the copy of step t + 1, just issued, before step t starts.  The barriers order these reads against the copies.
+        const unsigned wb = (unsigned)(uintptr_t)(wlds + (t & 1) * (NB * WSTEP) + lane * 16);
 #pragma unroll
         for (int qa = 2; qa >= 0; --qa) {
             u32x4_t w[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) w[nb] = *reinterpret_cast<const u32x4_t *>(wb + (nb * 3 + qa) * 1024);
+            for (int nb = 0; nb < NB; ++nb) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[nb]) : "v"(wb), "n"((nb * 3 + qa) * 1024));
+            if constexpr (NB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+            else if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]));
+            else if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]));
 #pragma unroll
             for (int qb = 2; qb >= 0; --qb) {
                 if (qa + qb > (TERMS == 8 ? 3 : 2)) continue;
@@ -785,24 +800,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     };
     weights(0);
     for (int c = 0; c < nchunk; ++c) {
-        if (c) __syncthreads();                                          // every wave is done with the previous chunk's tile
+        if (c) MPF_COPY_BARRIER();                                       // every wave is done with the previous chunk's tile
         stage(c);
         // the barrier at the top of a step: this step's weights (and, at tap 0, the tile) are in LDS; the other weight buffer is free.
         // accH: taps (0,1) (2,3) (4,5) (6,7) in pairs - 64 leading products per flush, the first of a pair from the zero operand - tap 8 alone
         int t = c * 9;
 #pragma unroll 1
         for (int tp = 0; tp < 4; ++tp) {
-            __syncthreads();
+            MPF_COPY_BARRIER();
             weights(t + 1);
             compute(t, 2 * tp, std::true_type());
             ++t;
-            __syncthreads();
+            MPF_COPY_BARRIER();
             weights(t + 1);
             compute(t, 2 * tp + 1, std::false_type());
             ++t;
             flush();
         }
-        __syncthreads();
+        MPF_COPY_BARRIER();
         weights(t + 1);
         compute(t, 8, std::true_type());
         flush();

@@ -25,6 +25,7 @@ DTYPE_CODE = {torch.float32: 0, torch.float64: 1}
 X3_CODE, X3_TILE_CODE, X3_CHUNK_CODE = 2, 3, 4      # MPF_DTYPE_F32X3 / _TILE / _CHUNK: fp32 tensors, products from bf16 pieces on the matrix cores
 X3_TILE = True                    # tools/bench_precise.py switches the LDS-tile forms off for A/B timings
 X3_CHUNK = True
+X3_TILE_MAXC = 40                 # input channels up to which the one-pass tile kernel is used (it takes 56; l8's 48 are 10 % faster as two 32-channel chunks)
 ACT = {None: 0, "relu": 1, "leaky": 2}
 
 
@@ -161,7 +162,7 @@ class PConv:
         if ksize > 3:
             x3 = False                                                   # the 7 x 7 stem (one launch, S = 1) stays on the fp32 instruction
         # the few-channel 3 x 3 layers: the input tile split once into LDS (k_pconv_x3_tile) instead of once per tap
-        self.tile = bool(x3 and ksize == 3 and stride == 1 and pad == 1 and CA + CB <= 56 and self.nblk <= 3 and X3_TILE)
+        self.tile = bool(x3 and ksize == 3 and stride == 1 and pad == 1 and CA + CB <= X3_TILE_MAXC and self.nblk <= 3 and X3_TILE)
         # every other 3 x 3 / stride 1 layer: the tile split once per 32-channel chunk (k_pconv_x3_chunk) - where the launch has the pixels for it (decided
         # per call, `_form`; both packings are built on first use); strides and 1 x 1 kernels stay on k_pconv_x3
         self.chunk = bool(x3 and not self.tile and ksize == 3 and stride == 1 and pad == 1 and X3_CHUNK)

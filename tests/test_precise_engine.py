@@ -206,7 +206,9 @@ def test_pconv_affine_matches_torch_fp64(dtype, x3, k, stride, up, cin, cout, S,
     (48, 0, 24, 0, 2, 10, 14, True, False),            # up0_1
     (12, 0, 4, 0, 2, 9, 13, False, True),              # disp0: planar raw output, odd sizes
     (516, 0, 192, 0, 2, 3, 5, True, False),            # up0_4: 514 real channels
-    (32, 14, 12, 1, 2, 12, 20, True, False),           # two sources in the LDS-tile kernel (x3): x2 nearest ++ a 14-of-16-channel skip, 48 channels
+    (16, 14, 12, 1, 2, 12, 20, True, False),           # two sources in the LDS-tile kernel (x3): x2 nearest ++ a 14-of-16-channel skip
+    (24, 0, 24, 0, 2, 10, 14, True, False),            # three row blocks in the LDS-tile kernel (x3)
+    (32, 14, 12, 1, 2, 12, 20, True, False),           # 48 channels from two sources: two 32-channel chunks, the first one straddles the sources
     (12, 6, 20, 0, 2, 11, 19, True, False),            # odd vector count (12 + 8 channels = 5 vectors: the zero half of the last 8-channel vector), three row blocks
 ])
 def test_pconv_gated_matches_torch_fp64(dtype, x3, ca, cb_real, cout, up, S, h, w, bnorm, planar):
@@ -231,7 +233,7 @@ def test_pconv_gated_matches_torch_fp64(dtype, x3, ca, cb_real, cout, up, S, h, 
             ref = F.elu(bn.double()(ref))
     segs = [(ca, ca_real)] + ([(pad4(cb_real), cb_real)] if cb_real else [])
     layer = PConv.gated(dev, dtype, gc, bn, segs, up=up, planar=planar, name="t", x3=x3)
-    assert layer.tile == (x3 and ca + (pad4(cb_real) if cb_real else 0) <= 56 and layer.nblk <= 3) and layer.chunk == (x3 and not layer.tile)
+    assert layer.tile == (x3 and ca + (pad4(cb_real) if cb_real else 0) <= 40 and layer.nblk <= 3) and layer.chunk == (x3 and not layer.tile)
     for force in ((False, True) if layer.chunk else (None,)):
         layer.force_chunk = force
         out = layer(S, h, w, _nhwc(xa, dtype, dev, ca), None if xb is None else _nhwc(xb, dtype, dev, pad4(cb_real)))
@@ -249,53 +251,58 @@ def test_pconv_random_shapes_match_torch_fp64(x3):
     x2 nearest in front, stride 2 and 1 x 1 kernels (the general kernel), zero and reflection padding, 1 - 9 row blocks, every epilogue - against torch in double.
     Covers what the fixed cases do not: every NB / PG variant of k_pconv_x3, partial tiles on all four edges of k_pconv_x3_tile / k_pconv_x3_chunk (forced where the
     plane is too small for the per-call choice to take it), partial last chunks, a chunk that straddles the two sources, odd vector counts."""
+    import mpiflow_amd.model.precise as P
     from mpiflow_amd.model.adampi import GatedConv
     from mpiflow_amd.model.precise import PConv, pad4
     dev = _gpu()
     rs = np.random.RandomState(11)
     g = torch.Generator().manual_seed(12)
     kinds = {"tile": 0, "chunk": 0, "general": 0}
-    for case in range(72):
-        gated = bool(rs.randint(2))
-        up = int(rs.randint(2))
-        S = int(rs.randint(1, 5))
-        h, w = (int(rs.randint(1, 12)) * 2, int(rs.randint(1, 20)) * 2) if up else (int(rs.randint(2, 23)), int(rs.randint(2, 39)))
-        ca_real = int(rs.choice([3, 4, 5, 8, 12, 13, 16, 24, 30, 48, 70, 100, 132]))
-        cb_real = int(rs.choice([0, 0, 2, 6, 14, 20, 36]))
-        cout = int(rs.choice([1, 4, 12, 16, 24, 33, 48, 64, 100, 130])) if not gated else int(rs.choice([2, 4, 12, 20, 24, 40, 66]))
-        if gated:
-            k, stride = 3, 1
-            mod = _randomize(GatedConv(ca_real + cb_real, cout), g)
-            bn = _randomize(torch.nn.BatchNorm2d(cout), g) if rs.randint(2) else None
-        else:
-            k, stride = (3, 1) if rs.randint(3) else ((1, 1) if rs.randint(2) else (3, 2))
-            mod = _randomize(torch.nn.Conv2d(ca_real + cb_real, cout, k, stride, k // 2, bias=bool(rs.randint(2))), g)
-            bn = _randomize(torch.nn.BatchNorm2d(cout), g)
-        xa = torch.randn(S, ca_real, h >> up, w >> up, generator=g, dtype=torch.float64)
-        xb = torch.randn(S, cb_real, h, w, generator=g, dtype=torch.float64) if cb_real else None
-        xin = F.interpolate(xa, scale_factor=2, mode="nearest") if up else xa
-        if xb is not None:
-            xin = torch.cat([xin, xb], dim=1)
-        segs = [(pad4(ca_real), ca_real)] + ([(pad4(cb_real), cb_real)] if cb_real else [])
-        with torch.no_grad():
+    try:
+        for case in range(72):
+            gated = bool(rs.randint(2))
+            up = int(rs.randint(2))
+            S = int(rs.randint(1, 5))
+            P.X3_TILE_MAXC = 56 if case & 1 else 40                           # the tile kernel takes up to 56 input channels; the engine uses it up to 40
+            h, w = (int(rs.randint(1, 12)) * 2, int(rs.randint(1, 20)) * 2) if up else (int(rs.randint(2, 23)), int(rs.randint(2, 39)))
+            ca_real = int(rs.choice([3, 4, 5, 8, 12, 13, 16, 24, 30, 48, 70, 100, 132]))
+            cb_real = int(rs.choice([0, 0, 2, 6, 14, 20, 36]))
+            cout = int(rs.choice([1, 4, 12, 16, 24, 33, 48, 64, 100, 130])) if not gated else int(rs.choice([2, 4, 12, 20, 24, 40, 66]))
             if gated:
-                ref = mod.double()(xin)
-                if bn is not None:
-                    ref = F.elu(bn.double()(ref))
-                layer = PConv.gated(dev, torch.float32, mod, bn, segs, up=up, planar=bn is None, name="fuzz%d" % case, x3=x3)      # without BatchNorm: the planar raw-output epilogue
+                k, stride = 3, 1
+                mod = _randomize(GatedConv(ca_real + cb_real, cout), g)
+                bn = _randomize(torch.nn.BatchNorm2d(cout), g) if rs.randint(2) else None
             else:
-                act = [None, "relu", "leaky"][rs.randint(3)]
-                ref = {"relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.1), None: lambda t: t}[act](bn.double()(mod.double()(xin)))
-                layer = PConv.affine(dev, torch.float32, mod, bn, segs, act=act, slope=0.1, up=up, name="fuzz%d" % case, x3=x3)
-        if layer.chunk:
-            layer.force_chunk = case % 3 != 0                                 # small planes would always take the general kernel
-        kinds["tile" if layer.tile else "chunk" if layer.chunk and layer.force_chunk else "general"] += 1
-        out = layer(S, h, w, _nhwc(xa, torch.float32, dev, pad4(ca_real)), None if xb is None else _nhwc(xb, torch.float32, dev, pad4(cb_real)))
-        torch.cuda.synchronize()
-        got = (out if gated and bn is None else out[..., :cout].permute(0, 3, 1, 2)).double().cpu()
-        assert got.shape == ref.shape, (case, got.shape, ref.shape)
-        err, scale = float((got - ref).abs().max()), max(1.0, float(ref.abs().max()))
-        assert err <= 3e-6 * scale, (case, dict(gated=gated, up=up, S=S, h=h, w=w, ca=ca_real, cb=cb_real, cout=cout, k=k, stride=stride, tile=layer.tile, code=layer.last_code), err, scale)
+                k, stride = (3, 1) if rs.randint(3) else ((1, 1) if rs.randint(2) else (3, 2))
+                mod = _randomize(torch.nn.Conv2d(ca_real + cb_real, cout, k, stride, k // 2, bias=bool(rs.randint(2))), g)
+                bn = _randomize(torch.nn.BatchNorm2d(cout), g)
+            xa = torch.randn(S, ca_real, h >> up, w >> up, generator=g, dtype=torch.float64)
+            xb = torch.randn(S, cb_real, h, w, generator=g, dtype=torch.float64) if cb_real else None
+            xin = F.interpolate(xa, scale_factor=2, mode="nearest") if up else xa
+            if xb is not None:
+                xin = torch.cat([xin, xb], dim=1)
+            segs = [(pad4(ca_real), ca_real)] + ([(pad4(cb_real), cb_real)] if cb_real else [])
+            with torch.no_grad():
+                if gated:
+                    ref = mod.double()(xin)
+                    if bn is not None:
+                        ref = F.elu(bn.double()(ref))
+                    layer = PConv.gated(dev, torch.float32, mod, bn, segs, up=up, planar=bn is None, name="fuzz%d" % case, x3=x3)      # without BatchNorm: the planar raw-output epilogue
+                else:
+                    act = [None, "relu", "leaky"][rs.randint(3)]
+                    ref = {"relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.1), None: lambda t: t}[act](bn.double()(mod.double()(xin)))
+                    layer = PConv.affine(dev, torch.float32, mod, bn, segs, act=act, slope=0.1, up=up, name="fuzz%d" % case, x3=x3)
+            if layer.chunk:
+                layer.force_chunk = case % 3 != 0                                 # small planes would always take the general kernel
+            kinds["tile" if layer.tile else "chunk" if layer.chunk and layer.force_chunk else "general"] += 1
+            out = layer(S, h, w, _nhwc(xa, torch.float32, dev, pad4(ca_real)), None if xb is None else _nhwc(xb, torch.float32, dev, pad4(cb_real)))
+            torch.cuda.synchronize()
+            got = (out if gated and bn is None else out[..., :cout].permute(0, 3, 1, 2)).double().cpu()
+            assert got.shape == ref.shape, (case, got.shape, ref.shape)
+            err, scale = float((got - ref).abs().max()), max(1.0, float(ref.abs().max()))
+            assert err <= 3e-6 * scale, (case, dict(gated=gated, up=up, S=S, h=h, w=w, ca=ca_real, cb=cb_real, cout=cout, k=k, stride=stride, tile=layer.tile, code=layer.last_code), err, scale)
+    finally:
+        P.X3_TILE_MAXC = 40
     assert (kinds["tile"] >= 8) == x3 and (kinds["chunk"] >= 8) == x3 and kinds["general"] >= 8, kinds
 
 

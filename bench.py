@@ -775,7 +775,7 @@ def main():
                 out["generator_precise"] = generator_record(n_images=24, n_distinct=24, model_dtype="fp32")
                 out["generator_precise"]["producer_precision"] = ("parity-grade engine (--model-dtype fp32): fp32 tensors, products from bf16 pieces on the matrix cores, fp32 blocks of "
                                                                   "64 products carried in fp64 (tests/test_precise_engine.py: closer to the fp64 mirror than torch's own fp32); "
-                                                                  "~43 ms per image, so the generator is bound by it")
+                                                                  "~37 ms per image, so the generator is bound by it")
             except Exception as e:                                   # noqa: BLE001
                 out["generator_precise"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:

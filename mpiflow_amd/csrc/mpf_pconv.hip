@@ -6,8 +6,8 @@
 // the tests use to show that the engine computes the reference's network and not something 1e-4 away from it.
 //
 // A third form, what --model-dtype fp32 runs: the same fp32 tensors and the same two-level sum with every PRODUCT taken from the three bf16 numbers each fp32 factor
-// is exactly the sum of, on v_mfma_f32_16x16x32_bf16 - the matrix cores instead of the vector-rate fp32 instruction (k_pconv_x3, k_pconv_x3_tile below: a third
-// faster and three times closer to exact arithmetic).
+// is exactly the sum of, on v_mfma_f32_16x16x32_bf16 - the matrix cores instead of the vector-rate fp32 instruction (k_pconv_x3, k_pconv_x3_tile, k_pconv_x3_chunk
+// below: 37 instead of 59 ms per image and three times closer to exact arithmetic).
 //
 // This is the accuracy mode, not the fast one (that is mpf_conv.hip: fp16 storage, 7.7 ms per image).  Inputs are plain
 // materialised NHWC tensors; the only synthesis left in the loader is what costs nothing: the concatenation of two sources,

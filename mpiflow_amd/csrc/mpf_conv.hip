@@ -359,7 +359,7 @@ void k_conv3x3(const MpfConvArgs a)
         if constexpr (WLDS) {
             // LDS-DMA (global_load_lds_dwordx4): the fragments are a plain copy (host-packed in fragment order), so they go global ->
             // LDS without passing through registers or ds_write; destination = wave-uniform base + lane * 16, i.e. one 1 KB fragment
-            // per wave instruction.  The __syncthreads() below drains it (hipcc waits vmcnt(0) before the barrier), and the barrier
+            // per wave instruction.  The explicit vmcnt(0) + __syncthreads() below drains it, and the barrier
             // at the top of the loop keeps it from overtaking the previous chunk's fragment reads.  Against staging through
             // registers: -20 % on the full-resolution bilinear layer, -5..-10 % on the decoder's 24-block layers, and it makes
             // LDS staging the better choice on three more layers (profiles/r2/engine_glds_layers.txt)
@@ -381,6 +381,7 @@ void k_conv3x3(const MpfConvArgs a)
                     if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const u32x4 *)a.srcA + (rawsrc[k] + (unsigned)(chunk * VPP))),
                                                          (__attribute__((address_space(3))) void *)(raw + (__builtin_amdgcn_readfirstlane(wave) * 64 + k * 256) * 16), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the raw tile's LDS-DMA: the issuing wave's wait, spelled out (see below)
                 __syncthreads();
             }
         }
@@ -410,6 +411,10 @@ void k_conv3x3(const MpfConvArgs a)
             const int p = sp + k * PPT;
             if (NI * PPT == LH * LW || p < LH * LW) *reinterpret_cast<u32x4 *>(tile + p * PIXB + sv * 16) = staged[k];
         }
+        // An LDS-DMA copy is ordered for other waves' reads only by the ISSUING wave's vmcnt wait in front of a barrier.  __syncthreads()'s fence emits that wait
+        // where the compiler believes a copy is pending; round 5 found it losing track of a copy issued under a wave-dependent condition (mpf_pconv.hip,
+        // MPF_COPY_BARRIER) - the fragment copies above are issued under one (vb < WVEC) - so the wait is explicit here too (it was already emitted: no change in time).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {

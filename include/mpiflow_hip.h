@@ -31,11 +31,12 @@
 extern "C" {
 #endif
 
-#define MPF_VERSION 502   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
+#define MPF_VERSION 503   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
                              round 4 (401): + mpf_moving_object_chain, mpf_warp_views_blend_next_merge_prev, mpf_stream_create_cu_subset / _destroy,
                              mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6;
                              round 5 (501): + the parity-grade producer engine mpf_pconv, mpf_pfmn_input, mpf_pencoder_input, mpf_pbilinear2x, mpf_pper_plane,
-                             mpf_pplane_masks, mpf_pmaxpool3x3s2; MpfMergeArgs + obj_mask_stride, mpf_merge_ex, mpf_src_flow_hard */
+                             mpf_pplane_masks, mpf_pmaxpool3x3s2; MpfMergeArgs + obj_mask_stride, mpf_merge_ex, mpf_src_flow_hard;
+                             (503): MpfConvArgs + pw (planes per workgroup of the few-block layers) */
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)
@@ -374,6 +375,8 @@ typedef struct MpfConvArgs {
                                          layers), 0: every wave loads its fragments from global memory (tuning choice, same results) */
     int plane_major;                  /* 1: the plane index is the fastest grid dimension (the S workgroups of a tile back to back: per-image sources
                                          shared by the planes stay in L2); scheduling only, same results */
+    int pw;                           /* planes per workgroup (0 / 1: one): a workgroup walks pw consecutive planes at its tile position and computes what depends
+                                         on the pixel only once (nblk / ncg <= 2 only; S % pw == 0); scheduling only, same results */
 } MpfConvArgs;
 
 int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream);

@@ -240,7 +240,10 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
-template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS>
+// WALK: the workgroup walks a.pw CONSECUTIVE planes at its tile position (grid: S / pw plane groups).  Everything that depends on the pixel only - border
+// handling, the bilinear weights and raw-tile offsets, tap offsets, the parked epilogue rows: about a third of the VALU work of a few-channel full-resolution
+// layer - is computed once per workgroup instead of once per plane; per plane only the sources' plane offsets advance.  Same arithmetic per output.
+template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS, bool WALK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB <= 2 ? 3 : (NB <= 6 ? 2 : 1))))
 void k_conv3x3(const MpfConvArgs a)
 {
@@ -267,7 +270,9 @@ void k_conv3x3(const MpfConvArgs a)
     // plane_major: the plane index is the FASTEST grid dimension, so the S workgroups of one tile are dispatched back to back (8 per XCD) and find the
     // per-image sources they share (LD_FMN_SYNTH / LD_BILINEAR_SYNTH: the A', B' maps) in that XCD's L2 instead of re-fetching them per plane
     const unsigned bx = a.plane_major ? blockIdx.y : blockIdx.x, by = a.plane_major ? blockIdx.z : blockIdx.y, bz = a.plane_major ? blockIdx.x : blockIdx.z;
-    const int s = (int)bz / a.ncg, cg = (int)bz - s * a.ncg;
+    const int npw = WALK ? a.pw : 1;
+    const int sgrp = (int)bz / a.ncg, cg = (int)bz - sgrp * a.ncg;
+    int s = sgrp * npw;                                       // first plane of this workgroup
     // affine epilogues use rows 0, 1 of all NB blocks; the gated one rows 1, 2 of its NB/2 feature blocks; the planar one none.
     // One value per thread, loaded here (the round trip overlaps the staging set-up) and parked in LDS: in its own region where
     // that costs no resident workgroup (EPW > 0), else in the input tile's space once the last MFMA phase is over.
@@ -304,6 +309,44 @@ void k_conv3x3(const MpfConvArgs a)
         const int ly = p / LW, lx = p - ly * LW;
         stage_init<LOADER>(stage[k], a, s, iy0 + ly, ix0 + lx, p < LH * LW, ry0, rx0, RW, VPP, sv);
     }
+    if (EPW && tid < 2 * EPN) eplds[tid] = epv;
+
+    const int q = lane >> 4, pi = lane & 15;
+    // per-lane LDS byte offset of the tap each k-step reads (tap-packed layers: the tap depends on the lane's k-quarter)
+    int tapoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        int slot = ks * TPS + q / VPP;
+        slot = slot > 8 ? 8 : slot;                          // zero weights there; any finite operand will do
+        const int ky = slot / 3, kx = slot - ky * 3;
+        tapoff[ks] = (ky * LW + pi * ST + kx) * PIXB + (q % VPP) * 16;
+    }
+    // weights (host-packed in fragment order, 1 KB per fragment).  WLDS: the chunk's KS x NB fragments go through LDS once
+    // per workgroup - per-wave fragment loads cost as much L1 time as the MFMAs they feed, which is what bounds the
+    // many-chunk / many-block layers; the few-chunk, LDS-hungry layers are better off loading fragments per wave (!WLDS).
+    const u32x4 *wbase = (const u32x4 *)a.wpack + (unsigned)(cg * NB) * 64u;
+    const unsigned wstride = (unsigned)a.nblk * 64u;         // vectors of one k-step in global memory
+
+#pragma nounroll
+    for (int pw = 0; pw < npw; ++pw, ++s) {
+    if (WALK && pw) {
+        // the next plane at the same tile position: only the sources' plane offsets move
+        if constexpr (RAW) {
+            const unsigned dr = (unsigned)(a.HA * a.WA) * ((unsigned)a.CA >> 3);
+#pragma unroll
+            for (int k = 0; k < NR; ++k) rawsrc[k] += dr;
+        }
+        if constexpr (LOADER == LD_DIRECT || LOADER == LD_NEAREST_PLANE) {
+            const unsigned da = LOADER == LD_DIRECT ? (unsigned)(a.Hin * a.Win) : (unsigned)(a.HA * a.WA);
+#pragma unroll
+            for (int k = 0; k < NI; ++k) stage[k].ia += da;
+        }
+        if constexpr (LOADER == LD_BILINEAR_CAT) {
+            const unsigned db = (unsigned)(a.Hin * a.Win);
+#pragma unroll
+            for (int k = 0; k < NI; ++k) stage[k].ib += db;
+        }
+    }
     if constexpr (LOADER == LD_NEAREST_PLANE) {
         // the plane's mask values of the staged pixels: all 2 * NI loads first, conversions after (written per pixel, hipcc waited
         // for each load before issuing the next: 6 dependent round trips at the head of every workgroup)
@@ -322,9 +365,6 @@ void k_conv3x3(const MpfConvArgs a)
             }
         }
     }
-    if (EPW && tid < 2 * EPN) eplds[tid] = epv;
-
-    const int q = lane >> 4, pi = lane & 15;
     // gated layers start their accumulators at the convolution biases (row 4q+i of block b), the others at zero
     f32x4 acc[PG][NB];
 #pragma unroll
@@ -338,25 +378,10 @@ void k_conv3x3(const MpfConvArgs a)
         for (int g = 0; g < PG; ++g) acc[g][b] = init;
     }
 
-    // per-lane LDS byte offset of the tap each k-step reads (tap-packed layers: the tap depends on the lane's k-quarter)
-    int tapoff[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        int slot = ks * TPS + q / VPP;
-        slot = slot > 8 ? 8 : slot;                          // zero weights there; any finite operand will do
-        const int ky = slot / 3, kx = slot - ky * 3;
-        tapoff[ks] = (ky * LW + pi * ST + kx) * PIXB + (q % VPP) * 16;
-    }
-    // weights (host-packed in fragment order, 1 KB per fragment).  WLDS: the chunk's KS x NB fragments go through LDS once
-    // per workgroup - per-wave fragment loads cost as much L1 time as the MFMAs they feed, which is what bounds the
-    // many-chunk / many-block layers; the few-chunk, LDS-hungry layers are better off loading fragments per wave (!WLDS).
-    const u32x4 *wbase = (const u32x4 *)a.wpack + (unsigned)(cg * NB) * 64u;
-    const unsigned wstride = (unsigned)a.nblk * 64u;         // vectors of one k-step in global memory
-
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        if (chunk) __syncthreads();
+        if (chunk || (WALK && pw)) __syncthreads();            // (a walked plane: the previous plane's MFMA reads and parked epilogue rows are done with the tile)
         u32x4 staged[NI];
-        if constexpr (WLDS) {
+        if (WLDS && !(WALK && pw && a.nchunk == 1)) {          // (a walked single-chunk layer: the fragments of the first plane are still there)
             // LDS-DMA (global_load_lds_dwordx4): the fragments are a plain copy (host-packed in fragment order), so they go global ->
             // LDS without passing through registers or ds_write; destination = wave-uniform base + lane * 16, i.e. one 1 KB fragment
             // per wave instruction.  The explicit vmcnt(0) + __syncthreads() below drains it, and the barrier
@@ -451,9 +476,10 @@ void k_conv3x3(const MpfConvArgs a)
         eprows = reinterpret_cast<const float *>(tile);
     }
 #include "mpf_conv_epilogue.inc"
+    }   // planes of this workgroup
 }
 
-template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS>
+template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS, bool WALK = false>
 int launch_w(const MpfConvArgs &a, hipStream_t st)
 {
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, KS = (9 * CT + 31) / 32;
@@ -463,18 +489,25 @@ int launch_w(const MpfConvArgs &a, hipStream_t st)
     static_assert(LDS_BYTES <= 160 * 1024, "tile + weights exceed the LDS of a CU");
     static bool attr_set = false;
     if (!attr_set && LDS_BYTES > 64 * 1024) {
-        MPF_HIP(hipFuncSetAttribute((const void *)k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        MPF_HIP(hipFuncSetAttribute((const void *)k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS, WALK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH, a.S * a.ncg);
-    if (a.plane_major) grid = dim3(a.S * a.ncg, (a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH);
-    hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS>), grid, dim3(256), LDS_BYTES, st, a);
+    const int groups = WALK ? a.S / a.pw : a.S;                // plane groups: a walking workgroup owns a.pw consecutive planes
+    dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH, groups * a.ncg);
+    if (a.plane_major) grid = dim3(groups * a.ncg, (a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH);
+    hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS, WALK>), grid, dim3(256), LDS_BYTES, st, a);
     return mpf_launch_status("k_conv3x3");
 }
 
 template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW>
 int launch(const MpfConvArgs &a, hipStream_t st)
 {
+    if constexpr (NB <= 2) {                                  // the walking form is built for the few-block (full-resolution) layers only
+        if (a.pw > 1) return a.wlds ? launch_w<ST, CT, LOADER, EPI, NB, TH, TW, true, true>(a, st) : launch_w<ST, CT, LOADER, EPI, NB, TH, TW, false, true>(a, st);
+    } else if (a.pw > 1) {
+        mpf_set_error("mpf_conv3x3_f16: planes per workgroup (pw = %d) needs at most 2 blocks per workgroup, got %d", a.pw, NB);
+        return MPF_ERR_UNSUPPORTED;
+    }
     return a.wlds ? launch_w<ST, CT, LOADER, EPI, NB, TH, TW, true>(a, st) : launch_w<ST, CT, LOADER, EPI, NB, TH, TW, false>(a, st);
 }
 
@@ -632,6 +665,7 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     hipStream_t st = (hipStream_t)stream;
     MPF_REQUIRE(a.S > 0 && a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "mpf_conv3x3_f16: bad shape");
     MPF_REQUIRE(a.stride == 1 || a.stride == 2, "mpf_conv3x3_f16: stride must be 1 or 2");
+    MPF_REQUIRE(a.pw >= 0 && (a.pw <= 1 || a.S % a.pw == 0), "mpf_conv3x3_f16: planes per workgroup (pw) must divide S");
     MPF_REQUIRE(a.Hout == (a.Hin - 1) / a.stride + 1 && a.Wout == (a.Win - 1) / a.stride + 1, "mpf_conv3x3_f16: output size does not match a pad-1 3x3 convolution");
     MPF_REQUIRE(a.ct == 8 || a.ct == 16 || a.ct == 32, "mpf_conv3x3_f16: channels per tap must be 8, 16 or 32");
     MPF_REQUIRE(a.nchunk > 0 && a.ncg > 0 && a.nblk > 0 && a.nblk % a.ncg == 0, "mpf_conv3x3_f16: bad block partition");

@@ -49,6 +49,17 @@ _PER_WAVE_LAYERS = {"l2", "l3", "l4"}
 _WLDS_LAYERS = {"l1", "l5", "l6", "l7", "l8", "l9", "up0_4", "up1_4", "up0_3", "up1_3", "up0_2", "up1_2", "up0_1", "up1_1", "up0_0", "up1_0", "disp0"}
 
 
+# planes per workgroup of the few-block full-resolution layers (MpfConvArgs.pw): the workgroup walks that many consecutive planes at its tile position and
+# computes the pixel-only part of the loader once.  MPIFLOW_PW="l8s=2,disp0=4" overrides (tuning aid; 1 = one plane per workgroup).
+_PW_LAYERS = {"l8s": 4, "l9": 4, "up1_0": 4, "disp0": 4}
+
+
+def _pw(layer, S, nb):
+    v = _env_override("MPIFLOW_PW", layer)
+    pw = _PW_LAYERS.get(layer, 1) if v is None else v
+    return pw if pw > 1 and nb <= 2 and S % pw == 0 else 1
+
+
 def _wlds(layer, default):
     """MPIFLOW_WLDS="all" | "none" | "l8,up1_1" overrides the per-layer choice (tuning aid)."""
     v = os.environ.get("MPIFLOW_WLDS")
@@ -231,6 +242,7 @@ class ConvLayer:
         a.loader, a.epi, a.stride, a.pad_mode = self.loader, self.epi, self.stride, self.pad_mode
         a.wlds = int(_wlds(self.name, self.wlds_default))
         a.plane_major = int(self.plane_major)
+        a.pw = _pw(self.name, S, self.nblk // self.ncg)
         self.last_call = dict(S=S, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, HA=a.HA, WA=a.WA)
         if self.loader in (LD_BILINEAR_CAT, LD_BILINEAR_SYNTH):
             a.fparams[0] = (a.HA - 1) / (Hin - 1) if Hin > 1 else 0.0

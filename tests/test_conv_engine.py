@@ -385,6 +385,40 @@ def test_graph_replay_equals_eager():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("S,H,W", [(8, 128, 256), (4, 72, 104)])
+def test_planes_per_workgroup_is_bit_identical(S, H, W, monkeypatch):
+    """MpfConvArgs.pw: a workgroup of a few-block layer walks pw consecutive planes at its tile position (the pixel-only part of the loader once per
+    workgroup, single-chunk weights kept in LDS).  Scheduling only: every walkable layer kind - synthesised / bilinear / direct / per-plane loaders, affine,
+    single-channel, gated and planar epilogues, ragged tiles - reproduces the one-plane-per-workgroup outputs BIT FOR BIT, layer by layer and end to end."""
+    from mpiflow_amd.model.engine import FeatMaskEngine, HipPredictor
+    dev = _gpu()
+    names = ("l2s", "l7", "l8s", "l9", "up0_0", "up1_0", "disp0")
+    m = _model(S, 128, 128, seed=3)
+    g = torch.Generator().manual_seed(11)
+    img, dsp = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 1, H, W, generator=g).to(dev)
+    Hp, Wp = (H + 127) // 128 * 128, (W + 127) // 128 * 128               # the whole forward needs multiples of 128 (the bottleneck's pooling)
+    imgp, dspp = torch.rand(1, 3, Hp, Wp, generator=g).to(dev), torch.rand(1, 1, Hp, Wp, generator=g).to(dev)
+    pd = torch.linspace(1, 0.001, S + 2)[1:-1].to(dev)
+
+    def run(pw):
+        monkeypatch.setenv("MPIFLOW_PW", ",".join("%s=%d" % (n, pw) for n in names))
+        eng = FeatMaskEngine(m.fmn, dev)
+        A1, B1 = eng.first_layer_maps(img[0], dsp[0, 0])
+        c2 = eng.l2s(S, H, W, srcA=A1, srcB=B1, plane_vals=pd)
+        c6 = torch.rand(S, H // 4, W // 4, 64, generator=torch.Generator().manual_seed(5)).to(torch.float16).to(dev)
+        c7 = eng.l7(S, H // 2, W // 2, srcA=c6, srcB=c2, HA=H // 4, WA=W // 4)
+        c8 = eng.l8s(S, H, W, srcA=c7, srcB=A1, cm=B1, plane_vals=pd, HA=H // 2, WA=W // 2)
+        lg = eng.l9(S, H, W, srcA=c8)
+        raw, cum, _ = HipPredictor(m, encoder_dtype=None)(imgp, dspp)
+        return [t.clone() for t in (c2, c7, c8, lg, raw, cum)]
+
+    ref = run(1)
+    for pw in (2, 4):
+        for a, b in zip(ref, run(pw)):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_conv_rejects_unsupported_and_bad_arguments():
     import ctypes
     from mpiflow_amd import _lib
@@ -395,6 +429,9 @@ def test_conv_rejects_unsupported_and_bad_arguments():
     a.S, a.Hin, a.Win, a.Hout, a.Wout, a.stride = 1, 8, 8, 8, 8, 3
     assert lib.mpf_conv3x3_f16(ctypes.byref(a), None) == 10001
     assert b"stride" in lib.mpf_last_error()
+    a.stride, a.ct, a.nchunk, a.nblk, a.ncg, a.S, a.pw = 1, 16, 1, 1, 1, 6, 4        # planes per workgroup must divide S
+    assert lib.mpf_conv3x3_f16(ctypes.byref(a), None) == 10001
+    assert b"pw" in lib.mpf_last_error()
 
 
 # ---- the single-image part in fp32: mpf_conv2d_f32 / mpf_maxpool3x3s2_f32 / mpf_encoder_input ---------------------------------------------

@@ -237,6 +237,15 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
     }
 }
 
+// LDS-DMA issued by assembly: hipcc does not know of the copy, so it neither drains vmcnt in front of the LDS reads that follow (with the builtin it waits
+// for every pending copy before ANY read of the array) nor moves memory operations across it ("memory").  16 bytes per lane to lds_base + lane * 16;
+// lds_base is wave-uniform (an SGPR).  The consumer's wait is an explicit s_waitcnt vmcnt(0) in front of a barrier.
+__device__ __forceinline__ void dma16_async(const void *gptr, unsigned lds_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
+
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
@@ -258,19 +267,23 @@ void k_conv3x3(const MpfConvArgs a)
     constexpr int RH = raw_rows(LH), RW = raw_cols(LW), RAWVEC = RH * RW * VPP, NR = (RAWVEC + 255) / 256;
     constexpr int WL_BYTES = WLDS ? KS * NB * 1024 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char *tile = lds, *wlds = lds + TILE_BYTES;      // input tile | this chunk's A fragments (shared by the 4 waves)
-    unsigned char *raw = lds + TILE_BYTES + WL_BYTES;         // | raw low-resolution tile of the bilinear loader
+    // the walking form keeps TWO buffers of fragments and of the raw tile: the next step's copies are issued in front of this step's MFMA phase (PFB = 2)
+    constexpr int PFB = (WALK && WLDS) ? 2 : 1;
+    unsigned char *tile = lds, *wlds0 = lds + TILE_BYTES;     // input tile | this chunk's A fragments (shared by the 4 waves)
+    unsigned char *raw0 = lds + TILE_BYTES + PFB * WL_BYTES;  // | raw low-resolution tile of the bilinear loader
     // | this workgroup's slice of the epilogue rows, parked at kernel entry: read from global memory in the
     // epilogue, hipcc sinks each block's loads into that block's store branch, i.e. 2 dependent L2 round trips per block with
     // nothing left to overlap them (profiles/r2/engine_epilogue_rows_in_lds.txt)
     constexpr int RAW_BYTES_ = RAW ? RH * RW * VPP * 16 : 0;
-    float *eplds = reinterpret_cast<float *>(lds + TILE_BYTES + WL_BYTES + RAW_BYTES_);
+    float *eplds = reinterpret_cast<float *>(lds + TILE_BYTES + PFB * (WL_BYTES + RAW_BYTES_));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // plane_major: the plane index is the FASTEST grid dimension, so the S workgroups of one tile are dispatched back to back (8 per XCD) and find the
     // per-image sources they share (LD_FMN_SYNTH / LD_BILINEAR_SYNTH: the A', B' maps) in that XCD's L2 instead of re-fetching them per plane
     const unsigned bx = a.plane_major ? blockIdx.y : blockIdx.x, by = a.plane_major ? blockIdx.z : blockIdx.y, bz = a.plane_major ? blockIdx.x : blockIdx.z;
-    const int npw = WALK ? a.pw : 1;
+    const int npw = WALK ? (a.pw & 0xffff) : 1;
+    const bool pf = PFB == 2 && (a.pw >> 16) != 0 && a.nchunk > 1;      // prefetch the next step's fragments / raw tile (launcher: mpf_tune("conv_pf"))
+    int step = 0;                                             // (plane, chunk) steps this workgroup has started
     const int sgrp = (int)bz / a.ncg, cg = (int)bz - sgrp * a.ncg;
     int s = sgrp * npw;                                       // first plane of this workgroup
     // affine epilogues use rows 0, 1 of all NB blocks; the gated one rows 1, 2 of its NB/2 feature blocks; the planar one none.
@@ -278,7 +291,7 @@ void k_conv3x3(const MpfConvArgs a)
     // that costs no resident workgroup (EPW > 0), else in the input tile's space once the last MFMA phase is over.
     constexpr bool EP_GATED = EPI == EP_GATED_ELU || EPI == EP_GATED_PLANAR_F32 || EPI == EP_GATED_PLANAR_F32_PAIRED || EPI == EP_GATED_ELU_PAIRED;
     constexpr int EPN = (EPI == EP_GATED_PLANAR_F32 || EPI == EP_GATED_PLANAR_F32_PAIRED) ? 0 : EPI == EP_GATED_ELU_PAIRED ? NB * 8 : (EPI == EP_GATED_ELU ? (NB / 2) * 16 : NB * 16);
-    constexpr int EPW = ep_lds_floats(EPI, NB, TILE_BYTES + WL_BYTES + RAW_BYTES_) / 2;
+    constexpr int EPW = ep_lds_floats(EPI, NB, TILE_BYTES + PFB * (WL_BYTES + RAW_BYTES_)) / 2;
     static_assert(2 * EPN <= 256 && 2 * EPN * 4 <= TILE_BYTES, "one epilogue value per thread");
     float epv = 0.f;
     if (tid < 2 * EPN) {
@@ -378,10 +391,14 @@ void k_conv3x3(const MpfConvArgs a)
         for (int g = 0; g < PG; ++g) acc[g][b] = init;
     }
 
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    for (int chunk = 0; chunk < a.nchunk; ++chunk, ++step) {
+        const bool fetched = pf && step > 0;                   // this step's copies were issued in front of the previous step's MFMA phase
+        unsigned char *wlds = wlds0 + (pf ? (step & 1) * WL_BYTES : 0), *raw = raw0 + (pf ? (step & 1) * RAW_BYTES_ : 0);
+        const bool rawchunk = RAW && (unsigned)(chunk * VPP) < ((unsigned)a.CA >> 3);       // uniform: a chunk of the upsampled source
+        if (fetched && rawchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prefetched raw tile: the issuing wave's wait, in front of the barrier
         if (chunk || (WALK && pw)) __syncthreads();            // (a walked plane: the previous plane's MFMA reads and parked epilogue rows are done with the tile)
         u32x4 staged[NI];
-        if (WLDS && !(WALK && pw && a.nchunk == 1)) {          // (a walked single-chunk layer: the fragments of the first plane are still there)
+        if (WLDS && !fetched && !(WALK && pw && a.nchunk == 1)) {   // (a walked single-chunk layer: the fragments of the first plane are still there)
             // LDS-DMA (global_load_lds_dwordx4): the fragments are a plain copy (host-packed in fragment order), so they go global ->
             // LDS without passing through registers or ds_write; destination = wave-uniform base + lane * 16, i.e. one 1 KB fragment
             // per wave instruction.  The explicit vmcnt(0) + __syncthreads() below drains it, and the barrier
@@ -400,7 +417,7 @@ void k_conv3x3(const MpfConvArgs a)
             }
         }
         if constexpr (RAW) {
-            if ((unsigned)(chunk * VPP) < ((unsigned)a.CA >> 3)) {              // uniform: a chunk of the upsampled source
+            if (rawchunk && !fetched) {
 #pragma unroll
                 for (int k = 0; k < NR; ++k)                                    // also a plain copy: LDS-DMA, lane-linear destination
                     if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC)
@@ -413,7 +430,7 @@ void k_conv3x3(const MpfConvArgs a)
         if constexpr (RAW) {
             // the source of a chunk (upsampled A from the raw tile / skip tensor B) is uniform: branch ONCE around the NI passes, so that
             // the B loads of all passes are in flight together (inside stage_load each pass had its own branch and its own wait)
-            if ((unsigned)(chunk * VPP) < ((unsigned)a.CA >> 3)) {
+            if (rawchunk) {
 #pragma unroll
                 for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv, raw, VPP * 16, RW * VPP * 16);
             } else {
@@ -441,6 +458,33 @@ void k_conv3x3(const MpfConvArgs a)
         // MPF_COPY_BARRIER) - the fragment copies above are issued under one (vb < WVEC) - so the wait is explicit here too (it was already emitted: no change in time).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (PFB == 2) {
+            // The next step's plain copies - its fragments, and its raw tile when it is a chunk of the upsampled source - go into the OTHER buffers now and land
+            // during this step's MFMA phase: buffer (step + 1) & 1 was last read in step - 1 (fragments: its MFMA phase, raw tile: its staging), and every wave
+            // has passed this step's barriers since.  Issued by assembly (dma16_async) so that hipcc does not put a vmcnt(0) in front of the MFMA phase's reads.
+            const int nchunk_n = chunk + 1 < a.nchunk ? chunk + 1 : 0;
+            if (pf && (chunk + 1 < a.nchunk || pw + 1 < npw)) {
+                const unsigned nb_w = lds_addr(wlds0 + ((step + 1) & 1) * WL_BYTES), nb_r = lds_addr(raw0 + ((step + 1) & 1) * RAW_BYTES_);
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    const unsigned vb = (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 64 + j * 256);
+                    if (NW * 256 == WVEC || vb < WVEC) {
+                        const unsigned v = vb + (unsigned)lane;
+                        const unsigned ks = v / (NB * 64), r = v - ks * (NB * 64);
+                        dma16_async(wbase + ((unsigned)(nchunk_n * KS + ks) * wstride + r), nb_w + vb * 16);
+                    }
+                }
+                if constexpr (RAW) {
+                    if ((unsigned)(nchunk_n * VPP) < ((unsigned)a.CA >> 3)) {
+                        const unsigned dr = nchunk_n ? 0u : (unsigned)(a.HA * a.WA) * ((unsigned)a.CA >> 3);      // chunk 0 of the NEXT plane
+#pragma unroll
+                        for (int k = 0; k < NR; ++k)
+                            if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC)
+                                dma16_async((const u32x4 *)a.srcA + (rawsrc[k] + dr + (unsigned)(nchunk_n * VPP)), nb_r + (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 64 + k * 256) * 16);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             h8 af[NB];
@@ -479,12 +523,15 @@ void k_conv3x3(const MpfConvArgs a)
     }   // planes of this workgroup
 }
 
+int g_conv_pf = 1;                // mpf_tune("conv_pf", 0 | 1): the walking kernels prefetch the next step's fragments / raw tile (scheduling only, same results)
+
 template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS, bool WALK = false>
 int launch_w(const MpfConvArgs &a, hipStream_t st)
 {
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, KS = (9 * CT + 31) / 32;
     constexpr int RAW_BYTES = is_bilinear(LOADER) ? raw_rows(LH) * raw_cols(LW) * (CT / 8) * 16 : 0;
-    constexpr int LDS_OTHER = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + (WLDS ? KS * NB * 1024 : 0) + RAW_BYTES;
+    constexpr int PFB = (WALK && WLDS) ? 2 : 1;                // the walking form double-buffers the fragments and the raw tile (prefetch)
+    constexpr int LDS_OTHER = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + PFB * ((WLDS ? KS * NB * 1024 : 0) + RAW_BYTES);
     constexpr int LDS_BYTES = LDS_OTHER + ep_lds_floats(EPI, NB, LDS_OTHER) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "tile + weights exceed the LDS of a CU");
     static bool attr_set = false;
@@ -495,7 +542,9 @@ int launch_w(const MpfConvArgs &a, hipStream_t st)
     const int groups = WALK ? a.S / a.pw : a.S;                // plane groups: a walking workgroup owns a.pw consecutive planes
     dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH, groups * a.ncg);
     if (a.plane_major) grid = dim3(groups * a.ncg, (a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH);
-    hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS, WALK>), grid, dim3(256), LDS_BYTES, st, a);
+    MpfConvArgs b = a;
+    if (WALK) b.pw = (a.pw & 0xffff) | (g_conv_pf ? 0x10000 : 0);      // bit 16: prefetch the next step's copies (kernel-internal encoding)
+    hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS, WALK>), grid, dim3(256), LDS_BYTES, st, b);
     return mpf_launch_status("k_conv3x3");
 }
 
@@ -646,6 +695,8 @@ __global__ __launch_bounds__(1024) void k_plane_masks(const float *__restrict__ 
 
 }  // namespace
 
+void mpf_conv_set_prefetch(int v) { g_conv_pf = v != 0; }          // mpf_tune("conv_pf", v) (mpf_render.hip)
+
 extern "C" int mpf_plane_masks(const float *d_logits, int S, int H, int W, float *d_feature_mask, float *d_cum_mask, float *const *d_cm,
                                float *const *d_fm, void *stream)
 {
@@ -665,7 +716,7 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     hipStream_t st = (hipStream_t)stream;
     MPF_REQUIRE(a.S > 0 && a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "mpf_conv3x3_f16: bad shape");
     MPF_REQUIRE(a.stride == 1 || a.stride == 2, "mpf_conv3x3_f16: stride must be 1 or 2");
-    MPF_REQUIRE(a.pw >= 0 && (a.pw <= 1 || a.S % a.pw == 0), "mpf_conv3x3_f16: planes per workgroup (pw) must divide S");
+    MPF_REQUIRE(a.pw >= 0 && a.pw < 0x10000 && (a.pw <= 1 || a.S % a.pw == 0), "mpf_conv3x3_f16: planes per workgroup (pw) must divide S");
     MPF_REQUIRE(a.Hout == (a.Hin - 1) / a.stride + 1 && a.Wout == (a.Win - 1) / a.stride + 1, "mpf_conv3x3_f16: output size does not match a pad-1 3x3 convolution");
     MPF_REQUIRE(a.ct == 8 || a.ct == 16 || a.ct == 32, "mpf_conv3x3_f16: channels per tap must be 8, 16 or 32");
     MPF_REQUIRE(a.nchunk > 0 && a.ncg > 0 && a.nblk > 0 && a.nblk % a.ncg == 0, "mpf_conv3x3_f16: bad block partition");

@@ -51,7 +51,7 @@ _WLDS_LAYERS = {"l1", "l5", "l6", "l7", "l8", "l9", "up0_4", "up1_4", "up0_3", "
 
 # planes per workgroup of the few-block full-resolution layers (MpfConvArgs.pw): the workgroup walks that many consecutive planes at its tile position and
 # computes the pixel-only part of the loader once.  MPIFLOW_PW="l8s=2,disp0=4" overrides (tuning aid; 1 = one plane per workgroup).
-_PW_LAYERS = {"l8s": 4, "l9": 4, "up1_0": 4, "disp0": 4}
+_PW_LAYERS = {"l7": 4, "l8s": 4, "l9": 4, "up0_0": 4, "up1_0": 4, "disp0": 4}
 
 
 def _pw(layer, S, nb):

@@ -412,10 +412,16 @@ def test_planes_per_workgroup_is_bit_identical(S, H, W, monkeypatch):
         raw, cum, _ = HipPredictor(m, encoder_dtype=None)(imgp, dspp)
         return [t.clone() for t in (c2, c7, c8, lg, raw, cum)]
 
+    from mpiflow_amd import _lib
     ref = run(1)
-    for pw in (2, 4):
-        for a, b in zip(ref, run(pw)):
-            assert torch.equal(a, b)
+    try:
+        for pf in (1, 0):                                      # the walking kernels' prefetch of the next step's copies (mpf_tune("conv_pf")) on / off
+            assert _lib.load().mpf_tune(b"conv_pf", pf) == 0
+            for pw in (2, 4):
+                for a, b in zip(ref, run(pw)):
+                    assert torch.equal(a, b)
+    finally:
+        _lib.load().mpf_tune(b"conv_pf", 1)
 
 
 @pytest.mark.gpu

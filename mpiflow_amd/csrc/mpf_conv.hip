@@ -30,6 +30,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// Timing ablations of the conv kernels (tools/build_ablate_conv.sh builds SEPARATE libraries with -DMPF_CONV_ABLATE=<bits>; results INVALID), compile-time so that
+// the code around the removed part is scheduled as in the shipped kernel: 2 no MFMAs, 4 loader arithmetic replaced by a copy of one tap / one map, 8 no barriers
+// in the chunk loop, 16 no global -> LDS copies (fragments, raw tile).  In the shipped build ABL() is constant false.
+#ifdef MPF_CONV_ABLATE
+#define ABL(bit) (((MPF_CONV_ABLATE) & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
 namespace {
 
 constexpr int LD_FMN_INPUT = MPF_CONV_LD_FMN_INPUT;
@@ -181,7 +190,7 @@ __device__ __forceinline__ u32x4 synth_c1(const float *__restrict__ A, const flo
 // divergent branches (clamped addresses + selects) so that the loads of all NI passes of a chunk can be in flight together.
 template <int LOADER, int VPP>
 __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfConvArgs &a, int s, int chunk, int sv, const unsigned char *raw = nullptr,
-                                            int raw_dx = 0, int raw_dy = 0)
+                                            int raw_dx = 0, int raw_dy = 0, bool cheap = false)
 {
     const unsigned vv = (unsigned)(chunk * VPP + sv);
     if constexpr (LOADER == LD_FMN_INPUT) {
@@ -200,6 +209,7 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
         const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3;       // va % VPP == 0 (checked by the launcher)
         if ((unsigned)(chunk * VPP) < va) {                                       // uniform: the whole chunk is source A
             const unsigned char *p = raw + st.ia;
+            if (cheap) return select4(st.ok, *reinterpret_cast<const u32x4 *>(p));      // (ablation build only)
             const u32x4 r00 = *reinterpret_cast<const u32x4 *>(p), r01 = *reinterpret_cast<const u32x4 *>(p + raw_dx);
             const u32x4 r10 = *reinterpret_cast<const u32x4 *>(p + raw_dy), r11 = *reinterpret_cast<const u32x4 *>(p + raw_dy + raw_dx);
             u32x4 o;
@@ -254,7 +264,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 // layer - is computed once per workgroup instead of once per plane; per plane only the sources' plane offsets advance.  Same arithmetic per output.
 template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS, bool WALK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB <= 2 ? 3 : (NB <= 6 ? 2 : 1))))
-void k_conv3x3(const MpfConvArgs a)
+void k_conv3x3(const MpfConvArgs a, const int prefetch)
 {
     constexpr int GROUPS = TH * TW / 16, PG = GROUPS / 4, GPR = TW / 16;
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, PIXB = pix_stride_bytes(CT, ST), VPP = CT / 8;
@@ -281,8 +291,8 @@ void k_conv3x3(const MpfConvArgs a)
     // plane_major: the plane index is the FASTEST grid dimension, so the S workgroups of one tile are dispatched back to back (8 per XCD) and find the
     // per-image sources they share (LD_FMN_SYNTH / LD_BILINEAR_SYNTH: the A', B' maps) in that XCD's L2 instead of re-fetching them per plane
     const unsigned bx = a.plane_major ? blockIdx.y : blockIdx.x, by = a.plane_major ? blockIdx.z : blockIdx.y, bz = a.plane_major ? blockIdx.x : blockIdx.z;
-    const int npw = WALK ? (a.pw & 0xffff) : 1;
-    const bool pf = PFB == 2 && (a.pw >> 16) != 0 && a.nchunk > 1;      // prefetch the next step's fragments / raw tile (launcher: mpf_tune("conv_pf"))
+    const int npw = WALK ? a.pw : 1;
+    const bool pf = PFB == 2 && prefetch != 0 && a.nchunk > 1;          // prefetch the next step's fragments / raw tile (launcher: mpf_tune("conv_pf"))
     int step = 0;                                             // (plane, chunk) steps this workgroup has started
     const int sgrp = (int)bz / a.ncg, cg = (int)bz - sgrp * a.ncg;
     int s = sgrp * npw;                                       // first plane of this workgroup
@@ -396,9 +406,9 @@ void k_conv3x3(const MpfConvArgs a)
         unsigned char *wlds = wlds0 + (pf ? (step & 1) * WL_BYTES : 0), *raw = raw0 + (pf ? (step & 1) * RAW_BYTES_ : 0);
         const bool rawchunk = RAW && (unsigned)(chunk * VPP) < ((unsigned)a.CA >> 3);       // uniform: a chunk of the upsampled source
         if (fetched && rawchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prefetched raw tile: the issuing wave's wait, in front of the barrier
-        if (chunk || (WALK && pw)) __syncthreads();            // (a walked plane: the previous plane's MFMA reads and parked epilogue rows are done with the tile)
+        if ((chunk || (WALK && pw)) && !ABL(8)) __syncthreads();  // (a walked plane: the previous plane's MFMA reads and parked epilogue rows are done with the tile)
         u32x4 staged[NI];
-        if (WLDS && !fetched && !(WALK && pw && a.nchunk == 1)) {   // (a walked single-chunk layer: the fragments of the first plane are still there)
+        if (WLDS && !fetched && !(WALK && pw && a.nchunk == 1) && !ABL(16)) {   // (a walked single-chunk layer: the fragments of the first plane are still there)
             // LDS-DMA (global_load_lds_dwordx4): the fragments are a plain copy (host-packed in fragment order), so they go global ->
             // LDS without passing through registers or ds_write; destination = wave-uniform base + lane * 16, i.e. one 1 KB fragment
             // per wave instruction.  The explicit vmcnt(0) + __syncthreads() below drains it, and the barrier
@@ -417,14 +427,14 @@ void k_conv3x3(const MpfConvArgs a)
             }
         }
         if constexpr (RAW) {
-            if (rawchunk && !fetched) {
+            if (rawchunk && !fetched && !ABL(16)) {
 #pragma unroll
                 for (int k = 0; k < NR; ++k)                                    // also a plain copy: LDS-DMA, lane-linear destination
                     if (NR * 256 == RAWVEC || tid + k * 256 < RAWVEC)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const u32x4 *)a.srcA + (rawsrc[k] + (unsigned)(chunk * VPP))),
                                                          (__attribute__((address_space(3))) void *)(raw + (__builtin_amdgcn_readfirstlane(wave) * 64 + k * 256) * 16), 16, 0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the raw tile's LDS-DMA: the issuing wave's wait, spelled out (see below)
-                __syncthreads();
+                if (!ABL(8)) __syncthreads();
             }
         }
         if constexpr (RAW) {
@@ -432,13 +442,13 @@ void k_conv3x3(const MpfConvArgs a)
             // the B loads of all passes are in flight together (inside stage_load each pass had its own branch and its own wait)
             if (rawchunk) {
 #pragma unroll
-                for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv, raw, VPP * 16, RW * VPP * 16);
+                for (int k = 0; k < NI; ++k) staged[k] = stage_load<LOADER, VPP>(stage[k], a, s, chunk, sv, raw, VPP * 16, RW * VPP * 16, ABL(4));
             } else {
                 const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3, vq = (unsigned)(chunk * VPP + sv) - va, vc = vq < vb ? vq : vb - 1;
                 u32x4 ld[NI];
 #pragma unroll
                 for (int k = 0; k < NI; ++k) {
-                    if constexpr (LOADER == LD_BILINEAR_SYNTH) ld[k] = synth_c1((const float *)a.srcB, a.cm, stage[k].ib, vc, a.plane_vals[s]);
+                    if constexpr (LOADER == LD_BILINEAR_SYNTH) ld[k] = ABL(4) ? ((const u32x4 *)a.srcB)[(size_t)stage[k].ib * 4 + vc] : synth_c1((const float *)a.srcB, a.cm, stage[k].ib, vc, a.plane_vals[s]);
                     else ld[k] = ((const u32x4 *)a.srcB)[(size_t)stage[k].ib * vb + vc];
                 }
 #pragma unroll
@@ -457,13 +467,13 @@ void k_conv3x3(const MpfConvArgs a)
         // where the compiler believes a copy is pending; round 5 found it losing track of a copy issued under a wave-dependent condition (mpf_pconv.hip,
         // MPF_COPY_BARRIER) - the fragment copies above are issued under one (vb < WVEC) - so the wait is explicit here too (it was already emitted: no change in time).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!ABL(8)) __syncthreads();
         if constexpr (PFB == 2) {
             // The next step's plain copies - its fragments, and its raw tile when it is a chunk of the upsampled source - go into the OTHER buffers now and land
             // during this step's MFMA phase: buffer (step + 1) & 1 was last read in step - 1 (fragments: its MFMA phase, raw tile: its staging), and every wave
             // has passed this step's barriers since.  Issued by assembly (dma16_async) so that hipcc does not put a vmcnt(0) in front of the MFMA phase's reads.
             const int nchunk_n = chunk + 1 < a.nchunk ? chunk + 1 : 0;
-            if (pf && (chunk + 1 < a.nchunk || pw + 1 < npw)) {
+            if (pf && (chunk + 1 < a.nchunk || pw + 1 < npw) && !ABL(16)) {
                 const unsigned nb_w = lds_addr(wlds0 + ((step + 1) & 1) * WL_BYTES), nb_r = lds_addr(raw0 + ((step + 1) & 1) * RAW_BYTES_);
 #pragma unroll
                 for (int j = 0; j < NW; ++j) {
@@ -507,7 +517,8 @@ void k_conv3x3(const MpfConvArgs a)
 #endif
                 h8 bf = *reinterpret_cast<h8 *>(&bv);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[b], bf, acc[g][b], 0, 0, 0);
+                for (int b = 0; b < NB; ++b)
+                    if (!ABL(2)) acc[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[b], bf, acc[g][b], 0, 0, 0);
             }
         }
     }
@@ -542,9 +553,7 @@ int launch_w(const MpfConvArgs &a, hipStream_t st)
     const int groups = WALK ? a.S / a.pw : a.S;                // plane groups: a walking workgroup owns a.pw consecutive planes
     dim3 grid((a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH, groups * a.ncg);
     if (a.plane_major) grid = dim3(groups * a.ncg, (a.Wout + TW - 1) / TW, (a.Hout + TH - 1) / TH);
-    MpfConvArgs b = a;
-    if (WALK) b.pw = (a.pw & 0xffff) | (g_conv_pf ? 0x10000 : 0);      // bit 16: prefetch the next step's copies (kernel-internal encoding)
-    hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS, WALK>), grid, dim3(256), LDS_BYTES, st, b);
+    hipLaunchKernelGGL((k_conv3x3<ST, CT, LOADER, EPI, NB, TH, TW, WLDS, WALK>), grid, dim3(256), LDS_BYTES, st, a, g_conv_pf);
     return mpf_launch_status("k_conv3x3");
 }
 
@@ -716,7 +725,7 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     hipStream_t st = (hipStream_t)stream;
     MPF_REQUIRE(a.S > 0 && a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "mpf_conv3x3_f16: bad shape");
     MPF_REQUIRE(a.stride == 1 || a.stride == 2, "mpf_conv3x3_f16: stride must be 1 or 2");
-    MPF_REQUIRE(a.pw >= 0 && a.pw < 0x10000 && (a.pw <= 1 || a.S % a.pw == 0), "mpf_conv3x3_f16: planes per workgroup (pw) must divide S");
+    MPF_REQUIRE(a.pw >= 0 && (a.pw <= 1 || a.S % a.pw == 0), "mpf_conv3x3_f16: planes per workgroup (pw) must divide S");
     MPF_REQUIRE(a.Hout == (a.Hin - 1) / a.stride + 1 && a.Wout == (a.Win - 1) / a.stride + 1, "mpf_conv3x3_f16: output size does not match a pad-1 3x3 convolution");
     MPF_REQUIRE(a.ct == 8 || a.ct == 16 || a.ct == 32, "mpf_conv3x3_f16: channels per tap must be 8, 16 or 32");
     MPF_REQUIRE(a.nchunk > 0 && a.ncg > 0 && a.nblk > 0 && a.nblk % a.ncg == 0, "mpf_conv3x3_f16: bad block partition");

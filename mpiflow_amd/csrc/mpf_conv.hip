@@ -279,13 +279,15 @@ void k_conv3x3(const MpfConvArgs a, const int prefetch)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // the walking form keeps TWO buffers of fragments and of the raw tile: the next step's copies are issued in front of this step's MFMA phase (PFB = 2)
     constexpr int PFB = (WALK && WLDS) ? 2 : 1;
+    // (the one-block bilinear layer prefetches its raw tile only: with ONE 5 KB buffer of fragments, copied at the head of each step, l8s runs 0.905 ms against 0.925)
+    constexpr int PFW = (NB == 1 && is_bilinear(LOADER)) ? 1 : PFB;      // buffers of fragments
     unsigned char *tile = lds, *wlds0 = lds + TILE_BYTES;     // input tile | this chunk's A fragments (shared by the 4 waves)
-    unsigned char *raw0 = lds + TILE_BYTES + PFB * WL_BYTES;  // | raw low-resolution tile of the bilinear loader
+    unsigned char *raw0 = lds + TILE_BYTES + PFW * WL_BYTES;  // | raw low-resolution tile of the bilinear loader
     // | this workgroup's slice of the epilogue rows, parked at kernel entry: read from global memory in the
     // epilogue, hipcc sinks each block's loads into that block's store branch, i.e. 2 dependent L2 round trips per block with
     // nothing left to overlap them (profiles/r2/engine_epilogue_rows_in_lds.txt)
     constexpr int RAW_BYTES_ = RAW ? RH * RW * VPP * 16 : 0;
-    float *eplds = reinterpret_cast<float *>(lds + TILE_BYTES + PFB * (WL_BYTES + RAW_BYTES_));
+    float *eplds = reinterpret_cast<float *>(lds + TILE_BYTES + PFW * WL_BYTES + PFB * RAW_BYTES_);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // plane_major: the plane index is the FASTEST grid dimension, so the S workgroups of one tile are dispatched back to back (8 per XCD) and find the
@@ -301,7 +303,7 @@ void k_conv3x3(const MpfConvArgs a, const int prefetch)
     // that costs no resident workgroup (EPW > 0), else in the input tile's space once the last MFMA phase is over.
     constexpr bool EP_GATED = EPI == EP_GATED_ELU || EPI == EP_GATED_PLANAR_F32 || EPI == EP_GATED_PLANAR_F32_PAIRED || EPI == EP_GATED_ELU_PAIRED;
     constexpr int EPN = (EPI == EP_GATED_PLANAR_F32 || EPI == EP_GATED_PLANAR_F32_PAIRED) ? 0 : EPI == EP_GATED_ELU_PAIRED ? NB * 8 : (EPI == EP_GATED_ELU ? (NB / 2) * 16 : NB * 16);
-    constexpr int EPW = ep_lds_floats(EPI, NB, TILE_BYTES + PFB * (WL_BYTES + RAW_BYTES_)) / 2;
+    constexpr int EPW = ep_lds_floats(EPI, NB, TILE_BYTES + PFW * WL_BYTES + PFB * RAW_BYTES_) / 2;
     static_assert(2 * EPN <= 256 && 2 * EPN * 4 <= TILE_BYTES, "one epilogue value per thread");
     float epv = 0.f;
     if (tid < 2 * EPN) {
@@ -403,12 +405,12 @@ void k_conv3x3(const MpfConvArgs a, const int prefetch)
 
     for (int chunk = 0; chunk < a.nchunk; ++chunk, ++step) {
         const bool fetched = pf && step > 0;                   // this step's copies were issued in front of the previous step's MFMA phase
-        unsigned char *wlds = wlds0 + (pf ? (step & 1) * WL_BYTES : 0), *raw = raw0 + (pf ? (step & 1) * RAW_BYTES_ : 0);
+        unsigned char *wlds = wlds0 + (pf && PFW == 2 ? (step & 1) * WL_BYTES : 0), *raw = raw0 + (pf ? (step & 1) * RAW_BYTES_ : 0);
         const bool rawchunk = RAW && (unsigned)(chunk * VPP) < ((unsigned)a.CA >> 3);       // uniform: a chunk of the upsampled source
         if (fetched && rawchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prefetched raw tile: the issuing wave's wait, in front of the barrier
         if ((chunk || (WALK && pw)) && !ABL(8)) __syncthreads();  // (a walked plane: the previous plane's MFMA reads and parked epilogue rows are done with the tile)
         u32x4 staged[NI];
-        if (WLDS && !fetched && !(WALK && pw && a.nchunk == 1) && !ABL(16)) {   // (a walked single-chunk layer: the fragments of the first plane are still there)
+        if (WLDS && !(fetched && PFW == 2) && !(WALK && pw && a.nchunk == 1) && !ABL(16)) {   // (a walked single-chunk layer: the fragments of the first plane are still there)
             // LDS-DMA (global_load_lds_dwordx4): the fragments are a plain copy (host-packed in fragment order), so they go global ->
             // LDS without passing through registers or ds_write; destination = wave-uniform base + lane * 16, i.e. one 1 KB fragment
             // per wave instruction.  The explicit vmcnt(0) + __syncthreads() below drains it, and the barrier
@@ -478,7 +480,7 @@ void k_conv3x3(const MpfConvArgs a, const int prefetch)
 #pragma unroll
                 for (int j = 0; j < NW; ++j) {
                     const unsigned vb = (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 64 + j * 256);
-                    if (NW * 256 == WVEC || vb < WVEC) {
+                    if ((NW * 256 == WVEC || vb < WVEC) && PFW == 2) {
                         const unsigned v = vb + (unsigned)lane;
                         const unsigned ks = v / (NB * 64), r = v - ks * (NB * 64);
                         dma16_async(wbase + ((unsigned)(nchunk_n * KS + ks) * wstride + r), nb_w + vb * 16);
@@ -542,7 +544,8 @@ int launch_w(const MpfConvArgs &a, hipStream_t st)
     constexpr int LW = TW * ST + 2, LH = TH * ST + 2, KS = (9 * CT + 31) / 32;
     constexpr int RAW_BYTES = is_bilinear(LOADER) ? raw_rows(LH) * raw_cols(LW) * (CT / 8) * 16 : 0;
     constexpr int PFB = (WALK && WLDS) ? 2 : 1;                // the walking form double-buffers the fragments and the raw tile (prefetch)
-    constexpr int LDS_OTHER = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + PFB * ((WLDS ? KS * NB * 1024 : 0) + RAW_BYTES);
+    constexpr int PFW = (NB == 1 && is_bilinear(LOADER)) ? 1 : PFB;
+    constexpr int LDS_OTHER = (LH * LW * pix_stride_bytes(CT, ST) + 255) / 256 * 256 + PFW * (WLDS ? KS * NB * 1024 : 0) + PFB * RAW_BYTES;
     constexpr int LDS_BYTES = LDS_OTHER + ep_lds_floats(EPI, NB, LDS_OTHER) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "tile + weights exceed the LDS of a CU");
     static bool attr_set = false;

@@ -36,7 +36,7 @@ extern "C" {
                              mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6;
                              round 5 (501): + the parity-grade producer engine mpf_pconv, mpf_pfmn_input, mpf_pencoder_input, mpf_pbilinear2x, mpf_pper_plane,
                              mpf_pplane_masks, mpf_pmaxpool3x3s2; MpfMergeArgs + obj_mask_stride, mpf_merge_ex, mpf_src_flow_hard;
-                             (503): MpfConvArgs + pw (planes per workgroup of the few-block layers) */
+                             (503): MpfConvArgs + bprime_table, pw (planes per workgroup of the few-block layers) */
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)
@@ -376,6 +376,8 @@ typedef struct MpfConvArgs {
                                          layers), 0: every wave loads its fragments from global memory (tuning choice, same results) */
     int plane_major;                  /* 1: the plane index is the fastest grid dimension (the S workgroups of a tile back to back: per-image sources
                                          shared by the planes stay in L2); scheduling only, same results */
+    int bprime_table;                 /* LD_FMN_SYNTH / LD_BILINEAR_SYNTH: 1 = B' (srcB / cm) is the [3][3][16] table of its border classes (top / inner / bottom row x
+                                         left / inner / right column: B' depends on the pixel only through which taps fall inside the image), 0 = an [Hin,Win,16] map */
     int pw;                           /* planes per workgroup (0 / 1: one): a workgroup walks pw consecutive planes at its tile position and computes what depends
                                          on the pixel only once (nblk / ncg <= 2 only; S % pw == 0); scheduling only, same results */
 } MpfConvArgs;

@@ -33,7 +33,7 @@ class MpfConvArgs(ctypes.Structure):
                 ("CA", c_i), ("CB", c_i), ("HA", c_i), ("WA", c_i),
                 ("ct", c_i), ("nchunk", c_i), ("nblk", c_i), ("ncg", c_i), ("Cst", c_i),
                 ("loader", c_i), ("epi", c_i), ("stride", c_i), ("pad_mode", c_i),
-                ("fparams", c_f * 4), ("wlds", c_i), ("plane_major", c_i), ("pw", c_i)]
+                ("fparams", c_f * 4), ("wlds", c_i), ("plane_major", c_i), ("bprime_table", c_i), ("pw", c_i)]
 
 
 class MpfConv2dArgs(ctypes.Structure):

@@ -147,8 +147,14 @@ __device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs 
     st.ok = in_tile && (reflect || (y >= 0 && y < a.Hin && x >= 0 && x < a.Win));
     y = reflect_or_clamp(y, a.Hin, reflect);
     x = reflect_or_clamp(x, a.Win, reflect);
+    // B' of the factorised first layer (the plane channel's share, BatchNorm-scale * conv(0, 0, 0, 0, 1)) depends on the pixel only through WHICH of the nine taps fall
+    // inside the image: one of 3 x 3 border classes (top / inner / bottom row x left / inner / right column).  bprime_table: B' is that [3][3][16] table instead
+    // of an [H, W, 16] map - the same values bit for bit, read from L1 instead of 64 bytes per pixel and plane from L2 (layer 2 is bound by its L2 requests: 9 GB at
+    // 25 TB/s; profiles/r5/engine_l2_requests.txt).  The bilinear layer keeps the class in the top bits of its pixel index: a field of its own cost registers
+    [[maybe_unused]] const unsigned bcls = (unsigned)((y == 0 ? 0 : (y == a.Hin - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == a.Win - 1 ? 2 : 1)));
     if constexpr (LOADER == LD_FMN_INPUT || LOADER == LD_FMN_SYNTH) {
         st.ia = (unsigned)(y * a.Win + x);
+        if constexpr (LOADER == LD_FMN_SYNTH) st.ib = a.bprime_table ? bcls : st.ia;
     } else if constexpr (LOADER == LD_DIRECT) {
         st.ia = (unsigned)((s * a.Hin + y) * a.Win + x);
     } else if constexpr (is_bilinear(LOADER)) {
@@ -162,6 +168,7 @@ __device__ __forceinline__ void stage_init(Stage<LOADER> &st, const MpfConvArgs 
         st.ia = (unsigned)((((y0 - ry0) * raw_pitch + (x0 - rx0)) * vpp + sv) * 16);
         st.w00 = hy * hx, st.w01 = hy * lx, st.w10 = ly * hx, st.w11 = ly * lx;
         st.ib = LOADER == LD_BILINEAR_SYNTH ? (unsigned)(y * a.Win + x) : (unsigned)((s * a.Hin + y) * a.Win + x);
+        if constexpr (LOADER == LD_BILINEAR_SYNTH) st.ib |= bcls << 28;      // pixel index into A' (bits 0..27: H * W < 2^27, checked by the launcher) | border class
     } else {
         const int ya = a.HA == a.Hin ? y : (y >> 1), xa = a.HA == a.Hin ? x : (x >> 1);
         st.ia = (unsigned)((s * a.HA + ya) * a.WA + xa);
@@ -177,9 +184,9 @@ __device__ __forceinline__ u32x4 select4(bool c, const u32x4 &v) { return u32x4{
 // channel d_s, and the layer is affine in it up to the ReLU - c1[s] = relu(A' + d_s * B') with A' = BN(conv(r, g, b, disparity, 0)) per image and
 // B' = BN-scale * conv(0, 0, 0, 0, 1) per size, both fp32 [H,W,16].  The consumers of c1 (layer 2, and layer 8's skip input) synthesise the 8
 // channels of vector v of pixel `pix` here: same fp32 value the layer-1 launch would have rounded to fp16 (up to the order of two roundings).
-__device__ __forceinline__ u32x4 synth_c1(const float *__restrict__ A, const float *__restrict__ B, unsigned pix, unsigned v, float d)
+__device__ __forceinline__ u32x4 synth_c1(const float *__restrict__ A, const float *__restrict__ B, unsigned pix, unsigned pixb, unsigned v, float d)
 {
-    const float4 *pa = reinterpret_cast<const float4 *>(A + ((size_t)pix * 16 + v * 8)), *pb = reinterpret_cast<const float4 *>(B + ((size_t)pix * 16 + v * 8));
+    const float4 *pa = reinterpret_cast<const float4 *>(A + ((size_t)pix * 16 + v * 8)), *pb = reinterpret_cast<const float4 *>(B + ((size_t)pixb * 16 + v * 8));
     const float4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
     const float r[8] = {fmaxf(fmaf(b0.x, d, a0.x), 0.f), fmaxf(fmaf(b0.y, d, a0.y), 0.f), fmaxf(fmaf(b0.z, d, a0.z), 0.f), fmaxf(fmaf(b0.w, d, a0.w), 0.f),
                         fmaxf(fmaf(b1.x, d, a1.x), 0.f), fmaxf(fmaf(b1.y, d, a1.y), 0.f), fmaxf(fmaf(b1.z, d, a1.z), 0.f), fmaxf(fmaf(b1.w, d, a1.w), 0.f)};
@@ -204,7 +211,7 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
         const unsigned vc = vv < va ? vv : va - 1;
         return select4(st.ok && vv < va, ((const u32x4 *)a.srcA)[(size_t)st.ia * va + vc]);
     } else if constexpr (LOADER == LD_FMN_SYNTH) {
-        return select4(st.ok && vv < 2u, synth_c1((const float *)a.srcA, (const float *)a.srcB, st.ia, vv < 2u ? vv : 1u, a.plane_vals[s]));
+        return select4(st.ok && vv < 2u, synth_c1((const float *)a.srcA, (const float *)a.srcB, st.ia, st.ib, vv < 2u ? vv : 1u, a.plane_vals[s]));
     } else if constexpr (is_bilinear(LOADER)) {
         const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3;       // va % VPP == 0 (checked by the launcher)
         if ((unsigned)(chunk * VPP) < va) {                                       // uniform: the whole chunk is source A
@@ -223,7 +230,7 @@ __device__ __forceinline__ u32x4 stage_load(const Stage<LOADER> &st, const MpfCo
             return select4(st.ok, o);
         }
         const unsigned vq = vv - va, vc = vq < vb ? vq : vb - 1;
-        if constexpr (LOADER == LD_BILINEAR_SYNTH) return select4(st.ok && vq < vb, synth_c1((const float *)a.srcB, a.cm, st.ib, vc, a.plane_vals[s]));
+        if constexpr (LOADER == LD_BILINEAR_SYNTH) return select4(st.ok && vq < vb, synth_c1((const float *)a.srcB, a.cm, st.ib & 0x0fffffffu, a.bprime_table ? st.ib >> 28 : (st.ib & 0x0fffffffu), vc, a.plane_vals[s]));
         return select4(st.ok && vq < vb, ((const u32x4 *)a.srcB)[(size_t)st.ib * vb + vc]);
     } else {
         // [x2 nearest upsample of srcA (CA may be 0)] ++ [shared features * context mask, context mask, feature mask]
@@ -450,7 +457,7 @@ void k_conv3x3(const MpfConvArgs a, const int prefetch)
                 u32x4 ld[NI];
 #pragma unroll
                 for (int k = 0; k < NI; ++k) {
-                    if constexpr (LOADER == LD_BILINEAR_SYNTH) ld[k] = ABL(4) ? ((const u32x4 *)a.srcB)[(size_t)stage[k].ib * 4 + vc] : synth_c1((const float *)a.srcB, a.cm, stage[k].ib, vc, a.plane_vals[s]);
+                    if constexpr (LOADER == LD_BILINEAR_SYNTH) ld[k] = ABL(4) ? ((const u32x4 *)a.srcB)[(size_t)(stage[k].ib & 0x0fffffffu) * 4 + vc] : synth_c1((const float *)a.srcB, a.cm, stage[k].ib & 0x0fffffffu, a.bprime_table ? stage[k].ib >> 28 : (stage[k].ib & 0x0fffffffu), vc, a.plane_vals[s]);
                     else ld[k] = ((const u32x4 *)a.srcB)[(size_t)stage[k].ib * vb + vc];
                 }
 #pragma unroll
@@ -738,6 +745,9 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     MPF_REQUIRE(!is_bilinear(a.loader) || (a.CA % a.ct == 0 && a.CA > 0 && a.CB > 0), "mpf_conv3x3_f16: the upsampled source must fill whole chunks");
     MPF_REQUIRE((a.loader != LD_FMN_SYNTH && a.loader != LD_BILINEAR_SYNTH) || (a.plane_vals && a.srcA && a.srcB && (a.loader == LD_FMN_SYNTH ? a.CA == 16 : (a.CB == 16 && a.cm))),
                 "mpf_conv3x3_f16: the synthesised first-layer source needs the two fp32 maps (16 channels) and the plane values");
+    MPF_REQUIRE(!a.bprime_table || ((a.loader == LD_FMN_SYNTH || a.loader == LD_BILINEAR_SYNTH) && a.Hin >= 2 && a.Win >= 2 && a.pad_mode == 0),
+                "mpf_conv3x3_f16: bprime_table needs a synthesising loader, zero padding and at least 2 x 2 pixels");
+    MPF_REQUIRE(a.loader != LD_BILINEAR_SYNTH || (size_t)a.Hin * a.Win < (1u << 27), "mpf_conv3x3_f16: LD_BILINEAR_SYNTH packs the pixel index into 27 bits");
     MPF_REQUIRE(a.plane_major ? ((a.Wout + 31) / 32 <= 65535 && (a.Hout + 3) / 4 <= 65535) : (size_t)a.S * a.ncg <= 65535, "mpf_conv3x3_f16: grid dimension limit exceeded");
     const int nb = a.nblk / a.ncg;
     const int key = a.loader * 1000 + a.epi * 100 + a.ct * 1 + a.stride * 10000;

@@ -219,7 +219,7 @@ class ConvLayer:
                    CA=CA, CB=CB, name=name)
 
     # -- launch -------------------------------------------------------------------------------------------------------
-    def __call__(self, S, Hin, Win, srcA=None, srcB=None, cm=None, fm=None, plane_vals=None, HA=None, WA=None, out=None):
+    def __call__(self, S, Hin, Win, srcA=None, srcB=None, cm=None, fm=None, plane_vals=None, HA=None, WA=None, out=None, bprime_table=False):
         Hout, Wout = (Hin - 1) // self.stride + 1, (Win - 1) // self.stride + 1
         dev = self.wpack.device
         if out is None:
@@ -242,6 +242,7 @@ class ConvLayer:
         a.loader, a.epi, a.stride, a.pad_mode = self.loader, self.epi, self.stride, self.pad_mode
         a.wlds = int(_wlds(self.name, self.wlds_default))
         a.plane_major = int(self.plane_major)
+        a.bprime_table = int(bool(bprime_table))
         a.pw = _pw(self.name, S, self.nblk // self.ncg)
         self.last_call = dict(S=S, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, HA=a.HA, WA=a.WA)
         if self.loader in (LD_BILINEAR_CAT, LD_BILINEAR_SYNTH):
@@ -309,7 +310,7 @@ class FeatMaskEngine:
         # loaders, plane index fastest in the grid so that the planes of a tile share the maps in L2.  The 1 GB activation is never written / read
         # twice, the 0.32 ms launch is gone.  MPIFLOW_FMN_FACTOR=0 keeps the materialised form (A/B, per-layer tests).
         # Only the set the mode uses is packed and uploaded; the other one is built on first access (per-layer tests, A/B runs).
-        self._plane_map, self._zeros = {}, {}
+        self._plane_map, self._zeros, self._plane_table = {}, {}, {}
 
     _LAZY = {"l1": lambda A, f, d: A(d, f.conv1, [(8, 5)], loader=LD_FMN_INPUT, stride=1, ct=8, name="l1"),
              "l2": lambda A, f, d: A(d, f.conv2, [(16, 16)], loader=LD_DIRECT, stride=2, ct=16, name="l2"),
@@ -338,6 +339,24 @@ class FeatMaskEngine:
             self._zeros[key] = torch.zeros(1, device=dev)
         return self.l1p(1, H, W, srcA=image_3HW, srcB=disp_HW, plane_vals=self._zeros[key])[0], self._plane_map[key]
 
+    def plane_table(self, H, W):
+        """B' as the [3,3,16] table of its border classes, or None.  B' depends on the pixel only through WHICH of the nine taps fall inside the image (zero
+        padding): top / inner / bottom row x left / inner / right column.  Layers 2 and 8 read 576 bytes from L1 instead of 64 bytes per pixel and plane from L2
+        (MpfConvArgs.bprime_table) - the SAME values, checked here against the whole map once per size; a size where that does not hold keeps the map."""
+        key = (H, W)
+        if key not in self._plane_table:
+            Bm, t = self._plane_map[key], None
+            if H >= 3 and W >= 3 and os.environ.get("MPIFLOW_BPRIME_TABLE", "1") != "0":
+                rows, cols = torch.tensor([0, 1, H - 1], device=Bm.device), torch.tensor([0, 1, W - 1], device=Bm.device)
+                t = Bm[rows][:, cols].contiguous()                        # [3,3,16]
+                ry = torch.ones(H, dtype=torch.long, device=Bm.device)
+                cx = torch.ones(W, dtype=torch.long, device=Bm.device)
+                ry[0], ry[-1], cx[0], cx[-1] = 0, 2, 0, 2
+                if not torch.equal(t[ry][:, cx], Bm):
+                    t = None
+            self._plane_table[key] = t
+        return self._plane_table[key]
+
     def logits(self, image_3HW, disp_HW, plane_disp_S):
         S = plane_disp_S.numel()
         H, W = disp_HW.shape
@@ -346,7 +365,8 @@ class FeatMaskEngine:
         img, dsp, pd = image_3HW.float().contiguous(), disp_HW.float().contiguous(), plane_disp_S.float().contiguous()
         if self.factor:
             A1, B1 = self.first_layer_maps(img, dsp)
-            c2 = self.l2s(S, H, W, srcA=A1, srcB=B1, plane_vals=pd)
+            Bt = self.plane_table(H, W)
+            c2 = self.l2s(S, H, W, srcA=A1, srcB=B1 if Bt is None else Bt, plane_vals=pd, bprime_table=Bt is not None)
         else:
             c1 = self.l1(S, H, W, srcA=img, srcB=dsp, plane_vals=pd)
             c2 = self.l2(S, H, W, srcA=c1)
@@ -356,7 +376,7 @@ class FeatMaskEngine:
         c6 = self.l6(S, H // 4, W // 4, srcA=c5, srcB=c3, HA=H // 8, WA=W // 8)
         c7 = self.l7(S, H // 2, W // 2, srcA=c6, srcB=c2, HA=H // 4, WA=W // 4)
         if self.factor:
-            c8 = self.l8s(S, H, W, srcA=c7, srcB=A1, cm=B1, plane_vals=pd, HA=H // 2, WA=W // 2)
+            c8 = self.l8s(S, H, W, srcA=c7, srcB=A1, cm=B1 if Bt is None else Bt, plane_vals=pd, HA=H // 2, WA=W // 2, bprime_table=Bt is not None)
         else:
             c8 = self.l8(S, H, W, srcA=c7, srcB=c1, HA=H // 2, WA=W // 2)
         return self.l9(S, H, W, srcA=c8)

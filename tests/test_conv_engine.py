@@ -187,6 +187,10 @@ def test_fmn_layers_match_torch():
         c2s = eng.l2s(S, H, W, srcA=A1, srcB=B1, plane_vals=pd)
         _close(_nchw(c2s, 32), fmn.conv2(_nchw(c1s, 16)))
         _close(_nchw(c2s, 32), fmn.conv2(_nchw(c1, 16)), ulps=6)
+        # B' as the table of its 3 x 3 border classes (MpfConvArgs.bprime_table): the same values, so the same bits out of both consumers
+        Bt = eng.plane_table(H, W)
+        assert Bt is not None and Bt.shape == (3, 3, 16)
+        assert torch.equal(eng.l2s(S, H, W, srcA=A1, srcB=Bt, plane_vals=pd, bprime_table=True), c2s)
         c3 = eng.l3(S, H // 2, W // 2, srcA=c2)
         _close(_nchw(c3, 64), fmn.conv3(_nchw(c2, 32)))
         c4 = eng.l4(S, H // 4, W // 4, srcA=c3)
@@ -201,6 +205,7 @@ def test_fmn_layers_match_torch():
         _close(_nchw(c8, 16), fmn.conv8(torch.cat([_q16(fmn.upsample(_nchw(c7, 32))), _nchw(c1, 16)], 1)), ulps=6)
         c8s = eng.l8s(S, H, W, srcA=c7, srcB=A1, cm=B1, plane_vals=pd, HA=H // 2, WA=W // 2)          # skip input synthesised, plane-major grid
         _close(_nchw(c8s, 16), fmn.conv8(torch.cat([_q16(fmn.upsample(_nchw(c7, 32))), _nchw(c1s, 16)], 1)), ulps=6)
+        assert torch.equal(eng.l8s(S, H, W, srcA=c7, srcB=A1, cm=Bt, plane_vals=pd, HA=H // 2, WA=W // 2, bprime_table=True), c8s)
         lg = eng.l9(S, H, W, srcA=c8)
         ref = fmn.conv9(_nchw(c8, 16))[:, 0]
         assert float((lg - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))

@@ -40,6 +40,8 @@ for setting in settings:
     os.environ["MPIFLOW_PW"] = setting              # an item "pf=0" / "pf=1" (not a layer name) switches the walking kernels' prefetch: mpf_tune("conv_pf", v)
     pf = [it.split("=")[1] for it in setting.split(",") if it.startswith("pf=")]
     _lib.load().mpf_tune(b"conv_pf", int(pf[0]) if pf else 1)
+    bt = [it.split("=")[1] for it in setting.split(",") if it.startswith("bt=")]            # "bt=0": B' of the factorised first layer as a map instead of its border-class table
+    os.environ["MPIFLOW_BPRIME_TABLE"] = bt[0] if bt else "1"
     hp = E.HipPredictor(m)
     out = [t.clone() for t in hp(img, dsp)]
     if ref is None:

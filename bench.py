@@ -93,6 +93,11 @@ def parse():
                    help="1 = Stage D of pair i is a per-pixel prologue of the Stage A+C role of launch i+2 (one launch per pair); 0 = a launch of its own after every pair launch")
     p.add_argument("--chain-ordered", type=int, default=0,
                    help="1 = the chain's results are stream-ordered on the main stream at every pair (event record + wait per pair); 0 = independent side pipeline, joined at the end")
+    p.add_argument("--host-prep", choices=["window", "per-pair", "once"], default="window",
+                   help="host work of a pair (utils/utils.py:207-208 pose draws + homography_sampler.py:105-122 per-plane homographies and their fp64 inverse): "
+                        "window = INSIDE the timed region, every timed pair draws its own two poses, the math batched over the in-flight window of --images pairs "
+                        "(one batched evaluation + one pinned upload per window); per-pair = inside the timed region, one prepare() call per pair; "
+                        "once = outside the timed region, fixed poses per image (rounds 1-5)")
     p.add_argument("--no-generator", action="store_true", help="skip the end-to-end generator record")
     p.add_argument("--batch", type=int, default=512, help="--mode batch: images of the whole job per step (BASELINE configs[3]: 512)")
     p.add_argument("--planes", type=int, default=64)
@@ -273,10 +278,15 @@ class PipelinedWorkload:
     i+1 in one heterogeneous-grid launch.  finish() flushes the pipeline (the last pair's stand-alone Stage B)."""
     dynamic = True
 
-    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False, chain_priority=False, chain_ordered=False, merge_in_launch=True, chain_cu_stride=0, chain_sides=2):
+    def __init__(self, S, H, W, B, dev, seed0=0, pose_seed=114514, moving_object=False, chain_priority=False, chain_ordered=False, merge_in_launch=True, chain_cu_stride=0, chain_sides=2,
+                 host_prep="once"):
         self.S, self.H, self.W, self.B, self.N = S, H, W, B, H * W
         K, disp = synth.intrinsics(H, W), synth.plane_disparities(S)
         rng = random.Random(pose_seed)
+        # host_prep != "once": the pose draws and the per-plane homographies of EVERY pair are host work inside step() - what the reference does per pair
+        # (utils/utils.py:207-208, homography_sampler.py:105-122); the set-up poses below then only serve the warm-up of the first window
+        self.host_prep, self.K, self.disp, self.rng = host_prep, torch.as_tensor(np.asarray(K, np.float32)), torch.as_tensor(np.asarray(disp, np.float32)), rng
+        self.host_seconds = 0.0
         # merge_in_launch: Stage D of pair i rides in launch i+2 (per-pixel prologue of its Stage A+C role): ONE launch per pair, nothing between
         self.r = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=merge_in_launch)
         # SURVEY 8(d)'s full c3: the moving-object chain of every pair runs on the renderer's SIDE stream, issued right behind the launch whose
@@ -312,13 +322,43 @@ class PipelinedWorkload:
             self.ev.append((e0, e1))
         self.r.on_fused = hook
 
+    def _draw_window(self, n):
+        """The host work of `n` pairs the way the reference orders it - per pair the dynamic pose, then the camera pose (utils/utils.py:207-208, Python's
+        `random` stream) - with the arithmetic batched over the window: ONE transformation_from_parameters over the 2n poses, ONE homography / fp64-inverse
+        evaluation over their 2n x S matrices, ONE pinned buffer and H2D copy for the 3n parameter blocks (pipeline.prepare_many; bit-identical to n
+        prepare() calls - tests/test_host_logic.py).  -> n prep dicts"""
+        t0 = time.perf_counter()
+        params = []
+        for _ in range(n):
+            dyn = host_math.draw_pose_parameters(0.15, rng=self.rng)
+            cam = host_math.draw_pose_parameters(0.15, base_motions=(0, 0, 0), rng=self.rng)
+            params += [cam, dyn]                                     # prepare()'s order: view 0 = camera pose (samples obj_mask), view 1 = dynamic pose
+        G = host_math.poses_from_parameters(params)
+        preps = self.r.prepare_many(self.K, self.disp, [[G[2 * r], G[2 * r + 1]] for r in range(n)])
+        self.host_seconds += time.perf_counter() - t0
+        return preps
+
     def step(self, timed, which=None):
-        idx = range(self.B) if which is None else which
+        idx = list(range(self.B) if which is None else which)
         self.timed = timed
         moving = (self.mo_disp, self.om) if self.mo is not None else None
-        for i in idx:
+        win = {"once": 0, "per-pair": 1, "window": self.B}[self.host_prep]
+        preps = None
+        for k, i in enumerate(idx):
             mpi, img = self.images[i % self.B]
-            self.r.push(mpi, img, self.preps[i % self.B], self.om, out=self.mix[self.n_pushed % 3], moving=moving, moving_ready=self.inputs_ready if moving else None)
+            if win == 0:
+                prep = self.preps[i % self.B]
+            elif win == 1:
+                t0 = time.perf_counter()
+                G_dyn = host_math.generate_random_pose(0.15, rng=self.rng)                          # utils/utils.py:207
+                G_cam = host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=self.rng)  # :208
+                prep = self.r.prepare(self.K, self.disp, [G_cam, G_dyn])
+                self.host_seconds += time.perf_counter() - t0
+            else:
+                if k % win == 0:
+                    preps = self._draw_window(min(win, len(idx) - k))
+                prep = preps[k % win]
+            self.r.push(mpi, img, prep, self.om, out=self.mix[self.n_pushed % 3], moving=moving, moving_ready=self.inputs_ready if moving else None)
             self.n_pushed += 1
         return len(idx)
 
@@ -505,7 +545,7 @@ def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64, model_d
                                      "gen_3dphoto_dynamic_v2.py:46,59,82-84), NOT the fp32 CPU parity target of the render path; its error against the fp32 model "
                                      "(random weights) is bounded by tests/test_conv_engine.py ENGINE_BARS, e.g. mean |sigmoid(rgb)| 3.2e-3 at this size "
                                      "(torch fp16 autocast: 1.2e-2); --model-engine hip --model-dtype fp32 runs the parity-grade engine (roofline_n1.precise)",
-               "model_dtype": model_dtype, "pairs": n_images * repeat, "flo_files_written": n_files, "process_seconds": dt,
+               "model_dtype": model_dtype, "n_images": n_images, "n_distinct": min(n_images, n_distinct), "repeat": repeat, "pairs": n_images * repeat, "flo_files_written": n_files, "process_seconds": dt,
                "pairs_per_s_whole_process": n_images * repeat / dt, "summary_line": summary[-1] if summary else None}
         if startup:
             rec["startup_line"] = startup[-1]
@@ -591,6 +631,10 @@ def main():
     rank, world, local, backend, rank_devices = init_dist(a)
     dev = torch.device("cuda", local)
     _lib.load()
+    # the product's host math is a few hundred 3x3 / 4x4 matrices per pair: torch's intra-op thread pool only costs there (a batched 1024 x 3 x 3 inverse fanned out over
+    # a 256-thread host took 10x its single-thread time) - one thread, as gen_3dphoto_dynamic.py runs it; restored for the CPU baseline below
+    host_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     if a.sbf_px:
         _lib.check(_lib.load().mpf_tune(b"sbf_px", a.sbf_px))
     for kv in a.tune:
@@ -618,7 +662,8 @@ def main():
         main_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_stream)
     if pipelined:
-        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank, moving_object=chain, chain_priority=bool(a.chain_priority), chain_ordered=bool(a.chain_ordered), merge_in_launch=bool(a.merge_in_launch), chain_cu_stride=a.chain_cu_stride, chain_sides=a.chain_sides)
+        wl = PipelinedWorkload(S, H, W, B, dev, seed0=rank * 1000, pose_seed=114514 + rank, moving_object=chain, chain_priority=bool(a.chain_priority), chain_ordered=bool(a.chain_ordered), merge_in_launch=bool(a.merge_in_launch), chain_cu_stride=a.chain_cu_stride, chain_sides=a.chain_sides,
+                               host_prep=a.host_prep)
     else:
         wl = Workload(S, H, W, B, dev, dynamic, seed0=rank * 1000, multi_view=not a.single_view_launches, pose_seed=114514 + rank, moving_object=chain)
     torch.cuda.synchronize()
@@ -646,6 +691,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     my_pairs = st["pairs"]
+    host_s_timed = getattr(wl, "host_seconds", 0.0)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -653,6 +699,27 @@ def main():
         dt = float(t.item())
     else:
         total_pairs = my_pairs
+
+    # the same pairs with the host work of a pair placed differently (outside the timed region; same box, seconds apart): what putting the per-pair pose
+    # draws + homographies inside the timed region costs.  "once" = rounds 1-5's headline (fixed poses per image, prepared at set-up)
+    host_prep_cmp = {}
+    if pipelined and not a.no_sub:
+        keep = wl.host_prep
+        for mode in ("once", "per-pair", "window"):
+            wl.host_prep = mode
+            wl.step(False, order[:16])
+            wl.finish()
+            torch.cuda.synchronize()
+            barrier()
+            h0, tc0 = wl.host_seconds, time.perf_counter()
+            nc = 0
+            for _ in range(max(1, min(a.steps, 5))):
+                nc += wl.step(False, order)
+            wl.finish()
+            torch.cuda.synchronize()
+            tc = time.perf_counter() - tc0
+            host_prep_cmp[mode] = {"pairs_per_s": nc / tc, "host_prep_us_per_pair": (wl.host_seconds - h0) / nc * 1e6, "pairs": nc}
+        wl.host_prep = keep
 
     # BASELINE configs[3] beside the weak-scaling `value`, on every run: a FIXED batch of --batch images (512) sharded i % world over the ranks,
     # each rank renders its share (cycling through its resident stacks); pairs/s = batch / slowest rank, per-rank seconds reported
@@ -706,6 +773,13 @@ def main():
                                        "with the pair's render results per pair inside the timed region (no consumer runs in this bench); the side stream is joined once, "
                                        "in the timed region's final flush.  --chain-ordered 1 measures the per-pair join (round 4: +12 us per pair)") if chain and pipelined else None),
                        "tune": a.tune,
+                       "host_prep": ({"window": "per pair, timed: every timed pair draws its own two poses (utils/utils.py:207-208) and gets its own per-plane homographies + fp64 "
+                                                "inverses (homography_sampler.py:105-122) INSIDE the timed region; the arithmetic is batched over the in-flight window of "
+                                                "%d pairs (one batched evaluation, one pinned upload per window - pipeline.prepare_many, bit-identical to per-pair prepare())" % B,
+                                      "per-pair": "per pair, timed: one pose draw + prepare() call per timed pair inside the timed region, nothing batched",
+                                      "once": "once per image at set-up, OUTSIDE the timed region (fixed poses; rounds 1-5)"}[a.host_prep] if pipelined else "once per image at set-up (serial pipeline)"),
+                       "host_prep_us_per_pair_timed": (host_s_timed / max(1, my_pairs) * 1e6) if pipelined else None,
+                       "host_prep_comparison": host_prep_cmp or None,
                        "pairs_per_step_per_gpu": len(order), "resident_stacks_per_gpu": B, "timed_seconds": dt,
                        "sharding": "independent images per rank (i % world == rank), stats all-reduce only",
                        "device": _lib.device_info(local),
@@ -779,9 +853,35 @@ def main():
             except Exception as e:                                   # noqa: BLE001
                 out["generator_precise"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
+            torch.set_num_threads(host_threads)
             out["cpu_baseline"] = cpu_baseline(S, H, W, a.cpu_pairs, chain=chain)
             out["cpu_baseline"]["reference_measured_in_build_container"] = \
                 "reference render_3dphoto_dynamic (the same full dynamic pair) 64x640x960: 104.8 s on 8 threads (tests/golden/make_golden.py)"
+        # the scalars that matter, inside `config` (the driver's record keeps config / roofline values but only the NAMES of the other sub-records)
+        c = out["config"]
+        def _get(d, *path):                                          # noqa: E306
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d if isinstance(d, (int, float)) else None
+        c["pair_alone_pairs_per_s"] = _get(out, "roofline_pair_alone", "pairs_per_s")
+        c["pair_alone_launch_ms"] = _get(out, "roofline_pair_alone", "avg_launch_ms")
+        c["pairs_per_s_host_prep_once"] = _get(c, "host_prep_comparison", "once", "pairs_per_s")
+        c["pairs_per_s_host_prep_per_pair"] = _get(c, "host_prep_comparison", "per-pair", "pairs_per_s")
+        c["pairs_per_s_host_prep_window"] = _get(c, "host_prep_comparison", "window", "pairs_per_s")
+        c["stage_b_2views_frac"] = _get(out, "roofline_stage_b", "frac")
+        c["stage_ac_frac"] = _get(out, "roofline_stage_ac", "frac")
+        c["batch512_pairs_per_s"] = _get(out, "batch512", "pairs_per_s")
+        c["n1_ms_per_image"] = _get(out, "roofline_n1", "ms_per_image")
+        c["n1_hbm_frac"] = _get(out, "roofline_n1", "hbm", "frac")
+        c["n1_mfma_frac"] = _get(out, "roofline_n1", "mfma", "frac")
+        c["n1_precise_fp32_ms"] = _get(out, "roofline_n1", "precise", "fp32", "ms_per_image")
+        c["n1_precise_fp64_ms"] = _get(out, "roofline_n1", "precise", "fp64", "ms_per_image")
+        c["generator_pairs_per_s_steady"] = _get(out, "generator", "pairs_per_s_steady_state")
+        c["generator_pairs_per_s_whole_process"] = _get(out, "generator", "pairs_per_s_whole_process")
+        c["generator_precise_pairs_per_s_steady"] = _get(out, "generator_precise", "pairs_per_s_steady_state")
+        c["hbm_read_GBps"] = _get(out, "hbm_reference", "read_GBps")
+        c["hbm_copy_GBps"] = _get(out, "hbm_reference", "copy_GBps")
+        c["cpu_baseline_pairs_per_s"] = _get(out, "cpu_baseline", "value")
         print(json.dumps(out))
     if masked_main is not None:
         torch.cuda.synchronize()

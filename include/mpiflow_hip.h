@@ -63,7 +63,8 @@ int mpf_stream_destroy(void *stream);
 
 /* bench/tuning knobs: "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2); "stage_b" = Stage B kernel variant; "planar_lds";
  * "ovl_depth" = planes of loads a Stage A+C wave keeps in flight inside the pair launch (4 or 8); "ovl_xcd_a"; "view_shift"; "fwarp_path" = 0 gather
- * (default) | 1 general radix path | 2 round 2's sort path; "chain_grid" / "chain_prio" (grid cap / s_setprio of the forward-warp kernels); "conv_pf" = 0 | 1 (default): the plane-walking conv kernels
+ * (default) | 1 general radix path | 2 round 2's sort path; "fwarp_gate" = bucket visits above which caller-supplied targets leave the gather path for the radix path
+ * (-1 = default: one visit per source; 0 = always radix); "chain_grid" / "chain_prio" (grid cap / s_setprio of the forward-warp kernels); "conv_pf" = 0 | 1 (default): the plane-walking conv kernels
  * (MpfConvArgs.pw > 1) copy the next step's weight fragments / raw tile into a second LDS buffer during the current MFMA phase.  None of
  * these changes a result - every variant is bit-identical, which the tests assert - except "ovl_ablate" and "stage_b" 101..106, which exist for
  * timing ablations only and produce INVALID outputs.  The knobs are PROCESS-GLOBAL plain ints, not per-stream and NOT thread-safe: set them from one

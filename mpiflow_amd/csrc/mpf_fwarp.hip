@@ -40,6 +40,12 @@ static int g_fw_prio = 0;       // mpf_tune("chain_prio", 0..3): s_setprio of th
 #define SORT_ITEMS 8
 #define SORT_TILE (SORT_THREADS * SORT_ITEMS)
 
+// Device-side choice between the gather path and the radix path for caller-supplied targets (mpf_forward_warp / forward_warping), without a host round trip:
+// pass 1 of the gather path adds up the bucket visits its slab ranges imply (work); every kernel of BOTH paths is launched, and each one returns at once when the
+// other path owns the call.  work == nullptr: ungated (the moving-object chain, whose targets come from a projection and are parallax-bounded).
+struct FwGate { const unsigned long long *work; unsigned long long thr; bool radix; };
+__device__ __forceinline__ bool fw_gate_closed(const FwGate g) { return g.work && ((*g.work > g.thr) != g.radix); }
+
 // ---- moving_obj.py:29-30 : depth = 1/(disp + 0.005), clamped to 100 --------------------------------------------------
 
 // `p1.cpu().long()` (moving_obj.py:121) is an x86 cvttss2si: values that do not fit an int64 - NaN, +-inf, |v| >= 2^63, reachable
@@ -191,8 +197,9 @@ extern "C" int mpf_moving_object_project(const float *d_disp, const float *h_inv
 // moving_obj.py:123 zero-initialises `warped_arr`) - one pass over N instead of two separate fill launches.
 __global__ void __launch_bounds__(256)
 k_fw_keys(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy, int h, int w, uint32_t *__restrict__ keys,
-          uint32_t *__restrict__ vals, uint32_t *__restrict__ win, uint8_t *__restrict__ warped_to_clear)
+          uint32_t *__restrict__ vals, uint32_t *__restrict__ win, uint8_t *__restrict__ warped_to_clear, const FwGate gate = FwGate{nullptr, 0, true})
 {
+    if (fw_gate_closed(gate)) return;
     const int64_t N = (int64_t)h * w;
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -211,10 +218,11 @@ k_fw_keys(const int64_t *__restrict__ idx, const int64_t *__restrict__ idy, int 
 
 template <int BITS>
 __global__ void __launch_bounds__(SORT_THREADS)
-k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t nb, uint32_t *__restrict__ hist)
+k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t nb, uint32_t *__restrict__ hist, const FwGate gate = FwGate{nullptr, 0, true})
 {
     constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS;
     __shared__ uint32_t h[RADIX];
+    if (fw_gate_closed(gate)) return;
 #pragma unroll
     for (int k = 0; k < DPT; ++k) h[threadIdx.x + k * SORT_THREADS] = 0;
     __syncthreads();
@@ -310,8 +318,9 @@ k_mo_project_keys_hist(const float *__restrict__ disp, const MpfMoProj m, const 
 // k_radix_scatter: every workgroup rebuilds base[] from the RADIX totals in LDS (256 .. 2048 numbers) and reads its own row of
 //                  colprefix with coalesced loads.
 __global__ void __launch_bounds__(256)
-k_radix_colscan(uint32_t *__restrict__ hist, uint32_t nb, uint32_t radix, uint32_t *__restrict__ totals, const int prio = 0)
+k_radix_colscan(uint32_t *__restrict__ hist, uint32_t nb, uint32_t radix, uint32_t *__restrict__ totals, const int prio = 0, const FwGate gate = FwGate{nullptr, 0, true})
 {
+    if (fw_gate_closed(gate)) return;
     MPF_FW_SETPRIO(prio);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     for (uint32_t c = blockIdx.x * wpb + wave; c < radix; c += gridDim.x * wpb) {       // one wave per column
@@ -340,9 +349,10 @@ template <int BITS>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
                 uint32_t *__restrict__ vals_out, uint32_t N, int shift, uint32_t nb, const uint32_t *__restrict__ offsets,
-                const uint32_t *__restrict__ totals, const int prio = 0)
+                const uint32_t *__restrict__ totals, const int prio = 0, const FwGate gate = FwGate{nullptr, 0, true})
 {
     constexpr int RADIX = 1 << BITS, DPT = RADIX / SORT_THREADS, NW = SORT_THREADS / 64;
+    if (fw_gate_closed(gate)) return;
     MPF_FW_SETPRIO(prio);
     __shared__ uint32_t running[RADIX];
     __shared__ uint32_t cnt[NW][RADIX];
@@ -413,11 +423,11 @@ k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict
 
 template <int BITS>
 static void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, uint32_t N, int shift, uint32_t nb,
-                       uint32_t *hist, uint32_t *totals, hipStream_t st)
+                       uint32_t *hist, uint32_t *totals, hipStream_t st, const FwGate gate)
 {
-    hipLaunchKernelGGL((k_radix_hist<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, N, shift, nb, hist);
-    hipLaunchKernelGGL(k_radix_colscan, dim3((1u << BITS) / 4u), dim3(256), 0, st, hist, nb, 1u << BITS, totals, g_fw_prio);
-    hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals, g_fw_prio);
+    hipLaunchKernelGGL((k_radix_hist<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, N, shift, nb, hist, gate);
+    hipLaunchKernelGGL(k_radix_colscan, dim3((1u << BITS) / 4u), dim3(256), 0, st, hist, nb, 1u << BITS, totals, g_fw_prio, gate);
+    hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals, g_fw_prio, gate);
 }
 
 // ---- buckets: finish the sort inside each high-digit bucket and resolve it, in ONE kernel ------------------------------------
@@ -603,12 +613,12 @@ template <bool PROJ>
 __global__ void __launch_bounds__(256)
 k_fw_keys_ranges(const float *__restrict__ disp, const MpfMoProj m, const float *__restrict__ inst, const MpfMoOut o, const int64_t *__restrict__ idx,
                  const int64_t *__restrict__ idy, int h, int w, uint32_t N, uint32_t ntiles, uint32_t *__restrict__ keys, uint32_t *__restrict__ slab_min,
-                 uint32_t *__restrict__ slab_max, uint32_t *__restrict__ tile_min, uint32_t *__restrict__ tile_max)
+                 uint32_t *__restrict__ slab_max, uint32_t *__restrict__ tile_min, uint32_t *__restrict__ tile_max, unsigned long long *__restrict__ work = nullptr)
 {
-    __shared__ uint32_t red[4][2];
+    __shared__ uint32_t red[4][3];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        uint32_t tmin = 0xFFFFFFFFu, tmax = 0u;
+        uint32_t tmin = 0xFFFFFFFFu, tmax = 0u, visits = 0u;     // visits: buckets of 256 targets this wave's four slabs touch = what pass 2 will spend on them
         // the four pixels' inputs first: the outputs are plain (possibly aliasing) pointers, so a load behind a store would wait for it
         float dv[4], iv[4];
         int64_t xv[4], yv[4];
@@ -645,8 +655,9 @@ k_fw_keys_ranges(const float *__restrict__ disp, const MpfMoProj m, const float 
             }
             tmin = kmin < tmin ? kmin : tmin;
             tmax = kmax > tmax ? kmax : tmax;
+            if (kmin <= kmax) visits += (kmax >> FWG_LB) - (kmin >> FWG_LB) + 1u;
         }
-        if (lane == 0) { red[wave][0] = tmin; red[wave][1] = tmax; }
+        if (lane == 0) { red[wave][0] = tmin; red[wave][1] = tmax; red[wave][2] = visits; }
         __syncthreads();
         if (tid == 0) {
             uint32_t a = red[0][0], b = red[0][1];
@@ -654,6 +665,7 @@ k_fw_keys_ranges(const float *__restrict__ disp, const MpfMoProj m, const float 
             for (int k = 1; k < 4; ++k) { a = red[k][0] < a ? red[k][0] : a; b = red[k][1] > b ? red[k][1] : b; }
             tile_min[tile] = a;
             tile_max[tile] = b;
+            if (work) atomicAdd(work, (unsigned long long)red[0][2] + red[1][2] + red[2][2] + red[3][2]);
         }
         __syncthreads();
     }
@@ -676,9 +688,10 @@ __global__ void __launch_bounds__(64 * FWG_WAVES)
 k_fw_gather_resolve(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ slab_min, const uint32_t *__restrict__ slab_max,
                     const uint32_t *__restrict__ tile_min, const uint32_t *__restrict__ tile_max, uint32_t N, uint32_t ntiles, const float *__restrict__ z,
                     const uint8_t *__restrict__ src, const float *__restrict__ src_f, uint8_t *__restrict__ warped, int zero_fill,
-                    uint8_t *__restrict__ Hm, uint8_t *__restrict__ Mm)
+                    uint8_t *__restrict__ Hm, uint8_t *__restrict__ Mm, const FwGate gate = FwGate{nullptr, 0, false})
 {
     constexpr int NT = 1 << FWG_LB;
+    if (fw_gate_closed(gate)) return;                        // scattered targets: the radix path behind this launch owns the call
     __shared__ uint32_t g_src_[FWG_WAVES][FWG_CAP], g_tl_[FWG_WAVES][FWG_CAP];      // gathered, raster order
     __shared__ float g_z_[FWG_WAVES][FWG_CAP];
     __shared__ uint32_t s_src_[FWG_WAVES][FWG_CAP], s_tl_[FWG_WAVES][FWG_CAP];      // sorted by (target, raster index)
@@ -903,8 +916,9 @@ k_warp_masks_planes(const uint8_t *__restrict__ Hm, const uint8_t *__restrict__ 
 
 __global__ void __launch_bounds__(256)
 k_fw_mark(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const float *__restrict__ z, uint32_t N,
-          uint32_t *__restrict__ win)
+          uint32_t *__restrict__ win, const FwGate gate = FwGate{nullptr, 0, true})
 {
+    if (fw_gate_closed(gate)) return;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N) return;
     const uint32_t t = keys[j];
@@ -916,8 +930,9 @@ k_fw_mark(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, 
 __global__ void __launch_bounds__(256)
 k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const float *__restrict__ z,
            const uint8_t *__restrict__ src, uint32_t N, const uint32_t *__restrict__ win, uint8_t *__restrict__ warped,
-           const float *__restrict__ src_f = nullptr)
+           const float *__restrict__ src_f = nullptr, const FwGate gate = FwGate{nullptr, 0, true})
 {
+    if (fw_gate_closed(gate)) return;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N) return;
     const uint32_t t = keys[j];
@@ -945,6 +960,9 @@ static int g_fw_path = 0;       // mpf_tune("fwarp_path", p): 0 = gather (round 
                                 // Process-global and not thread-safe, like every mpf_tune knob: set it before launching work, from one thread.
 
 void mpf_fwarp_set_path(int v) { g_fw_path = v; }
+static long long g_fw_gate_thr = -1;   // mpf_tune("fwarp_gate", t): bucket visits above which caller-supplied targets take the radix path (-1 = default, one per source;
+                                       // 0 = always radix behind the gate - same results either way: the tests run both sides of it)
+void mpf_fwarp_set_gate(int v) { g_fw_gate_thr = v; }
 static int g_fw_grid = 0;       // mpf_tune("chain_grid", g): cap the workgroup count of every sort / resolve / mask launch at g (0 = one per tile);
                                 // fewer, longer-lived workgroups for runs underneath a chip-filling launch of another stream
 void mpf_fwarp_set_grid(int v) { g_fw_grid = v < 0 ? 0 : v; }
@@ -959,7 +977,7 @@ extern "C" size_t mpf_forward_warp_workspace(int h, int w)
     if (N <= 0) return 0;
     const size_t a = ((size_t)N * 4 + 255) & ~(size_t)255;
     const size_t hs = (((size_t)RADIX_MAX * fw_blocks(N)) * 4 + 255) & ~(size_t)255;
-    return 5 * a + hs + 4 * RADIX_MAX;    // keysA, keysB, valsA, valsB, win, hist, digit totals
+    return 5 * a + hs + 4 * RADIX_MAX + 256;    // keysA, keysB, valsA, valsB, win, hist, digit totals, the gather / radix gate counter
 }
 
 // proj != nullptr (mpf_moving_object_chain): the targets are not given but computed - d_idx / d_idy / d_z are the projection's own outputs
@@ -986,25 +1004,39 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
     uint32_t *hist = (uint32_t *)(ws + 5 * a);
     const uint32_t nb = fw_blocks(N);
     uint32_t *totals = hist + (((size_t)RADIX_MAX * nb + 63) & ~(size_t)63);
+    unsigned long long *work = (unsigned long long *)(totals + RADIX_MAX);
     const uint32_t g256 = (N + 255) / 256;
 
     int bits = 0;
     while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)N) ++bits;
+    FwGate gate = FwGate{nullptr, 0, true};                   // set by the gather branch for caller-supplied targets: the radix launches below then run conditionally
     if (bits <= 24 && g_fw_path == 0) {
         // round 5: gather instead of sort - keys + slab / tile ranges, then one wave per bucket of 256 targets (k_fw_gather_resolve)
         const uint32_t ntiles = (N + FWG_TILE - 1) / FWG_TILE, nslabs = ntiles * 16, nbuckets = (N + (1u << FWG_LB) - 1) >> FWG_LB;
         uint32_t *slab_min = keys[1], *slab_max = keys[1] + nslabs, *tile_min = slab_max + nslabs, *tile_max = tile_min + ntiles;   // 34 N / 1024 words of the second key array
         static const MpfMoProj no_proj = {};
-        if (proj) hipLaunchKernelGGL((k_fw_keys_ranges<true>), dim3(fw_cap(ntiles)), dim3(256), 0, st, proj->disp, proj->m, proj->inst, proj->out, d_idx, d_idy, h, w, N,
-                                     ntiles, keys[0], slab_min, slab_max, tile_min, tile_max);
-        else hipLaunchKernelGGL((k_fw_keys_ranges<false>), dim3(fw_cap(ntiles)), dim3(256), 0, st, (const float *)nullptr, no_proj, (const float *)nullptr, MpfMoOut{}, d_idx,
-                                d_idy, h, w, N, ntiles, keys[0], slab_min, slab_max, tile_min, tile_max);
+        if (proj) {
+            // the chain: targets are the projection of raster-ordered sources under one rigid motion - a slab's key range is bounded by the parallax, not by the caller
+            hipLaunchKernelGGL((k_fw_keys_ranges<true>), dim3(fw_cap(ntiles)), dim3(256), 0, st, proj->disp, proj->m, proj->inst, proj->out, d_idx, d_idy, h, w, N,
+                               ntiles, keys[0], slab_min, slab_max, tile_min, tile_max, (unsigned long long *)nullptr);
+            hipLaunchKernelGGL(k_fw_gather_resolve, dim3(fw_cap((nbuckets + FWG_WAVES - 1) / FWG_WAVES)), dim3(64 * FWG_WAVES), 0, st, keys[0], slab_min, slab_max, tile_min, tile_max, N, ntiles, d_z, d_src, src_f,
+                               d_warped, zero_fill ? 1 : 0, planes_H, planes_M, FwGate{nullptr, 0, false});
+            if (planes_written) *planes_written = planes_H != nullptr;
+            return mpf_launch_status("forward_warp kernels");
+        }
+        // caller-supplied targets (mpf_forward_warp / forward_warping): nothing bounds how far the targets of 64 consecutive sources are spread, and the gather
+        // costs one slab read per (slab, bucket its range touches) - O(N^2 / 256) for scattered targets, where the radix path stays O(N) per pass.  Pass 1 adds
+        // up those visits; beyond `thr` (one visit per source on average: <= 64 N key reads) the gather kernel returns at once and the radix launches behind it,
+        // which otherwise return at once, do the work.  Decided on the device: no host round trip, the call stays asynchronous.
+        MPF_HIP(hipMemsetAsync(work, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL((k_fw_keys_ranges<false>), dim3(fw_cap(ntiles)), dim3(256), 0, st, (const float *)nullptr, no_proj, (const float *)nullptr, MpfMoOut{}, d_idx,
+                           d_idy, h, w, N, ntiles, keys[0], slab_min, slab_max, tile_min, tile_max, work);
+        const unsigned long long thr = g_fw_gate_thr >= 0 ? (unsigned long long)g_fw_gate_thr : (unsigned long long)nslabs * 64ull;
         hipLaunchKernelGGL(k_fw_gather_resolve, dim3(fw_cap((nbuckets + FWG_WAVES - 1) / FWG_WAVES)), dim3(64 * FWG_WAVES), 0, st, keys[0], slab_min, slab_max, tile_min, tile_max, N, ntiles, d_z, d_src, src_f,
-                           d_warped, zero_fill ? 1 : 0, planes_H, planes_M);
-        if (planes_written) *planes_written = planes_H != nullptr;
-        return mpf_launch_status("forward_warp kernels");
+                           d_warped, zero_fill ? 1 : 0, planes_H, planes_M, FwGate{work, thr, false});
+        gate = FwGate{work, thr, true};
     }
-    if (bits <= 2 * RADIX_BITS_MAX && g_fw_path == 2) {
+    if (!gate.work && bits <= 2 * RADIX_BITS_MAX && g_fw_path == 2) {
         // the fast path: one stable pass on the high bits, then one workgroup per bucket of 2^lb targets sorts and resolves it
         const int lb = bits <= 16 ? 8 : (bits <= 18 ? 9 : (bits <= 20 ? 10 : 11));
         const int hb = bits > lb ? bits - lb : 1;                        // 1 .. 11 high bits (hb < 8: the pass still uses 8-bit digits)
@@ -1034,7 +1066,7 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
         return mpf_launch_status("forward_warp kernels");
     }
     if (proj) hipLaunchKernelGGL(k_moving_object_project, dim3(g256), dim3(256), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out);
-    hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], win, zero_fill ? d_warped : (uint8_t *)nullptr);
+    hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], win, zero_fill ? d_warped : (uint8_t *)nullptr, gate);
     // the fewest passes of 8..11-bit digits that cover the key: 640 x 960 (20 bits) -> 2 x 10, 1024 x 1536 (21 bits) -> 2 x 11
     if (bits < 1) bits = 1;
     const int passes = (bits + RADIX_BITS_MAX - 1) / RADIX_BITS_MAX;
@@ -1044,15 +1076,15 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
     for (int p = 0; p < passes; ++p) {
         const int shift = p * dbits;
         switch (dbits) {
-        case 8: radix_pass<8>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st); break;
-        case 9: radix_pass<9>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st); break;
-        case 10: radix_pass<10>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st); break;
-        default: radix_pass<11>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st); break;
+        case 8: radix_pass<8>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st, gate); break;
+        case 9: radix_pass<9>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st, gate); break;
+        case 10: radix_pass<10>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st, gate); break;
+        default: radix_pass<11>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], N, shift, nb, hist, totals, st, gate); break;
         }
         cur ^= 1;
     }
-    hipLaunchKernelGGL(k_fw_mark, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, N, win);
-    hipLaunchKernelGGL(k_fw_write, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, d_src, N, win, d_warped, src_f);
+    hipLaunchKernelGGL(k_fw_mark, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, N, win, gate);
+    hipLaunchKernelGGL(k_fw_write, dim3(g256), dim3(256), 0, st, keys[cur], vals[cur], d_z, d_src, N, win, d_warped, src_f, gate);
     return mpf_launch_status("forward_warp kernels");
 }
 

@@ -2106,6 +2106,7 @@ extern "C" int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int
 }
 
 void mpf_fwarp_set_path(int v);      // mpf_fwarp.hip
+void mpf_fwarp_set_gate(int v);
 void mpf_conv_set_prefetch(int v);   // mpf_conv.hip
 void mpf_fwarp_set_prio(int v);
 void mpf_fwarp_set_grid(int v);
@@ -2119,6 +2120,7 @@ extern "C" int mpf_tune(const char *key, int value)
     if (key && !strcmp(key, "ovl_ablate")) { g_ovl_ablate = value; return 0; }
     if (key && !strcmp(key, "view_shift")) { g_view_shift = value < 0 ? 0 : value; return 0; }
     if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
+    if (key && !strcmp(key, "fwarp_gate")) { mpf_fwarp_set_gate(value); return 0; }
     if (key && !strcmp(key, "conv_pf")) { mpf_conv_set_prefetch(value); return 0; }
     if (key && !strcmp(key, "chain_grid")) { mpf_fwarp_set_grid(value); return 0; }
     if (key && !strcmp(key, "chain_prio")) { mpf_fwarp_set_prio(value); return 0; }

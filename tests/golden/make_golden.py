@@ -421,6 +421,64 @@ def gen_model(S=4, H=128, W=128, seed=0):
          n_state=len(ref.state_dict()), sha_keys=np.array(sha(np.frombuffer("|".join(sorted(ref.state_dict())).encode(), np.uint8))))
 
 
+def gen_e2e(name="e2e_loop_body", S=8, H=128, W=256, seed=0, pose_seed=61):
+    """The reference's LOOP BODY end to end (gen_3dphoto_dynamic_v2.py:82-118) in fp32 on the CPU: its own input resize (F.interpolate bilinear,
+    align_corners=True, :86-89, :104-105), its own network (model/AdaMPI.py MPIPredictor with the deterministic parameters of
+    mpiflow_amd.model.MPIPredictor.randomize_(seed), loaded strict - the published checkpoint is not available offline), and its own
+    render_3dphoto_dynamic on the stack the network produced (:107-118).  The only fixture whose sigma field has the network's distribution
+    (relu(x * cum_mask) + 1e-4, model/CPN/decoder.py:166-173) instead of synth.make_inputs' white / smooth / opaque draws.  Stored: the resized inputs,
+    the network's stack, both posed views un-thresholded, the merge products and cv2.inpaint's inputs."""
+    import torch.nn.functional as F
+    from model.AdaMPI import MPIPredictor as RefModel
+    from mpiflow_amd.model import MPIPredictor
+    mine = MPIPredictor(W, H, S).randomize_(seed)
+    ref = RefModel(width=W, height=H, num_planes=S)
+    ref.load_state_dict(mine.state_dict(), strict=True)
+    ref.eval()
+    rs = np.random.RandomState(seed + 7)
+    h0, w0 = 100, 230                                                     # the files' own size, resized to (H, W) as the reference does
+    yy, xx = np.mgrid[0:h0, 0:w0].astype(np.float32)
+    img0 = np.stack([0.5 + 0.3 * np.sin(xx / 9.0 + c) * np.cos(yy / 7.0 - c) + 0.15 * rs.rand(h0, w0) for c in range(3)]).astype(np.float32).clip(0, 1)
+    dsp0 = (0.15 + 0.7 * yy / h0 + 0.1 * np.sin(xx / 23.0) + 0.03 * rs.rand(h0, w0)).astype(np.float32).clip(0, 1)
+    ids = np.zeros((h0, w0), np.uint8)
+    ids[30:70, 60:120] = 1
+    ids[45:90, 150:200] = 2
+    image = F.interpolate(torch.from_numpy(img0)[None], size=(H, W), mode="bilinear", align_corners=True)       # :86-87
+    disp = F.interpolate(torch.from_numpy(dsp0)[None, None], size=(H, W), mode="bilinear", align_corners=True)  # :88-89
+    with torch.no_grad():
+        mpi_all_src, disparity_all_src = ref(image, disp)                                                         # :92-93
+    np.random.seed(seed)
+    obj_index = np.random.randint(ids.max()) + 1                                                                   # :101
+    obj_mask = torch.FloatTensor(ids == obj_index).unsqueeze(0).unsqueeze(0)                                      # :103
+    obj_mask = F.interpolate(obj_mask, size=(H, W), mode="bilinear", align_corners=True)                          # :104-105
+    K = torch.tensor([[0.58, 0, 0.5], [0, 0.58, 0.5], [0, 0, 1]])                                                  # :42-49
+    K[0, :] *= W
+    K[1, :] *= H
+    K = K.unsqueeze(0)
+    G_cam, G_dyn = poses_for(pose_seed)
+    random.seed(pose_seed)
+    ref_harness.captured.clear()
+    flow_mix, src_np, inpainted, _ = R.utils.render_3dphoto_dynamic(Opt, image, obj_mask, disp, mpi_all_src, disparity_all_src, K, K,
+                                                                    data_path="outputs", name="demo")              # :107-118
+    cap = ref_harness.captured["inpaint"]
+    inp = dict(mpi=mpi_all_src[0].numpy(), disparity=disparity_all_src[0].numpy(), K=K[0].numpy(), image=image[0].numpy(), obj_mask=obj_mask[0, 0].numpy())
+    views = run_views(inp, G_cam.numpy(), G_dyn.numpy())
+    sig = inp["mpi"][:, 3]
+    arrays = dict(S=S, H=H, W=W, seed=seed, pose_seed=pose_seed, image_file=img0, disp_file=dsp0, ids_file=ids, obj_index=obj_index,
+                  mpi=inp["mpi"], disparity=inp["disparity"], image=inp["image"], disp=disp[0, 0].numpy(), obj_mask=inp["obj_mask"], K=inp["K"],
+                  G_cam=G_cam.numpy(), G_dyn=G_dyn.numpy(), flow_mix=flow_mix, src_np=src_np, frame_mix=cap["img"], fill_mask=cap["mask"].astype(np.uint8),
+                  sigma_floor_share=np.array(float((sig == np.float32(1e-4)).mean())), sigma_max=np.array(float(sig.max())))
+    for tag in ("cam", "dyn"):
+        for k, v in views[tag].items():
+            arrays["%s_%s" % (tag, k)] = v
+        arrays["margin_px_%s" % tag] = margin_pixels(views[tag]["objmask"])
+    arrays["margin_px_obj"] = margin_pixels(inp["obj_mask"])
+    print("   network stack: sigma == 1e-4 on %.1f %% of the entries, max %.3g; fill mask %d px; margin band %d + %d px" %
+          (100 * float(arrays["sigma_floor_share"]), float(arrays["sigma_max"]), int(arrays["fill_mask"].astype(bool).sum()),
+           arrays["margin_px_cam"].size, arrays["margin_px_dyn"].size))
+    save(name, **arrays)
+
+
 def gen_input_stage(seed=41):
     """The input stage as the reference runs it (gen_3dphoto_dynamic_v2.py:82-89, :101-105 with utils/utils.py:35-52):
     image_to_tensor / disparity_to_tensor on PNG files, the three F.interpolate(bilinear, align_corners=True) calls and the
@@ -543,6 +601,7 @@ JOBS = {
     "flo": gen_flo,
     "geometry": gen_geometry,
     "model": gen_model,
+    "e2e": gen_e2e,
     "hard": gen_hard_flow,
     "copy": gen_copy_variant,
 }

@@ -158,6 +158,37 @@ def test_pair_vs_reference_golden_small(dev, name):
     assert bits_equal(N(out["src_np"]), g["src_np"]) == 0
 
 
+def test_pair_on_the_reference_networks_own_stack(dev):
+    """e2e_loop_body.npz - the reference's LOOP BODY end to end (gen_3dphoto_dynamic_v2.py:82-118: its network's stack through its own
+    render_3dphoto_dynamic): hot-path parity on a NETWORK-SHAPED sigma field (relu(x * cum_mask) + 1e-4, model/CPN/decoder.py:166-173) instead of a
+    synthetic draw.  Same bars as the synthetic goldens - and this fixture's margin band is empty, so both thresholded masks compare on EVERY pixel.
+    Serial renderer and the pipelined one (one launch per pair, merge in the launch)."""
+    from mpiflow_amd import pipeline
+    g = load_golden("e2e_loop_body")
+    S, H, W = int(g["S"]), int(g["H"]), int(g["W"])
+    assert g["margin_px_cam"].size == 0 and g["margin_px_dyn"].size == 0
+    out = pipeline.render_pair(T(g["image"], dev), T(g["obj_mask"], dev), T(g["mpi"], dev), g["disparity"], g["K"], g["G_cam"], g["G_dyn"])
+    for tag, v in (("cam", out["view_cam"]), ("dyn", out["view_dyn"])):
+        assert max_abs(N(v["rgb"]), g[tag + "_rgb"]) < 2e-6
+        assert max_abs(N(v["objmask"]), g[tag + "_objmask"]) < 2e-6
+        assert bits_equal(N(v["objmask"]) >= TH, g[tag + "_objmask"] >= TH) == 0
+    assert max_abs(N(out["flows"][0]), g["cam_flow"]) < 5e-5
+    assert max_abs(N(out["flows"][1]), g["dyn_flow"]) < 5e-5
+    assert bits_equal(N(out["fill_mask"]), g["fill_mask"]) == 0
+    assert max_abs(N(out["flow_mix"]), g["flow_mix"]) < 1e-4
+    dfr = np.abs(N(out["frame_mix"]).astype(np.int32) - g["frame_mix"].astype(np.int32))
+    assert dfr.max() <= 1 and (dfr > 0).mean() < 2e-3
+    assert bits_equal(N(out["src_np"]), g["src_np"]) == 0
+    ovl = pipeline.OverlappedPairRenderer(S, H, W, dev, merge_in_launch=True)
+    prep = ovl.prepare(g["K"], g["disparity"], [g["G_cam"], g["G_dyn"]])
+    res = [ovl.push(T(g["mpi"], dev), T(g["image"], dev), prep, T(g["obj_mask"], dev)) for _ in range(3)]
+    res = [x for x in res if x is not None] + ovl.flush()
+    assert len(res) == 3
+    for d in res:
+        for k, a in zip(("flow_mix", "frame_mix", "fill_mask"), d):
+            assert torch.equal(a, out[k]), k
+
+
 @pytest.mark.parametrize("name", ["c1_white", "c2_white", "c2_smooth"])
 def test_pair_vs_reference_golden_config_shapes(dev, name):
     """BASELINE configs 1 and 2/3 at full size (32x384x512, 64x640x960): inputs regenerated from the recorded seed."""
@@ -294,6 +325,47 @@ def test_forward_warp_random_vs_oracle(dev, oracle, h, w, spread):
         finally:
             _lib.check(lib.mpf_tune(b"fwarp_path", 0))
         assert bits_equal(N(got2), want) == 0, path
+    # caller-supplied targets choose between gather and radix ON THE DEVICE (the bucket visits pass 1 counts against a threshold): both sides of that gate
+    for gate in (0, 2 ** 31 - 1):                          # 0: the radix launches behind the gate do the work; huge: the gather always does
+        try:
+            _lib.check(lib.mpf_tune(b"fwarp_gate", gate))
+            got3 = ops.forward_warp(T(src, dev), T(idx, dev), T(idy, dev), T(z, dev), h, w)
+        finally:
+            _lib.check(lib.mpf_tune(b"fwarp_gate", -1))
+        assert bits_equal(N(got3), want) == 0, gate
+
+
+def test_forward_warp_scattered_targets_stay_linear(dev, oracle):
+    """Uniformly random targets over the whole frame (every 64-source slab's key range spans the image): the gather path alone would re-read all N keys for every
+    bucket of 256 targets - O(N^2 / 256), about 70 GB at 2048 x 2048 - so the device-side gate hands the call to the radix path.  Same bytes as the serial C, and
+    the call stays within a small multiple of the radix path's own time."""
+    import time
+    from mpiflow_amd import _lib, ops
+    lib = _lib.load()
+    h, w = 2048, 2048
+    n = h * w
+    rs = np.random.RandomState(5)
+    idx, idy = rs.randint(0, w, n).astype(np.int64), rs.randint(0, h, n).astype(np.int64)
+    z = (rs.randint(0, 64, n) * 0.25 + 0.5).astype(np.float32)
+    src = rs.randint(0, 256, n * 3).astype(np.uint8)
+    a = (T(src, dev), T(idx, dev), T(idy, dev), T(z, dev))
+
+    def timed():
+        ops.forward_warp(*a, h, w)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = ops.forward_warp(*a, h, w)
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+    got, t_default = timed()
+    assert bits_equal(N(got), oracle.forward_warping(src, idx, idy, z, h, w)) == 0
+    try:
+        _lib.check(lib.mpf_tune(b"fwarp_path", 1))
+        got1, t_radix = timed()
+    finally:
+        _lib.check(lib.mpf_tune(b"fwarp_path", 0))
+    assert torch.equal(got, got1)
+    assert t_default < 4 * t_radix + 2e-3, (t_default, t_radix)        # (the ungated gather: seconds)
 
 
 def test_forward_warping_ffi_symbol_host_pointers(dev, oracle):

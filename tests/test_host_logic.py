@@ -252,6 +252,24 @@ def test_batched_host_algebra_is_bit_identical_to_single_evaluations():
     for i, G in enumerate(poses):
         a, b = host_math.homographies(G, k_inv, K, d)
         assert torch.equal(H_ts[i], a) and torch.equal(H_st[i], b)
+    # bench.py's timed host work (--host-prep window): 8 pairs = 16 poses x 64 planes in ONE evaluation, against the per-pose ones
+    K = torch.from_numpy(synth.intrinsics(640, 960))
+    k_inv = host_math.k_inverse(K)
+    d = host_math.plane_depths(torch.from_numpy(synth.plane_disparities(64)))
+    rng = _random.Random(7)
+    params = []
+    for _ in range(8):
+        params += [host_math.draw_pose_parameters(0.15, rng=rng), host_math.draw_pose_parameters(0.15, base_motions=(0, 0, 0), rng=rng)]
+    rng = _random.Random(7)
+    singles = []
+    for _ in range(8):
+        singles += [host_math.generate_random_pose(0.15, rng=rng), host_math.generate_random_pose(0.15, base_motions=(0, 0, 0), rng=rng)]
+    G = host_math.poses_from_parameters(params)
+    assert all(torch.equal(G[i], singles[i]) for i in range(16))
+    H_ts, H_st = host_math.homographies_multi(list(G), k_inv, K, d)
+    for i in range(16):
+        a, b = host_math.homographies(singles[i], k_inv, K, d)
+        assert torch.equal(H_ts[i], a) and torch.equal(H_st[i], b)
 
 
 def test_reference_named_entry_points_share_the_generator_cli():

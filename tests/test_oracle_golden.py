@@ -197,6 +197,23 @@ def test_render_pair_small(oracle, name):
     assert bits_equal(out["src_np"], g["src_np"]) == 0
 
 
+def test_render_pair_on_the_reference_networks_own_stack(oracle):
+    """e2e_loop_body.npz: the reference's loop body end to end (its network's output through its render, gen_3dphoto_dynamic_v2.py:82-118).  The oracle on
+    the network-shaped stack (sigma = relu(x * cum_mask) + 1e-4, not a synthetic draw): same bars as the synthetic goldens, and the margin band of this
+    fixture is EMPTY, so both thresholded masks compare on every pixel."""
+    g = load_golden("e2e_loop_body")
+    assert g["margin_px_cam"].size == 0 and g["margin_px_dyn"].size == 0
+    out = oracle.render_pair(g["image"], g["obj_mask"], g["mpi"], g["disparity"], g["K"], g["G_cam"], g["G_dyn"])
+    _check_pair_against_golden(out, g)
+    assert bits_equal(out["src_np"], g["src_np"]) == 0
+    assert bits_equal(out["fill_mask"], g["fill_mask"]) == 0
+    for tag, v in (("cam", out["view_cam"]), ("dyn", out["view_dyn"])):
+        assert max_abs(v["rgb"], g[tag + "_rgb"]) < 2e-6
+        assert max_abs(v["objmask"], g[tag + "_objmask"]) < 2e-6
+        assert bits_equal(v["objmask"] >= np.float32(0.99), g[tag + "_objmask"] >= np.float32(0.99)) == 0
+    assert max_abs(out["flows"][0], g["cam_flow"]) < 5e-5 and max_abs(out["flows"][1], g["dyn_flow"]) < 5e-5
+
+
 @pytest.mark.parametrize("name,tol_flow", [("c1_white", 1e-4), ("c1_opaque", 1e-4)])
 def test_render_pair_config_shape(oracle, name, tol_flow):
     """BASELINE config 1 shape (32 x 384 x 512): inputs regenerated from the seed, outputs checked at the recorded

@@ -499,6 +499,51 @@ def test_render_of_the_precise_stacks_matches_the_mirror():
           "max |flow|:", float(ref64["flow_mix"].abs().max()))
 
 
+# e2e_loop_body.npz: (mean, 99.9th percentile, max) of |engine's loop body - the reference's loop body|.  The reference's own fp32 network sits at
+# rgb 2.5e-8 / 1.8e-7 / 3.0e-7 and flow 1.1e-6 / 1.1e-5 / 1.8e-5 px from the fp64 mirror's stack rendered by the oracle on this fixture (0 fill-mask flips)
+E2E_BARS = {"fp64": dict(rgb=(2e-7, 2e-6, 1e-5), flow=(1e-5, 1e-4, 1e-4), flips=0),
+            "fp32": dict(rgb=(1e-6, 2e-5, 1e-4), flow=(5e-5, 1e-3, 5e-3), flips=8)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp64", "fp32", "fp32-mfma"])
+def test_engines_end_to_end_against_the_reference_loop_body(mode):
+    """The product's loop body - parity-grade engine -> render_pair, from the SAME resized image / disparity / mask / poses - against the reference's own
+    (its fp32 CPU network through its own render_3dphoto_dynamic, gen_3dphoto_dynamic_v2.py:82-118; tests/golden/make_golden.py e2e).  On this fixture
+    the reference's fp32 network is within 3e-6 of exact arithmetic, so the north star's bars hold literally: fp64 engine -> rgb 1e-5, flow 1e-4 px, fill
+    mask and both thresholded masks bit-equal; fp32 engine -> rgb 1e-4, fill-mask flips counted."""
+    from mpiflow_amd import pipeline
+    from mpiflow_amd.model import MPIPredictor
+    from mpiflow_amd.model.precise import PrecisePredictor
+    dev = _gpu()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_loop_body.npz"))
+    S, H, W = int(g["S"]), int(g["H"]), int(g["W"])
+    m = MPIPredictor(W, H, S).randomize_(int(g["seed"])).eval().to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    pp = PrecisePredictor(m, dtype=torch.float64 if mode == "fp64" else torch.float32, x3=mode == "fp32")
+    raw, cum, disp = pp(t(g["image"])[None], t(g["disp"])[None, None])
+    assert torch.equal(disp.cpu(), torch.from_numpy(g["disparity"]))
+    rgb_a, sig_a = _act(raw.cpu(), cum.cpu())
+    st_rgb, st_sig = _stats(rgb_a, torch.from_numpy(g["mpi"][:, :3]).double()), _stats(sig_a, torch.from_numpy(g["mpi"][:, 3]).double())
+    out = pipeline.render_pair(t(g["image"]), t(g["obj_mask"]), raw.float().contiguous(), g["disparity"], g["K"], g["G_cam"], g["G_dyn"], cum_mask=cum.float().contiguous())
+    torch.cuda.synchronize()
+    rep = dict(stack_rgb=st_rgb, stack_sigma=st_sig)
+    for k, a, b in (("rgb_cam", out["view_cam"]["rgb"], g["cam_rgb"]), ("rgb_dyn", out["view_dyn"]["rgb"], g["dyn_rgb"]), ("flow_mix", out["flow_mix"], g["flow_mix"])):
+        rep[k] = _stats(a.cpu().double(), torch.from_numpy(b).double())
+    flips = int((out["fill_mask"].cpu().numpy() != g["fill_mask"]).sum())
+    mflips = sum(int(((out[v]["objmask"].cpu().numpy() >= np.float32(0.99)) != (g[tag + "_objmask"] >= np.float32(0.99))).sum()) for v, tag in (("view_cam", "cam"), ("view_dyn", "dyn")))
+    dfr = np.abs(out["frame_mix"].cpu().numpy().astype(np.int32) - g["frame_mix"].astype(np.int32))
+    print("loop body on the %s engine vs the reference's (mean, p99.9, max):" % mode, rep, "fill-mask flips:", flips, "of", int(g["fill_mask"].astype(bool).sum()),
+          "rendered-mask flips:", mflips, "frame_mix: max", int(dfr.max()), "share > 0 %.2e" % float((dfr > 0).mean()), "max |flow| %.1f" % float(np.abs(g["flow_mix"]).max()))
+    bars = E2E_BARS["fp64" if mode == "fp64" else "fp32"]
+    for k in ("rgb_cam", "rgb_dyn"):
+        assert all(a <= b for a, b in zip(rep[k], bars["rgb"])), (k, rep[k], bars["rgb"])
+    assert all(a <= b for a, b in zip(rep["flow_mix"], bars["flow"])), (rep["flow_mix"], bars["flow"])
+    assert flips <= bars["flips"] and mflips <= bars["flips"], (flips, mflips)
+    assert int(dfr.max()) <= 1
+    assert torch.equal(out["src_np"].cpu(), torch.from_numpy(g["src_np"]))
+
+
 @pytest.mark.gpu
 def test_precise_engine_rejects_bad_arguments():
     import ctypes

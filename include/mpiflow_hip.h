@@ -31,12 +31,13 @@
 extern "C" {
 #endif
 
-#define MPF_VERSION 503   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
+#define MPF_VERSION 601   /* round 3 (301): + mpf_warp_views_and_blend_next, mpf_warp_composite_split, mpf_src_flow, mpf_merge_depth_ordered;
                              round 4 (401): + mpf_moving_object_chain, mpf_warp_views_blend_next_merge_prev, mpf_stream_create_cu_subset / _destroy,
                              mpf_encoder_input, mpf_conv2d_f32, mpf_maxpool3x3s2_f32; MpfConvArgs + plane_major, loaders 4 / 5, epilogues 4 / 5 / 6;
                              round 5 (501): + the parity-grade producer engine mpf_pconv, mpf_pfmn_input, mpf_pencoder_input, mpf_pbilinear2x, mpf_pper_plane,
                              mpf_pplane_masks, mpf_pmaxpool3x3s2; MpfMergeArgs + obj_mask_stride, mpf_merge_ex, mpf_src_flow_hard;
-                             (503): MpfConvArgs + bprime_table, pw (planes per workgroup of the few-block layers) */
+                             (503): MpfConvArgs + bprime_table, pw (planes per workgroup of the few-block layers);
+                             round 6 (601): + loader 6 (MPF_CONV_LD_NEAREST_PHASE), mpf_tune("fwarp_gate"), mpf_forward_warp_workspace + 256 bytes */
 
 /* d_params layout (floats):
  *   [0..8]   K_src^-1 (3x3 row-major)            [9..20]  G_tgt_src rows 0..2 (3x4 row-major: R | t)
@@ -350,6 +351,10 @@ int mpf_moving_object_chain(const float *d_disp, const float *h_inv_k9, const fl
 #define MPF_CONV_LD_FMN_SYNTH      4   /* the feature-mask network's first layer never materialised: channels = relu(A' + plane_vals[s] * B'), srcA = A', srcB = B',
                                          both f32 [Hin,Win,16] (A' = its pre-activation output for plane value 0, B' = the plane channel's share) */
 #define MPF_CONV_LD_BILINEAR_SYNTH 5   /* LD_BILINEAR_CAT whose skip source is synthesised the same way: srcB = A', cm = B' f32 [Hin,Win,16], CB = 16 */
+#define MPF_CONV_LD_NEAREST_PHASE   6   /* LD_NEAREST_PLANE with HA = Hin / 2, reflection padding, PHASE-DECOMPOSED: on the upsampled source the 3x3 window of an output pixel covers
+                                            2 x 2 distinct srcA pixels, chosen - with host-summed weights - by the pixel's phase (y & 1, x & 1); 4 taps instead of 9 there, the skip
+                                            source as in LD_NEAREST_PLANE.  Chunks: ceil(CA / ct) of srcA, then ceil(CB / ct) of the skip; wpack = [chunkA][phase 2 py + px][ksteps(4 taps)]
+                                            [nblk][64][8] ++ [chunkB][ksteps(9 taps)][nblk][64][8]  (engine.py: pack_weights_up).  Gated epilogues 2 / 6 only */
 #define MPF_CONV_EP_AFFINE_RELU      0   /* out f16 [S,Hout,Wout,Cst] = relu(acc * ep[0][row] + ep[1][row]) */
 #define MPF_CONV_EP_AFFINE_RELU_F32  1   /* same, output channel 0 only, out f32 [S,Hout,Wout] */
 #define MPF_CONV_EP_GATED_ELU        2   /* g = (accF + ep[0][rowF]) * sigmoid(accM + ep[0][rowM]); out f16 NHWC = elu(g * ep[1][rowF] + ep[2][rowF]) */

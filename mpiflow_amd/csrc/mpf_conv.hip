@@ -47,6 +47,7 @@ constexpr int LD_BILINEAR_CAT = MPF_CONV_LD_BILINEAR_CAT;
 constexpr int LD_NEAREST_PLANE = MPF_CONV_LD_NEAREST_PLANE;
 constexpr int LD_FMN_SYNTH = MPF_CONV_LD_FMN_SYNTH;
 constexpr int LD_BILINEAR_SYNTH = MPF_CONV_LD_BILINEAR_SYNTH;
+constexpr int LD_NEAREST_PHASE = MPF_CONV_LD_NEAREST_PHASE;
 constexpr bool is_bilinear(int loader) { return loader == LD_BILINEAR_CAT || loader == LD_BILINEAR_SYNTH; }
 constexpr int EP_AFFINE_RELU = MPF_CONV_EP_AFFINE_RELU;
 constexpr int EP_AFFINE_RELU_F32 = MPF_CONV_EP_AFFINE_RELU_F32;
@@ -539,8 +540,219 @@ void k_conv3x3(const MpfConvArgs a, const int prefetch)
         __syncthreads();
         eprows = reinterpret_cast<const float *>(tile);
     }
+#define MPF_EP_PIXEL(g) const int gi = wave * PG + (g), gy = gi / GPR, gx = (gi - gy * GPR) * 16; const int oy = oy0 + gy, ox = ox0 + gx + pi;
 #include "mpf_conv_epilogue.inc"
+#undef MPF_EP_PIXEL
     }   // planes of this workgroup
+}
+
+
+// ---- the x2-nearest layers, phase-decomposed ----------------------------------------------------------------------------------
+// upconv(i, 1) of the decoder (model/CPN/decoder.py:19-20,156-162) convolves cat(nearest_x2(x), skip) under reflection padding.  On the upsampled part the
+// 3x3 window of an output pixel covers only 2 x 2 DISTINCT low-resolution pixels, and which ones - and with which sums of the nine weights - depends only on
+// the output pixel's phase (py, px) = (y & 1, x & 1):
+//     py = 0: rows (y/2 - 1, y/2) with weights (w[0], w[1] + w[2]);   py = 1: rows (y/2, y/2 + 1) with (w[0] + w[1], w[2]);   columns alike
+// and reflection padding of the upsampled map is CLAMPING of the low-resolution index (row -1 reflects to row 1 = low-resolution row 0; row Hin to Hin - 2 =
+// low-resolution row HA - 1).  So the layer is FOUR 2x2 convolutions on the low-resolution map - host-summed weights, 4 taps instead of 9, a 6 x 18 tile
+// instead of 10 x 34 staged per chunk - plus the ordinary 3x3 on the skip channels, accumulated in the same registers.
+//   * a wave owns ONE phase: its four pixel groups are the tile's four low-resolution rows, 16 low-resolution columns each (output pixels two apart);
+//     the upsampled chunks' A fragments are that phase's own (nothing to share between the waves: loaded per wave, one coalesced 1 KB read each),
+//     the skip chunks' go through LDS once per workgroup as in k_conv3x3;
+//   * the skip chunks' B fragments are 16 pixels TWO apart in the 10 x 34 tile: the pixel stride of the stride-2 layers keeps their ds_read_b128 conflict-free.
+// Chunks: first the ceil(CA / CT) upsampled ones (virtual width padded to whole chunks), then the skip's.  wpack = [chunkA][phase][KSA][nblk][64][8] ++
+// [chunkB][KS][nblk][64][8] (mpiflow_amd/model/engine.py: pack_weights_up).
+template <int CT, int EPI, int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB <= 2 ? 3 : (NB <= 6 ? 2 : 1))))
+void k_conv3x3_up(const MpfConvArgs a)
+{
+    constexpr int TH = 8, TW = 32, PG = 4, VPP = CT / 8;
+    constexpr int LW = TW + 2, LH = TH + 2, PIXB = pix_stride_bytes(CT, 2);          // skip chunks: full-resolution tile, fragment lanes two pixels apart
+    constexpr int LWA = TW / 2 + 2, LHA = TH / 2 + 2, PIXA = pix_stride_bytes(CT, 1); // upsampled chunks: low-resolution tile
+    constexpr int KS = (9 * CT + 31) / 32, TPS = 32 / CT, KSA = (4 * CT + 31) / 32;
+    constexpr int PPT = 256 / VPP, NI = (LH * LW + PPT - 1) / PPT, NIA = (LHA * LWA + PPT - 1) / PPT;
+    constexpr int WVEC = KS * NB * 64, NW = (WVEC + 255) / 256;
+    constexpr int TB = LH * LW * PIXB, TA = LHA * LWA * PIXA;
+    constexpr int TILE_BYTES = ((TB > TA ? TB : TA) + 255) / 256 * 256;
+    constexpr int WL_BYTES = KS * NB * 1024;
+    constexpr bool EP_GATED = true;
+    constexpr int EPN = EPI == EP_GATED_ELU_PAIRED ? NB * 8 : (NB / 2) * 16;
+    static_assert(EPI == EP_GATED_ELU || EPI == EP_GATED_ELU_PAIRED, "the x2-nearest layers are the decoder's gated convolutions");
+    static_assert(2 * EPN <= 256, "one epilogue value per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *tile = lds, *wlds = lds + TILE_BYTES;
+    float *eplds = reinterpret_cast<float *>(lds + TILE_BYTES + WL_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int py = wave >> 1, px = wave & 1;                  // this wave's phase
+    const int s = (int)blockIdx.z / a.ncg, cg = (int)blockIdx.z - s * a.ncg;
+    if (tid < 2 * EPN) {
+        const int row = tid / EPN, c = tid - row * EPN;
+        eplds[tid] = a.ep[(row + 1) * (a.nblk * 16) + cg * (NB * 16) + c];
+    }
+    const int ox0 = (int)blockIdx.x * TW, oy0 = (int)blockIdx.y * TH;
+    const int ix0 = ox0 - 1, iy0 = oy0 - 1, ax0 = (ox0 >> 1) - 1, ay0 = (oy0 >> 1) - 1;
+    const int sv = tid % VPP, sp = tid / VPP;
+    const unsigned va = (unsigned)a.CA >> 3, vb = (unsigned)a.CB >> 3, nf = vb ? vb - 1 : 0u;
+    const int nchunkA = (a.CA + CT - 1) / CT;
+
+    // staging slots: the low-resolution pixels of the upsampled chunks (clamped = reflection of the upsampled map) and the full-resolution ones of the skip chunks
+    unsigned aidx[NIA];
+#pragma unroll
+    for (int k = 0; k < NIA; ++k) {
+        const int p = sp + k * PPT, ly = p / LWA, lx = p - ly * LWA;
+        const int ya = min(max(ay0 + ly, 0), a.HA - 1), xa = min(max(ax0 + lx, 0), a.WA - 1);
+        aidx[k] = (unsigned)((s * a.HA + ya) * a.WA + xa);
+    }
+    Stage<LD_NEAREST_PLANE> stage[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int p = sp + k * PPT, ly = p / LW, lx = p - ly * LW;
+        stage_init<LD_NEAREST_PLANE>(stage[k], a, s, iy0 + ly, ix0 + lx, p < LH * LW);
+    }
+    if (a.CB) {
+        float cmv[NI], fmv[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const size_t o = (size_t)s * a.Hin * a.Win + stage[k].ib;
+            cmv[k] = a.cm[o];
+            fmv[k] = a.fm[o];
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            stage[k].cm2 = __float2half2_rn(cmv[k]);
+            stage[k].masks = pack2(cmv[k], fmv[k]);
+        }
+    }
+    const int q = lane >> 4, pi = lane & 15;
+    int tapA[KSA], tapB[KS];
+#pragma unroll
+    for (int ks = 0; ks < KSA; ++ks) {
+        int slot = ks * TPS + q / VPP;
+        slot = slot > 3 ? 3 : slot;
+        const int ty = slot >> 1, tx = slot & 1;
+        tapA[ks] = ((py + ty) * LWA + pi + px + tx) * PIXA + (q % VPP) * 16;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        int slot = ks * TPS + q / VPP;
+        slot = slot > 8 ? 8 : slot;
+        const int ky = slot / 3, kx = slot - ky * 3;
+        tapB[ks] = ((py + ky) * LW + 2 * pi + px + kx) * PIXB + (q % VPP) * 16;
+    }
+    const unsigned wstride = (unsigned)a.nblk * 64u;
+    const u32x4 *wA = (const u32x4 *)a.wpack + (unsigned)(cg * NB) * 64u + (unsigned)lane;                 // + ((chunk * 4 + phase) * KSA + ks) * wstride + b * 64
+    const u32x4 *wB = (const u32x4 *)a.wpack + (size_t)nchunkA * 4u * KSA * wstride + (unsigned)(cg * NB) * 64u;
+
+    f32x4 acc[PG][NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float *bias = a.ep + (cg * NB + b) * 16 + 4 * q;
+        const f32x4 init = f32x4{bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+        for (int g = 0; g < PG; ++g) acc[g][b] = init;
+    }
+
+    // ---- upsampled chunks: 2x2 taps on the low-resolution tile, this wave's phase weights ----
+    for (int chunk = 0; chunk < nchunkA; ++chunk) {
+        if (chunk) __syncthreads();
+        const unsigned vv = (unsigned)(chunk * VPP + sv);
+        u32x4 st[NIA];
+#pragma unroll
+        for (int k = 0; k < NIA; ++k) st[k] = vv < va ? ((const u32x4 *)a.srcA)[(size_t)aidx[k] * va + vv] : zero4();
+        const u32x4 *wk = wA + (unsigned)((chunk * 4 + wave) * KSA) * wstride;
+        h8 af[KSA][NB];
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                u32x4 w = wk[(unsigned)ks * wstride + (unsigned)(b * 64)];
+                af[ks][b] = *reinterpret_cast<h8 *>(&w);
+            }
+#pragma unroll
+        for (int k = 0; k < NIA; ++k) {
+            const int p = sp + k * PPT;
+            if (NIA * PPT == LHA * LWA || p < LHA * LWA) *reinterpret_cast<u32x4 *>(tile + p * PIXA + sv * 16) = st[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks) {
+#pragma unroll
+            for (int g = 0; g < PG; ++g) {
+                u32x4 bv = *reinterpret_cast<const u32x4 *>(tile + g * LWA * PIXA + tapA[ks]);
+                h8 bf = *reinterpret_cast<h8 *>(&bv);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][b], bf, acc[g][b], 0, 0, 0);
+            }
+        }
+    }
+    // ---- skip chunks: the ordinary 3x3 on the full-resolution tile (shared features x context mask, the two masks) ----
+    for (int chunk = nchunkA; chunk < a.nchunk; ++chunk) {
+        if (chunk) __syncthreads();
+        const int cb = chunk - nchunkA;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const unsigned vbase = (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 64 + j * 256);
+            if (NW * 256 == WVEC || vbase < WVEC) {
+                const unsigned v = vbase + (unsigned)lane;
+                const unsigned ks = v / (NB * 64), r = v - ks * (NB * 64);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wB + ((unsigned)(cb * KS + ks) * wstride + r)),
+                                                 (__attribute__((address_space(3))) void *)(wlds + vbase * 16), 16, 0, 0);
+            }
+        }
+        const unsigned vq = (unsigned)(cb * VPP + sv);
+        const bool isF = vq < nf, isM = vb && vq == nf;
+        u32x4 st[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) st[k] = isF ? ((const u32x4 *)a.srcB)[(size_t)stage[k].ib * nf + vq] : zero4();
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            u32x4 f = st[k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = as_u32(__hmul2(as_h2(f[i]), stage[k].cm2));
+            f[0] = isM ? stage[k].masks : f[0];
+            const int p = sp + k * PPT;
+            if (NI * PPT == LH * LW || p < LH * LW) *reinterpret_cast<u32x4 *>(tile + p * PIXB + sv * 16) = select4(stage[k].ok, f);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the fragments' LDS-DMA: the issuing wave's wait, in front of the barrier (see k_conv3x3)
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            h8 af[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                u32x4 w = *reinterpret_cast<const u32x4 *>(wlds + ((ks * NB + b) * 64 + lane) * 16);
+                af[b] = *reinterpret_cast<h8 *>(&w);
+            }
+#pragma unroll
+            for (int g = 0; g < PG; ++g) {
+                u32x4 bv = *reinterpret_cast<const u32x4 *>(tile + 2 * g * LW * PIXB + tapB[ks]);
+                h8 bf = *reinterpret_cast<h8 *>(&bv);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[b], bf, acc[g][b], 0, 0, 0);
+            }
+        }
+    }
+    const float *eprows = eplds;
+#define MPF_EP_PIXEL(g) const int oy = oy0 + 2 * (g) + py, ox = ox0 + 2 * pi + px;
+#include "mpf_conv_epilogue.inc"
+#undef MPF_EP_PIXEL
+}
+
+template <int CT, int EPI, int NB>
+int launch_up(const MpfConvArgs &a, hipStream_t st)
+{
+    constexpr int TB = 10 * 34 * pix_stride_bytes(CT, 2), TA = 6 * 18 * pix_stride_bytes(CT, 1), KS = (9 * CT + 31) / 32;
+    constexpr int EPN = EPI == EP_GATED_ELU_PAIRED ? NB * 8 : (NB / 2) * 16;
+    constexpr int LDS_BYTES = ((TB > TA ? TB : TA) + 255) / 256 * 256 + KS * NB * 1024 + 2 * EPN * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "tile + weights exceed the LDS of a CU");
+    static bool attr_set = false;
+    if (!attr_set && LDS_BYTES > 64 * 1024) {
+        MPF_HIP(hipFuncSetAttribute((const void *)k_conv3x3_up<CT, EPI, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid((a.Wout + 31) / 32, (a.Hout + 7) / 8, a.S * a.ncg);
+    hipLaunchKernelGGL((k_conv3x3_up<CT, EPI, NB>), grid, dim3(256), LDS_BYTES, st, a);
+    return mpf_launch_status("k_conv3x3_up");
 }
 
 int g_conv_pf = 1;                // mpf_tune("conv_pf", 0 | 1): the walking kernels prefetch the next step's fragments / raw tile (scheduling only, same results)
@@ -750,6 +962,19 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
     MPF_REQUIRE(a.loader != LD_BILINEAR_SYNTH || (size_t)a.Hin * a.Win < (1u << 27), "mpf_conv3x3_f16: LD_BILINEAR_SYNTH packs the pixel index into 27 bits");
     MPF_REQUIRE(a.plane_major ? ((a.Wout + 31) / 32 <= 65535 && (a.Hout + 3) / 4 <= 65535) : (size_t)a.S * a.ncg <= 65535, "mpf_conv3x3_f16: grid dimension limit exceeded");
     const int nb = a.nblk / a.ncg;
+    if (a.loader == LD_NEAREST_PHASE) {
+        MPF_REQUIRE(a.stride == 1 && a.pad_mode == 1 && a.CA > 0 && a.srcA && a.Hin == 2 * a.HA && a.Win == 2 * a.WA, "mpf_conv3x3_f16: the phase-decomposed loader is the x2-nearest, reflection-padded layer");
+        MPF_REQUIRE(a.CB == 0 || (a.srcB && a.cm && a.fm && a.CB >= 16), "mpf_conv3x3_f16: the skip source needs its features and both masks");
+        MPF_REQUIRE(a.nchunk == (a.CA + a.ct - 1) / a.ct + (a.CB + a.ct - 1) / a.ct, "mpf_conv3x3_f16: chunk count of the phase-decomposed layer (whole chunks per source)");
+        MPF_REQUIRE(a.pw <= 1 && !a.plane_major, "mpf_conv3x3_f16: the phase-decomposed kernel neither walks planes nor reorders the grid");
+        if (a.epi == EP_GATED_ELU && a.ct == 32 && nb == 4) return launch_up<32, EP_GATED_ELU, 4>(a, st);
+        if (a.epi == EP_GATED_ELU && a.ct == 16 && nb == 6) return launch_up<16, EP_GATED_ELU, 6>(a, st);
+        if (a.epi == EP_GATED_ELU && a.ct == 16 && nb == 4) return launch_up<16, EP_GATED_ELU, 4>(a, st);
+        if (a.epi == EP_GATED_ELU && a.ct == 16 && nb == 2) return launch_up<16, EP_GATED_ELU, 2>(a, st);
+        if (a.epi == EP_GATED_ELU_PAIRED && a.ct == 16 && nb == 3) return launch_up<16, EP_GATED_ELU_PAIRED, 3>(a, st);
+        mpf_set_error("mpf_conv3x3_f16: phase-decomposed layer with epilogue=%d ct=%d blocks=%d is not built", a.epi, a.ct, nb);
+        return MPF_ERR_UNSUPPORTED;
+    }
     const int key = a.loader * 1000 + a.epi * 100 + a.ct * 1 + a.stride * 10000;
     switch (key) {
     // feature-mask UNet (zero padding)

@@ -21,7 +21,7 @@ import torch
 
 from .. import _lib
 
-LD_FMN_INPUT, LD_DIRECT, LD_BILINEAR_CAT, LD_NEAREST_PLANE, LD_FMN_SYNTH, LD_BILINEAR_SYNTH = 0, 1, 2, 3, 4, 5
+LD_FMN_INPUT, LD_DIRECT, LD_BILINEAR_CAT, LD_NEAREST_PLANE, LD_FMN_SYNTH, LD_BILINEAR_SYNTH, LD_NEAREST_PHASE = 0, 1, 2, 3, 4, 5, 6
 EP_AFFINE_RELU, EP_AFFINE_RELU_F32, EP_GATED_ELU, EP_GATED_PLANAR_F32, EP_AFFINE_F32_NHWC, EP_GATED_PLANAR_F32_PAIRED, EP_GATED_ELU_PAIRED = 0, 1, 2, 3, 4, 5, 6
 
 
@@ -107,6 +107,60 @@ def pack_weights(w_rows, vmap, ct, device=None):
     return out.reshape(nchunk, KS, nblk, 64, 8).to(torch.float16).contiguous()
 
 
+def pack_weights_taps(w_RCT, vmap, ct, device=None):
+    """pack_weights for any tap count: w_RCT [R, Cin, T] fp32 -> fp16 [nchunk, ksteps(T), nblk, 64, 8] in MFMA A-fragment order: lane l of fragment (chunk, ks, blk)
+    holds W[row 16 blk + (l & 15)][tap ks * (32/ct) + (l >> 4) // (ct/8)][virtual channel chunk * ct + ((l >> 4) % (ct/8)) * 8 + j], zero past the last tap."""
+    R, T = w_RCT.shape[0], w_RCT.shape[2]
+    assert R % 16 == 0 and vmap.numel() % ct == 0
+    nblk, nchunk, KS, vpp, tps = R // 16, vmap.numel() // ct, (T * ct + 31) // 32, ct // 8, 32 // ct
+    dev = torch.device(device) if device is not None else w_RCT.device
+    w_RCT, vmap = w_RCT.to(dev), vmap.to(dev)
+    wv = torch.zeros(R, vmap.numel(), T + 1, dtype=torch.float32, device=dev)      # tap T = the all-zero tap
+    valid = vmap >= 0
+    wv[:, valid, :T] = w_RCT.float()[:, vmap[valid], :]
+    q = torch.arange(4)
+    slot = (torch.arange(KS)[:, None] * tps + (q[None, :] // vpp)).clamp(max=T)
+    ch = (((q % vpp) * 8)[:, None] + torch.arange(8)[None, :]).to(dev)
+    out = torch.empty(nchunk, KS, nblk, 4, 16, 8, dtype=torch.float32, device=dev)
+    wv = wv.reshape(nblk, 16, nchunk, ct, T + 1)
+    for k in range(KS):
+        for qq in range(4):
+            out[:, k, :, qq] = wv[:, :, :, ch[qq], int(slot[k, qq])].permute(2, 0, 1, 3)
+    return out.reshape(nchunk, KS, nblk, 64, 8).to(torch.float16).contiguous()
+
+
+# which of the three taps of one axis fall on the first / second of the two distinct low-resolution pixels a 3-tap window of phase p covers (k_conv3x3_up)
+_PHASE_TAPS = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+
+
+def pack_weights_up(w_rows, n_up, vmap_skip, ct, device=None):
+    """Weights of a phase-decomposed x2-nearest layer (MPF_CONV_LD_NEAREST_PHASE).  w_rows [R, Cin, 3, 3]; the first `n_up` input channels are the upsampled
+    source, the rest the skip (vmap_skip: its virtual -> real map, real indices counted from n_up).  The upsampled part becomes, per phase (py, px), a 2 x 2
+    kernel of SUMS of the nine weights (summed in fp32, rounded to fp16 once): [chunkA][phase 2 py + px][ksteps(4)][nblk][64][8]; the skip part keeps its nine
+    taps: [chunkB][ksteps(9)][nblk][64][8].  -> one flat fp16 tensor, A part first."""
+    R = w_rows.shape[0]
+    dev = torch.device(device) if device is not None else w_rows.device
+    w = w_rows.float().to(dev)
+    nchunkA = (n_up + ct - 1) // ct
+    vmapA = torch.full((nchunkA * ct,), -1, dtype=torch.long)
+    vmapA[:n_up] = torch.arange(n_up)
+    parts = []
+    phases = []
+    for py in (0, 1):
+        for px in (0, 1):
+            w4 = torch.zeros(R, n_up, 2, 2, device=dev)
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    for ky in _PHASE_TAPS[py][ty]:
+                        for kx in _PHASE_TAPS[px][tx]:
+                            w4[:, :, ty, tx] += w[:, :n_up, ky, kx]
+            phases.append(pack_weights_taps(w4.reshape(R, n_up, 4), vmapA, ct, device=dev))          # [chunkA, KSA, nblk, 64, 8]
+    parts.append(torch.stack(phases, dim=1).reshape(-1))                                               # [chunkA, phase, KSA, nblk, 64, 8]
+    if vmap_skip is not None and vmap_skip.numel():
+        parts.append(pack_weights_taps(w[:, n_up:].reshape(R, w.shape[1] - n_up, 9), vmap_skip, ct, device=dev).reshape(-1))
+    return torch.cat(parts).contiguous()
+
+
 def _bn_affine(bn):
     scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     return scale, bn.bias.detach().float() - bn.running_mean.detach().float() * scale
@@ -115,14 +169,23 @@ def _bn_affine(bn):
 class ConvLayer:
     """One packed layer + its launch."""
 
-    def __init__(self, device, *, loader, epi, stride, pad_mode, ct, vmap, rows_w, ep, nblk, ncg, Cst, CA, CB, name="", plane_major=False):
+    def __init__(self, device, *, loader, epi, stride, pad_mode, ct, vmap, rows_w, ep, nblk, ncg, Cst, CA, CB, name="", plane_major=False, n_up=0):
         self.name, self.wlds_default, self.plane_major = name, name.rstrip("sp") in _WLDS_LAYERS or name in _WLDS_LAYERS, plane_major
         self.loader, self.epi, self.stride, self.pad_mode, self.ct = loader, epi, stride, pad_mode, ct
         self.nchunk = vmap.numel() // ct
         self.nblk, self.ncg, self.Cst, self.CA, self.CB = nblk, ncg, Cst, CA, CB
         self.vmap_real = vmap
         self.rows_real = int((rows_w.reshape(rows_w.shape[0], -1).abs().sum(1) > 0).sum())     # output rows that are not padding
-        self.wpack = pack_weights(rows_w, vmap, ct, device=device).to(device)
+        if loader == LD_NEAREST_PHASE:
+            # n_up real channels of the upsampled source (CA physical, padded to 8), then the skip's CB virtual channels: whole chunks per source
+            skip = vmap[CA:] - n_up if CB else None                      # virtual -> real map of the skip part, real indices counted from n_up
+            if skip is not None:
+                skip = torch.where(vmap[CA:] >= 0, skip, torch.full_like(skip, -1))
+                skip = torch.cat([skip, torch.full(((-skip.numel()) % ct,), -1, dtype=torch.long)])
+            self.nchunk = (CA + ct - 1) // ct + (0 if skip is None else skip.numel() // ct)
+            self.wpack = pack_weights_up(rows_w, n_up, skip, ct, device=device).to(device)
+        else:
+            self.wpack = pack_weights(rows_w, vmap, ct, device=device).to(device)
         self.ep = ep.float().contiguous().to(device)
         assert self.ep.shape == (3, nblk * 16)
 
@@ -185,7 +248,7 @@ class ConvLayer:
             scale, shift = _bn_affine(bn)
             ep[1, :cout], ep[2, :cout] = scale.cpu(), shift.cpu()
             return cls(device, loader=loader, epi=EP_GATED_ELU_PAIRED, stride=1, pad_mode=1, ct=ct, vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep,
-                       nblk=3, ncg=1, Cst=pad8(cout), CA=segments[0][0], CB=(segments[1][0] if len(segments) > 1 else 0), name=name)
+                       nblk=3, ncg=1, Cst=pad8(cout), CA=segments[0][0], CB=(segments[1][0] if len(segments) > 1 else 0), name=name, n_up=segments[0][1])
         nf = max(d for d in (4, 3, 2, 1) if nf_total % d == 0)            # feature blocks per workgroup (NB = 2 nf in {2,4,6,8})
         if nf == 4:
             # the 8-block kernels hold 128 accumulator + 158 other registers: ONE wave per SIMD, nothing to hide a load behind.  With 4 blocks
@@ -216,7 +279,7 @@ class ConvLayer:
         CA, CB = segments[0][0], (segments[1][0] if len(segments) > 1 else 0)
         return cls(device, loader=loader, epi=EP_GATED_PLANAR_F32 if planar else EP_GATED_ELU, stride=1, pad_mode=1, ct=ct,
                    vmap=cls._vmap(segments, ct), rows_w=rows_w, ep=ep, nblk=nblk, ncg=ncg, Cst=cout if planar else pad8(cout),
-                   CA=CA, CB=CB, name=name)
+                   CA=CA, CB=CB, name=name, n_up=segments[0][1])
 
     # -- launch -------------------------------------------------------------------------------------------------------
     def __call__(self, S, Hin, Win, srcA=None, srcB=None, cm=None, fm=None, plane_vals=None, HA=None, WA=None, out=None, bprime_table=False):
@@ -243,7 +306,7 @@ class ConvLayer:
         a.wlds = int(_wlds(self.name, self.wlds_default))
         a.plane_major = int(self.plane_major)
         a.bprime_table = int(bool(bprime_table))
-        a.pw = _pw(self.name, S, self.nblk // self.ncg)
+        a.pw = 1 if self.loader == LD_NEAREST_PHASE else _pw(self.name, S, self.nblk // self.ncg)
         self.last_call = dict(S=S, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, HA=a.HA, WA=a.WA)
         if self.loader in (LD_BILINEAR_CAT, LD_BILINEAR_SYNTH):
             a.fparams[0] = (a.HA - 1) / (Hin - 1) if Hin > 1 else 0.0
@@ -274,7 +337,7 @@ def layer_accounting(layer):
         rd = S * Hin * Win * layer.CA * 2
     elif layer.loader == LD_BILINEAR_CAT:
         rd = S * c["HA"] * c["WA"] * layer.CA * 2 + S * Hin * Win * layer.CB * 2
-    else:                                                               # nearest-upsampled planes + shared skip features + the two fp32 masks
+    else:                                                               # nearest-upsampled planes (either loader form) + shared skip features + the two fp32 masks
         rd = S * c["HA"] * c["WA"] * layer.CA * 2 + (Hin * Win * (layer.CB - 8) * 2 + 2 * S * Hin * Win * 4 if layer.CB else 0)
     if layer.epi == EP_AFFINE_RELU_F32:
         wr = S * Hout * Wout * 4
@@ -524,6 +587,11 @@ class DecoderEngine:
         key = lambda *t: "-".join(str(tuple(t)))                     # noqa: E731
         self.up0, self.up1 = {}, {}
         dec = self.DEC
+        # upconv(i, 1): the 3x3 window over the x2-nearest source covers 2 x 2 distinct low-resolution pixels per output phase - four 2x2 convolutions with
+        # host-summed weights (k_conv3x3_up, MPF_CONV_LD_NEAREST_PHASE) instead of nine taps on a gathered full-resolution tile.  MPIFLOW_UP_PHASE=0 (or a
+        # list of layer names to keep on the gather form, "up1_0,up1_4") selects the round-5 kernels (A/B, per-layer tests).
+        off = os.environ.get("MPIFLOW_UP_PHASE", "1")
+        up_loader = lambda n: LD_NEAREST_PLANE if off == "0" or n in off.split(",") else LD_NEAREST_PHASE      # noqa: E731
         for i in range(4, -1, -1):
             blk0, blk1 = decoder.convs[key("upconv", i, 0)], decoder.convs[key("upconv", i, 1)]
             if i == 4:
@@ -534,9 +602,9 @@ class DecoderEngine:
             cx = dec[i]
             if i > 0:
                 self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx), (enc[i - 1] + 8, enc[i - 1] + 2)],
-                                loader=LD_NEAREST_PLANE, ct=_ct("up1_%d" % i, 16 if i in (1, 2, 3) else 32), name="up1_%d" % i)
+                                loader=up_loader("up1_%d" % i), ct=_ct("up1_%d" % i, 16 if i in (1, 2, 3) else 32), name="up1_%d" % i)
             else:
-                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx)], loader=LD_NEAREST_PLANE, ct=16, name="up1_0")
+                self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx)], loader=up_loader("up1_0"), ct=16, name="up1_0")
         self.disp0 = G(device, decoder.convs[key("dispconv", 0)], None, [(16, dec[0])], loader=LD_DIRECT, ct=16, planar=True, name="disp0")
 
     def shared_inputs(self, feats):

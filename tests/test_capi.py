@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_ctypes_table_matches_header(built):
     assert sorted(built.SIGNATURES) == declared_symbols()
     lib = built.load()
-    assert lib.mpf_version() == 503
+    assert lib.mpf_version() == 601
 
 
 def test_bad_arguments_return_error_codes(built):

@@ -47,6 +47,64 @@ def test_pack_weights_layout(ct, segments):
     assert got.shape == ref.shape and np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("ct,n_up,skip_real", [(16, 12, 0), (16, 24, 66), (32, 40, 30)])
+def test_phase_decomposed_weights_are_the_upsampled_convolution(ct, n_up, skip_real):
+    """MPF_CONV_LD_NEAREST_PHASE (k_conv3x3_up): conv3x3(reflection_pad(nearest_x2(x))) == four 2x2 convolutions on the CLAMP-padded low-resolution map,
+    one per output phase, with sums of the nine weights.  (a) the identity itself in double, borders included; (b) pack_weights_up's layout: the A part
+    [chunkA][phase][ksteps(4)][nblk][64][8] holds exactly those sums (fp32 sum, one rounding to fp16), the skip part the ordinary nine taps."""
+    from mpiflow_amd.model.engine import _PHASE_TAPS, pack_weights_up
+    g = torch.Generator().manual_seed(ct + n_up)
+    R, h, w = 32, 5, 7
+    W9 = torch.randn(R, n_up + skip_real, 3, 3, generator=g)
+    x = torch.randn(1, n_up, h, w, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.pad(F.interpolate(x, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"), W9[:, :n_up].double())
+    xp = F.pad(x, (1, 1, 1, 1), mode="replicate")
+    got = torch.zeros_like(ref)
+    sums = {}
+    for py in (0, 1):
+        for px in (0, 1):
+            w4, w4f = torch.zeros(R, n_up, 2, 2, dtype=torch.float64), torch.zeros(R, n_up, 2, 2)
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    for ky in _PHASE_TAPS[py][ty]:
+                        for kx in _PHASE_TAPS[px][tx]:
+                            w4[:, :, ty, tx] += W9[:, :n_up, ky, kx].double()
+                            w4f[:, :, ty, tx] += W9[:, :n_up, ky, kx]           # the packer's sums: fp32, this order, ONE rounding to fp16 afterwards
+            sums[(py, px)] = w4f
+            full = F.conv2d(xp, w4)                                         # [1, R, h + 1, w + 1]: window origin at low-resolution (y - 1, x - 1)
+            got[:, :, py::2, px::2] = full[:, :, py:py + h, px:px + w]
+    assert float((got - ref).abs().max()) < 1e-12
+    # (b) the packed layout
+    vpp, tps = ct // 8, 32 // ct
+    nchunkA, KSA, KS, nblk = (n_up + ct - 1) // ct, (4 * ct + 31) // 32, (9 * ct + 31) // 32, R // 16
+    skip = None
+    if skip_real:
+        skip = torch.cat([torch.arange(skip_real), torch.full(((-skip_real) % ct,), -1, dtype=torch.long)])
+    flat = pack_weights_up(W9, n_up, skip, ct).float()
+    nA = nchunkA * 4 * KSA * nblk * 64 * 8
+    A = flat[:nA].reshape(nchunkA, 4, KSA, nblk, 64, 8).numpy()
+    want = np.zeros_like(A)
+    for c in range(nchunkA):
+        for ph in range(4):
+            w4 = sums[(ph >> 1, ph & 1)].to(torch.float16).float().numpy()
+            for k in range(KSA):
+                for b in range(nblk):
+                    for l in range(64):
+                        q, r = l >> 4, l & 15
+                        slot = k * tps + q // vpp
+                        for j in range(8):
+                            ch = c * ct + (q % vpp) * 8 + j
+                            if slot < 4 and ch < n_up:
+                                want[c, ph, k, b, l, j] = w4[b * 16 + r, ch, slot >> 1, slot & 1]
+    assert np.array_equal(A, want)
+    if skip_real:
+        B = flat[nA:].reshape(-1, KS, nblk, 64, 8).numpy()
+        ref_b = _pack_reference(W9[:, n_up:].to(torch.float16).float().numpy(), skip.numpy(), ct)
+        assert B.shape == ref_b.shape and np.array_equal(B, ref_b)
+    else:
+        assert flat.numel() == nA
+
+
 def test_conv_args_struct_matches_header(tmp_path):
     """ctypes mirror == the C struct: compare sizeof and every offsetof through gcc."""
     import ctypes

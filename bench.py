@@ -453,10 +453,10 @@ def cpu_baseline(S, H, W, pairs, budget_s=12.0, chain=True):
                        (n, " + the moving-object chain: depth->flow projection, serial forward warp, masks" if chain else "", S, H, W, os.cpu_count(), dt))
 
 
-def sub_record(name, S, H, W, B, dev, dynamic, steps, multi_view=True, pipelined=False, moving_object=False):
+def sub_record(name, S, H, W, B, dev, dynamic, steps, multi_view=True, pipelined=False, moving_object=False, host_prep="once"):
     """One workload outside the timed region (rank 0, N=1): pairs/s plus per-kernel roofline entries from HIP-event brackets."""
     if pipelined:
-        w = PipelinedWorkload(S, H, W, B, dev, seed0=500, moving_object=moving_object)
+        w = PipelinedWorkload(S, H, W, B, dev, seed0=500, moving_object=moving_object, host_prep=host_prep)
     else:
         w = Workload(S, H, W, B, dev, dynamic, seed0=500, multi_view=multi_view, moving_object=moving_object)
     w.step(False)
@@ -827,7 +827,9 @@ def main():
                 sub.append(sub_record("c3 pipelined: Stage B of pair i + Stage A+C of pair i+1 per launch", 64, 640, 960, 4, dev, True, 5, pipelined=True))
             sub.append(sub_record("c3 + moving-object chain (SURVEY 8(d)'s full c3), serial: pair kernels one after the other + the chain's 3 launches on the same stream",
                                   64, 640, 960, 4, dev, True, 5, moving_object=True))
-            alone = sub_record("c3 render only, pipelined (no moving-object chain: the `value` of rounds 1-3)", 64, 640, 960, 8, dev, True, 10, pipelined=True)
+            # the same pairs, same host work per pair (--host-prep), WITHOUT the moving-object chain: `value` / this = what the chain costs the pair rate
+            alone = sub_record("c3 render only, pipelined (no moving-object chain: the `value` of rounds 1-3), host prep: %s" % a.host_prep, 64, 640, 960, 8, dev, True, 26,
+                               pipelined=True, host_prep=a.host_prep)
             sub.append(alone)
             if pipelined and chain:
                 # the same launch WITHOUT the chain's kernels running underneath it: what the kernel does on its own on this box (the headline
@@ -876,6 +878,7 @@ def main():
                 d = d.get(k) if isinstance(d, dict) else None
             return d if isinstance(d, (int, float)) else None
         c["pair_alone_pairs_per_s"] = _get(out, "roofline_pair_alone", "pairs_per_s")
+        c["value_over_pair_alone"] = (out["value"] / c["pair_alone_pairs_per_s"]) if c["pair_alone_pairs_per_s"] else None
         c["pair_alone_launch_ms"] = _get(out, "roofline_pair_alone", "avg_launch_ms")
         c["pairs_per_s_host_prep_once"] = _get(c, "host_prep_comparison", "once", "pairs_per_s")
         c["pairs_per_s_host_prep_per_pair"] = _get(c, "host_prep_comparison", "per-pair", "pairs_per_s")

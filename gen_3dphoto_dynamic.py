@@ -202,6 +202,9 @@ def main(argv=None):
     if opt.model_engine == "torch" and opt.model_dtype in ("fp64", "fp32-mfma"):
         raise SystemExit("gen_3dphoto_dynamic: --model-dtype %s is the HIP precise engine's (--model-engine hip)" % opt.model_dtype)
     precise_dtype = {"fp32": torch.float32, "fp32-mfma": torch.float32, "fp64": torch.float64}.get(opt.model_dtype) if opt.model_engine == "hip" else None
+    if precise_dtype is not None and rank == 0 and opt.mpi_from == "model":
+        print("note: --model-engine hip --model-dtype %s selects the PARITY-GRADE producer (mpf_pconv, ~5x the fast engine's time per image, eager launches); "
+              "`--model-dtype auto` / fp16 is the fast fp16-storage engine - until round 4 `fp32` named that one (INTEGRATION.md)" % opt.model_dtype, flush=True)
     if opt.mpi_from == "model":                                            # the reference's only producer (:52-60, :92-93)
         from mpiflow_amd.model import MPIPredictor
         if opt.ckpt_path.startswith("random:"):

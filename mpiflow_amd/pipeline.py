@@ -202,7 +202,8 @@ class OverlappedPairRenderer(_PairHostSide):
 
     LIFETIME of the caller's tensors: `mpi`, `image` and `obj_mask` are consumed by the push() they are given to (stream-ordered: they may be
     rewritten on the same stream right after it returns) - the deferred merge reads the object mask from the slot's own mask quads, not from
-    the caller's tensor.  `out` of pair i (and `moving`'s disparity / instance mask) is written / read by the launches that COMPLETE pair i,
+    the caller's tensor.  EXCEPTION - an independent chain (attach_chain(ordered=False)): the chain reads `image` and the `moving` tensors on a SIDE
+    stream, ordered only behind `moving_ready`; they must stay untouched until the handed-back set's `.ready` event (or flush()), not just until push() returns.  `out` of pair i (and `moving`'s disparity / instance mask) is written / read by the launches that COMPLETE pair i,
     i.e. inside the NEXT push() / flush() (two further push() calls with merge_in_launch): it must stay untouched until that call has been issued.
 
     attach_chain(chain): SURVEY 8(d)'s full c3 - the moving-object chain of every pair (moving_obj.MovingObjectChain: depth -> flow
@@ -256,10 +257,12 @@ class OverlappedPairRenderer(_PairHostSide):
         need = (3 if self.merge_in_launch else 2) + (max(1, int(sides)) - 1 if not ordered else 0)
         if len(chain.bufs) < need or (chain.H, chain.W) != (self.H, self.W):
             raise ValueError("attach_chain: the chain needs %d output sets (n_buffers) of %d x %d for this renderer" % (need, self.H, self.W))
-        self.chain, self.chain_ordered, self._chain_next = chain, ordered, 0
         if cu_stride and cu_stride > 1 and high_priority:
             raise ValueError("attach_chain: a CU-masked side stream (cu_stride) has no priority; give one of cu_stride / high_priority")
-        self.close()                                                  # a previously attached chain's CU-masked stream
+        if cu_stride and cu_stride > 1 and not ordered and int(sides) > 1:
+            raise ValueError("attach_chain: cu_stride masks ONE side stream; with sides > 1 the others would run on every CU - give sides=1 with cu_stride")
+        self.close()                                                  # a previously attached chain's CU-masked stream (detaches that chain)
+        self.chain, self.chain_ordered, self._chain_next = chain, ordered, 0
         if cu_stride and cu_stride > 1:
             # the side stream may only use every cu_stride-th compute unit: the chain's latency-sized workgroups then sit on few CUs instead of
             # taking a slot here and there on all of them, underneath a launch that fills the whole chip
@@ -286,7 +289,8 @@ class OverlappedPairRenderer(_PairHostSide):
             try:
                 self.side.synchronize()
             finally:
-                self.side = None
+                # the wrapper in _sides points at the destroyed stream: detach everything that could launch on it
+                self.side, self._sides, self.chain = None, [], None
                 _lib.load().mpf_stream_destroy(h)
 
     def __del__(self):

@@ -108,7 +108,10 @@ def parse():
     p.add_argument("--cpu-pairs", type=int, default=64, help="most pairs the CPU oracle renders for cpu_baseline (it stops after ~12 s of CPU work)")
     p.add_argument("--sbf-px", type=int, default=0, help="tuning: pixels/thread of Stage A+C (0 = library default)")
     p.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
-                   help="tuning: mpf_tune(KEY, INT) before anything runs (ovl_xcd_a, chain_prio, view_shift, ...); recorded in config.tune")
+                   help="tuning: mpf_tune(KEY, INT) before anything runs (chain_prio, chain_grid, conv_pf, ...); recorded in config.tune")
+    p.add_argument("--witness", action="store_true",
+                   help="run on libmpiflow_hip_witness.so (the -DMPF_WITNESS build: retired kernel variants and timing ablations, --tune ovl_xcd_a / view_shift / "
+                        "ovl_ablate / stage_b ...); recorded in config.library - a line measured on it is not the product's")
     p.add_argument("--single-view-launches", action="store_true", help="tuning: one Stage B launch per view instead of one per pair")
     return p.parse_args()
 
@@ -644,6 +647,8 @@ def main():
     # a 256-thread host took 10x its single-thread time) - one thread, as gen_3dphoto_dynamic.py runs it; restored for the CPU baseline below
     host_threads = torch.get_num_threads()
     torch.set_num_threads(1)
+    if a.witness:
+        _lib.select_witness()
     if a.sbf_px:
         _lib.check(_lib.load().mpf_tune(b"sbf_px", a.sbf_px))
     for kv in a.tune:
@@ -784,7 +789,7 @@ def main():
                                        "the chain is an independent side pipeline: each pair's moving-object results carry their own `ready` event and are NOT joined "
                                        "with the pair's render results per pair inside the timed region (no consumer runs in this bench); the side stream is joined once, "
                                        "in the timed region's final flush.  --chain-ordered 1 measures the per-pair join (round 4: +12 us per pair)") if chain and pipelined else None),
-                       "tune": a.tune,
+                       "tune": a.tune, "library": "libmpiflow_hip_witness.so (NOT the product build)" if a.witness else "libmpiflow_hip.so",
                        "host_prep": ({"window": "per pair, timed: every timed pair draws its own two poses (utils/utils.py:207-208) and gets its own per-plane homographies + fp64 "
                                                 "inverses (homography_sampler.py:105-122) INSIDE the timed region; the arithmetic is batched over the in-flight window of "
                                                 "%d pairs (one batched evaluation, one pinned upload per window - pipeline.prepare_many, bit-identical to per-pair prepare())" % B,

@@ -62,15 +62,18 @@ int mpf_device_info(int device, int *cu_count, size_t *hbm_bytes, char *arch, si
 int mpf_stream_create_cu_subset(int stride, int offset, void **out_stream);
 int mpf_stream_destroy(void *stream);
 
-/* bench/tuning knobs: "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2); "stage_b" = Stage B kernel variant; "planar_lds";
- * "ovl_depth" = planes of loads a Stage A+C wave keeps in flight inside the pair launch (4 or 8); "ovl_xcd_a"; "view_shift"; "fwarp_path" = 0 gather
- * (default) | 1 general radix path | 2 round 2's sort path; "fwarp_gate" = bucket visits above which caller-supplied targets leave the gather path for the radix path
- * (-1 = default: one visit per source; 0 = always radix); "chain_grid" / "chain_prio" (grid cap / s_setprio of the forward-warp kernels); "conv_pf" = 0 | 1 (default): the plane-walking conv kernels
- * (MpfConvArgs.pw > 1) copy the next step's weight fragments / raw tile into a second LDS buffer during the current MFMA phase.  None of
- * these changes a result - every variant is bit-identical, which the tests assert - except "ovl_ablate" and "stage_b" 101..106, which exist for
- * timing ablations only and produce INVALID outputs.  The knobs are PROCESS-GLOBAL plain ints, not per-stream and NOT thread-safe: set them from one
- * thread while no other thread is launching work through this library.  Unknown keys return MPF_ERR_BAD_ARGUMENT. */
+/* Scheduling knobs of the product library (libmpiflow_hip.so) - none of them can change a result, every setting gives the same bytes (asserted by the tests):
+ *   "sbf_px" = pixels per thread of mpf_src_blend_flow (0 auto, 1, 2);  "conv_pf" = 0 | 1 (default): the plane-walking conv kernels (MpfConvArgs.pw > 1) copy the
+ *   next step's weight fragments / raw tile into a second LDS buffer during the current MFMA phase;  "chain_grid" / "chain_prio" = grid cap / s_setprio of the
+ *   forward-warp kernels;  "fwarp_gate" = bucket visits above which caller-supplied targets leave the gather path for the radix path (-1 = default: one visit per
+ *   source; 0 = always radix).
+ * Keys that select RETIRED KERNEL VARIANTS ("stage_b", "planar_lds", "ovl_depth", "ovl_xcd_a", "view_shift", "fwarp_path": bit-identical witnesses of the shipped
+ * kernels) or TIMING ABLATIONS ("ovl_ablate", "stage_b" 101..106: INVALID results) exist only in the witness build, libmpiflow_hip_witness.so (-DMPF_WITNESS; the
+ * tests and tools load it through mpiflow_amd._lib.witness()); the product library returns MPF_ERR_BAD_ARGUMENT for them and does not contain those kernels.
+ * The knobs are PROCESS-GLOBAL plain ints, not per-stream and NOT thread-safe: set them from one thread while no other thread is launching work through this
+ * library.  Unknown keys return MPF_ERR_BAD_ARGUMENT. */
 int mpf_tune(const char *key, int value);
+int mpf_is_witness_build(void);   /* 1 for libmpiflow_hip_witness.so, 0 for the product library */
 
 /* ================= fused hot path =============================================================================== */
 

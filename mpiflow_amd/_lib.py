@@ -15,7 +15,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPIFLOW_HIP_LIB: development hook for same-box A/B timing of two builds of the library (tools/); symbols an older build lacks are skipped
 LIB_PATH = os.environ.get("MPIFLOW_HIP_LIB") or os.path.join(_HERE, "libmpiflow_hip.so")
 
+# the WITNESS build of the same sources (-DMPF_WITNESS): + retired kernel variants and timing ablations, selectable through mpf_tune keys the product library
+# refuses.  Test / tool infrastructure: the product never loads it on its own (witness() / select_witness() below).
+WITNESS_PATH = os.path.join(_HERE, "libmpiflow_hip_witness.so")
+
 _lib = None
+_witness = None
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -119,6 +124,7 @@ SIGNATURES = {
     "forward_warping": (None, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
     "mpf_forward_warping_host": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i]),
     "mpf_tune": (c_i, [ctypes.c_char_p, c_i]),
+    "mpf_is_witness_build": (c_i, []),
     "mpf_conv3x3_f16": (c_i, [ctypes.POINTER(MpfConvArgs), c_p]),
     "mpf_plane_masks": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p]),
     "mpf_encoder_input": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
@@ -136,6 +142,49 @@ SIGNATURES = {
 
 class MpiFlowHipError(RuntimeError):
     pass
+
+
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load_witness():
+    """The witness build (libmpiflow_hip_witness.so), loaded once, NOT made the library the package's calls go through (see witness())."""
+    global _witness
+    if _witness is None:
+        if not os.path.exists(WITNESS_PATH):
+            raise MpiFlowHipError("libmpiflow_hip_witness.so not found at %s - `make -C mpiflow_amd/csrc` builds it beside the product library" % WITNESS_PATH)
+        _witness = _bind(WITNESS_PATH)
+        assert _witness.mpf_is_witness_build() == 1
+    return _witness
+
+
+class witness:
+    """`with _lib.witness() as lib:` - inside the block every call of the package goes through the WITNESS build, whose mpf_tune accepts the variant / ablation
+    keys ("stage_b", "planar_lds", "fwarp_path", "ovl_depth", "ovl_xcd_a", "view_shift", "ovl_ablate").  Tests and tools only; not re-entrant, one thread."""
+
+    def __enter__(self):
+        global _lib
+        self.prev = load()
+        _lib = load_witness()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
+def select_witness():
+    """Process-wide switch to the witness build (tools/ that time retired variants; bench.py --witness)."""
+    global _lib
+    _lib = load_witness()
+    return _lib
 
 
 def load():

@@ -240,6 +240,7 @@ k_radix_hist(const uint32_t *__restrict__ keys, uint32_t N, int shift, uint32_t 
     }
 }
 
+#ifdef MPF_WITNESS            // round 2's one-pass sort + per-bucket workgroups (mpf_tune("fwarp_path", 2)): a second witness of the splat, witness build only
 // The first pass of the fast path: keys and the histogram of their high digit in one sweep over the sources (tile = SORT_TILE keys)
 template <int BITS>
 __global__ void __launch_bounds__(SORT_THREADS)
@@ -309,6 +310,8 @@ k_mo_project_keys_hist(const float *__restrict__ disp, const MpfMoProj m, const 
         }
     }
 }
+
+#endif   // MPF_WITNESS
 
 // Offsets of the scatter, two cheap steps instead of one scan over all RADIX*nb counters (which took a single workgroup 34 us
 // per pass - half of the whole forward warp): the exclusive offset of (digit d, tile b) is
@@ -430,6 +433,7 @@ static void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
     hipLaunchKernelGGL((k_radix_scatter<BITS>), dim3(nb), dim3(SORT_THREADS), 0, st, kin, vin, kout, vout, N, shift, nb, hist, totals, g_fw_prio, gate);
 }
 
+#ifdef MPF_WITNESS
 // ---- buckets: finish the sort inside each high-digit bucket and resolve it, in ONE kernel ------------------------------------
 // After ONE stable pass on the HIGH bits of the target (bucket = 2^LB consecutive targets, about an image row), a bucket's visitors
 // are contiguous and in raster order.  One workgroup per bucket then (A) counts them per target, (B) scans the counts, (C) places
@@ -588,6 +592,8 @@ k_fw_bucket(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ v
     __syncthreads();                                                           // the LDS tables are re-used by the next bucket
     }
 }
+
+#endif   // MPF_WITNESS
 
 // ---- round 5: gather instead of sort ----------------------------------------------------------------------------------------------
 #define FWG_TILE 1024             // sources per tile of pass 1 (one 256-thread workgroup, 4 per thread) = 16 slabs of 64
@@ -955,11 +961,15 @@ k_fw_write(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
     o[4] = (zprev == 1000.0f) ? 1 : 0;                                // warping.c:24-27
 }
 
+#ifdef MPF_WITNESS
 static int g_fw_path = 0;       // mpf_tune("fwarp_path", p): 0 = gather (round 5; images up to 2^24 pixels), 1 = the general multi-pass radix path (what larger
                                 // images take), 2 = round 2's one-pass sort + per-bucket workgroups (kept for A/B and as a second witness in the tests).
                                 // Process-global and not thread-safe, like every mpf_tune knob: set it before launching work, from one thread.
 
 void mpf_fwarp_set_path(int v) { g_fw_path = v; }
+#else
+static constexpr int g_fw_path = 0;     // the product build: gather (<= 2^24 pixels) with the general radix path behind it; the other paths are witnesses
+#endif
 static long long g_fw_gate_thr = -1;   // mpf_tune("fwarp_gate", t): bucket visits above which caller-supplied targets take the radix path (-1 = default, one per source;
                                        // 0 = always radix behind the gate - same results either way: the tests run both sides of it)
 void mpf_fwarp_set_gate(int v) { g_fw_gate_thr = v; }
@@ -1036,6 +1046,7 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
                            d_warped, zero_fill ? 1 : 0, planes_H, planes_M, FwGate{work, thr, false});
         gate = FwGate{work, thr, true};
     }
+#ifdef MPF_WITNESS
     if (!gate.work && bits <= 2 * RADIX_BITS_MAX && g_fw_path == 2) {
         // the fast path: one stable pass on the high bits, then one workgroup per bucket of 2^lb targets sorts and resolves it
         const int lb = bits <= 16 ? 8 : (bits <= 18 ? 9 : (bits <= 20 ? 10 : 11));
@@ -1065,6 +1076,7 @@ static int fw_run(const uint8_t *d_src, const int64_t *d_idx, const int64_t *d_i
 #undef MPF_FW_BUCKET
         return mpf_launch_status("forward_warp kernels");
     }
+#endif
     if (proj) hipLaunchKernelGGL(k_moving_object_project, dim3(g256), dim3(256), 0, st, proj->disp, proj->m, proj->inst, h, w, proj->out);
     hipLaunchKernelGGL(k_fw_keys, dim3(g256), dim3(256), 0, st, d_idx, d_idy, h, w, keys[0], vals[0], win, zero_fill ? d_warped : (uint8_t *)nullptr, gate);
     // the fewest passes of 8..11-bit digits that cover the key: 640 x 960 (20 bits) -> 2 x 10, 1024 x 1536 (21 bits) -> 2 x 11

@@ -13,6 +13,17 @@
 #include "mpf_common.h"
 #include "mpf_math.h"
 
+// PRODUCT vs WITNESS build.  libmpiflow_hip.so (the product) is built WITHOUT MPF_WITNESS: every bench-only knob is a compile-time constant there, mpf_tune refuses the
+// keys that select retired kernel variants or timing ablations, and those kernels are not compiled.  libmpiflow_hip_witness.so (-DMPF_WITNESS, loaded by the tests and
+// tools that A/B the retired forms against the shipped ones) keeps them all.  MPF_WIT(x): a run-time knob in the witness build, the constant 0 in the product.
+#ifdef MPF_WITNESS
+#define MPF_WIT(x) (x)
+#define MPF_KNOB static int
+#else
+#define MPF_WIT(x) 0
+#define MPF_KNOB static constexpr int
+#endif
+
 #define MPF_TILE_W 64   // one wavefront = 64 consecutive target pixels of one row
 #define MPF_TILE_H 4    // 4 waves per 256-thread workgroup
 
@@ -543,6 +554,7 @@ MPF_DEV void mpf_wc2_body(const float *__restrict__ rgba, const float *__restric
     }
 }
 
+#ifdef MPF_WITNESS            // timing ablations of the Stage B body (results invalid): witness build only
 template <bool HAS_MASK, int TW, int TH, int DBG>
 __global__ void __launch_bounds__(TW *TH, 4)
 k_warp_composite_dbg(const float *__restrict__ rgba, const float *__restrict__ quads, const float *__restrict__ params,
@@ -552,6 +564,7 @@ k_warp_composite_dbg(const float *__restrict__ rgba, const float *__restrict__ q
     mpf_wc2_body<HAS_MASK, 2, TW, TH, true, true, DBG>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, nullptr,
                                                        mpf_xcd_remap(blockIdx.x, gridDim.x));
 }
+#endif
 
 // Tile order: strips of MPF_STRIP_TILES tiles wide, row by row inside a strip.  With the image-wide row-major order the ~80 tiles an
 // XCD has resident at a time form a band 2-3 tile rows tall and as wide as the image; the two poses of a pair displace a tile's source
@@ -889,6 +902,7 @@ MPF_DEV void mpf_wcl_body(const float *__restrict__ rgba, const float *__restric
     }
 }
 
+#ifdef MPF_WITNESS            // rejected variants kept as witnesses (bit-identical, slower): the wave-private planar form and the LDS-staged interleaved form
 // WAVE-PRIVATE footprints (round 5; mpf_tune("planar_lds", 2)): the 32 x 8 tile as four 32 x 2 wave strips.  Every wave computes the boxes of ITS strip
 // (<= 48 x 6 texels), stages them into its own slab of LDS and reads its taps from there: the LDS traffic of a wave is ordered by the hardware, so
 // the plane loop needs NO workgroup barrier - what the workgroup-wide box pays once per plane.  The price: the four strips' row halos overlap
@@ -1096,6 +1110,7 @@ k_warp_composite_lds(const float *__restrict__ rgba, const MpfViewSet vs, const 
     else
         mpf_wcl_body<HAS_MASK, NL, false, true>(rgba, w.d_mask_quads, params, S, H, W, w.d_rgb, w.d_depth, w.d_objmask, w.d_tgt_mask, w.d_rgb_u8_bgr, tile, s_tex, s_box);
 }
+#endif   // MPF_WITNESS
 
 template <bool HAS_MASK, int NL>
 __global__ void __launch_bounds__(256, 4)
@@ -1119,11 +1134,12 @@ k_warp_composite_planar_lds(const MpfPlanarSrc src, const float *__restrict__ qu
         mpf_wcl_body<HAS_MASK, NL, false, true, true>(rgba, quads, params, S, H, W, rgb_out, depth_out, om_out, tgt_mask_out, u8_out, tile, s_tex, s_box, &src);
 }
 
-static int g_planar_lds = 1;        // mpf_tune("planar_lds", 0 | 1 | 2): Stage B on the reference's channel-planar tensors by gathers (0), through LDS-staged
+MPF_KNOB g_planar_lds = 1;          // mpf_tune("planar_lds", 0 | 1 | 2): Stage B on the reference's channel-planar tensors by gathers (0), through LDS-staged
                                     // footprints of the workgroup's tile (1) or of every wave's own strip, no barrier in the plane loop (2)
 
-static int g_stage_b_variant = 1;   // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = gather shapes, 20 = LDS-staged footprints
+MPF_KNOB g_stage_b_variant = 1;     // mpf_tune("stage_b", v): 0 = v1 reference kernel, 1.. = gather shapes, 20 = LDS-staged footprints
 
+#ifdef MPF_WITNESS
 template <bool HAS_MASK>
 static int launch_lds(const float *rgba, const MpfViewSet &vs, int V, int S, int H, int W, hipStream_t st)
 {
@@ -1131,6 +1147,7 @@ static int launch_lds(const float *rgba, const MpfViewSet &vs, int V, int S, int
     hipLaunchKernelGGL((k_warp_composite_lds<HAS_MASK, 2>), dim3(tiles * (unsigned)V), dim3(256), 0, st, rgba, vs, (unsigned)V, S, H, W);
     return mpf_launch_status("k_warp_composite_lds");
 }
+#endif
 
 
 template <bool HAS_MASK, int TW, int TH, int WPS>
@@ -1150,6 +1167,7 @@ template <bool HAS_MASK>
 static int dispatch_wc2(int variant, bool tp, const float *rgba, const float *quads, const float *params, int S, int H, int W,
                         float *rgb, float *depth, float *om, float *tm, uint8_t *u8, hipStream_t st)
 {
+#ifdef MPF_WITNESS
     if (variant >= 101 && variant <= 106) {   // bench-only ablations (invalid results)
         dim3 grid(((W + 63) / 64) * ((H + 3) / 4)), block(256);
         if (variant == 101) hipLaunchKernelGGL((k_warp_composite_dbg<HAS_MASK, 64, 4, 1>), grid, block, 0, st, rgba, quads, params, S, H, W, rgb, depth, om, tm);
@@ -1164,9 +1182,10 @@ static int dispatch_wc2(int variant, bool tp, const float *rgba, const float *qu
     case 2: return launch_wc2<HAS_MASK, 64, 4, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
     case 7: return launch_wc2<HAS_MASK, 64, 2, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
     case 9: return launch_wc2<HAS_MASK, 64, 4, 4>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
-    default:   // 32x8 target tile per workgroup (a wave = 32 px x 2 rows): measured best, the two rows of a wave share a source row
-        return launch_wc2<HAS_MASK, 32, 8, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
     }
+#endif
+    // 32x8 target tile per workgroup (a wave = 32 px x 2 rows): measured best, the two rows of a wave share a source row
+    return launch_wc2<HAS_MASK, 32, 8, 5>(tp, rgba, quads, params, S, H, W, rgb, depth, om, tm, u8, st);
 }
 
 template <bool INTERLEAVED, bool HAS_MASK>
@@ -1188,11 +1207,13 @@ static int launch_planar(const MpfPlanarSrc &src, const float *quads, const floa
                          float *tm, uint8_t *u8, hipStream_t st)
 {
     const unsigned tiles = ((W + 31) / 32) * ((H + 7) / 8);
+#ifdef MPF_WITNESS
     if (g_planar_lds == 2 && S <= MPF_WT_MAXS) {
         if (quads) hipLaunchKernelGGL((k_warp_composite_planar_wave<true, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
         else hipLaunchKernelGGL((k_warp_composite_planar_wave<false, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
         return mpf_launch_status("k_warp_composite_planar_wave");
     }
+#endif
     if (g_planar_lds && S <= MPF_LT_MAXS && S < 256) {
         if (quads) hipLaunchKernelGGL((k_warp_composite_planar_lds<true, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
         else hipLaunchKernelGGL((k_warp_composite_planar_lds<false, 2>), dim3(tiles), dim3(256), 0, st, src, quads, params, S, H, W, rgb, depth, om, tm, u8);
@@ -1230,6 +1251,7 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
     MPF_REQUIRE(!interleaved || mpf_aligned16(d_rgba), "mpf_warp_composite: interleaved stack must be 16-byte aligned");
     MPF_REQUIRE(!d_mask_quads || mpf_aligned16(d_mask_quads), "mpf_warp_composite: mask quads must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+#ifdef MPF_WITNESS
     if (interleaved == 2 && g_stage_b_variant == 20 && S <= MPF_LT_MAXS && (int64_t)H * W < ((int64_t)1 << 27)) {
         MpfViewSet vs;
         memset(&vs, 0, sizeof(vs));
@@ -1237,6 +1259,7 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
         if (d_mask_quads) return launch_lds<true>(d_rgba, vs, 1, S, H, W, st);
         return launch_lds<false>(d_rgba, vs, 1, S, H, W, st);
     }
+#endif
     if (interleaved && g_stage_b_variant > 0 && (int64_t)H * W < ((int64_t)1 << 27)) {
         const bool tp = (interleaved == 2);
         if (d_mask_quads) return dispatch_wc2<true>(g_stage_b_variant, tp, d_rgba, d_mask_quads, d_params, S, H, W, d_rgb, d_depth, d_objmask, d_tgt_mask, d_rgb_u8_bgr, st);
@@ -1261,7 +1284,7 @@ extern "C" int mpf_warp_composite(const float *d_rgba, int interleaved, const fl
 // (any of +-4 .. +-32, or a whole strip) takes 5-7 % off the two-view launch of bench.py's serial c3 pairs (302-312 -> 288-291 us, the same for
 // every sign and size tried: it is the de-synchronisation that helps, not an alignment of the footprints) and 3 % off the pair launch's L2-miss
 // traffic at unchanged time; neutral (+-1 %) for the fixed-pose launches of tools/bench_stage_b_views.py (profiles/r3/stage_b_view_shift.log).
-static int g_view_shift = 8;
+MPF_KNOB g_view_shift = 8;
 
 template <bool HAS_MASK>
 static int launch_views(bool tp, const float *rgba, const MpfViewSet &vs, int V, int S, int H, int W, hipStream_t st)
@@ -1296,10 +1319,12 @@ extern "C" int mpf_warp_composite_views(const float *d_rgba, int interleaved, co
         MPF_REQUIRE(mpf_aligned16(w.d_mask_quads), "mpf_warp_composite_views: view %d: mask quads must be 16-byte aligned", v);
         vs.v[v] = w;
     }
+#ifdef MPF_WITNESS
     if (g_stage_b_variant == 20 && interleaved == 2 && S <= MPF_LT_MAXS) {
         if (has_mask) return launch_lds<true>(d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
         return launch_lds<false>(d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
     }
+#endif
     if (has_mask) return launch_views<true>(interleaved == 2, d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
     return launch_views<false>(interleaved == 2, d_rgba, vs, n_views, S, H, W, (hipStream_t)stream);
 }
@@ -1839,13 +1864,15 @@ MPF_DEV void mpf_sbf_stream(const MpfSbfArgs &a, const int S, const int H, const
 template <bool HAS_MASK, int NL, int P, bool ACT, int DEPTH>
 __global__ void __launch_bounds__(256, 5)
 k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsigned V, const MpfSbfArgs ac, const int S, const int H, const int W,
-               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate, const unsigned view_shift, const unsigned xcd_a,
+               const unsigned nB, const unsigned nA, const unsigned KB, const unsigned KA, const int ablate_, const unsigned view_shift, const unsigned xcd_a_,
                const MpfMergeArgs mg)
 {
     constexpr int TW = 32, TH = 8;
     const unsigned xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;          // the k-th workgroup of this XCD
     bool role_a;
     unsigned ja = 0, jb = 0, l = 0;
+    const int ablate = MPF_WIT(ablate_);                                // (the product build compiles neither the ablations nor the by-XCD role split)
+    const unsigned xcd_a = MPF_WIT(xcd_a_);
     if (xcd_a) {
         // roles partitioned by XCD (mpf_tune("ovl_xcd_a", n)): the first n XCDs run Stage A+C workgroups only, the others Stage B only, so
         // the streaming role's 1.27 GB cannot evict the gather role's texel rows from the L2 they are re-used in
@@ -1882,9 +1909,9 @@ k_pair_overlap(const float *__restrict__ rgba_b, const MpfViewSet vs, const unsi
     }
 }
 
-static int g_ovl_depth = 4;     // mpf_tune("ovl_depth", 4 | 8): no measurable difference at 64x640x960 (both 492-523 us per launch on one box)
-static int g_ovl_ablate = 0;    // mpf_tune("ovl_ablate", 0 | 1 | 2): bench-only, results invalid when non-zero
-static int g_ovl_xcd_a = 0;     // mpf_tune("ovl_xcd_a", 0..7): 0 = both roles interleaved on every XCD (Bresenham), n = the first n XCDs run Stage A+C only
+MPF_KNOB g_ovl_depth = 4;       // mpf_tune("ovl_depth", 4 | 8): no measurable difference at 64x640x960 (both 492-523 us per launch on one box)
+MPF_KNOB g_ovl_ablate = 0;      // mpf_tune("ovl_ablate", 0 | 1 | 2): bench-only, results invalid when non-zero
+MPF_KNOB g_ovl_xcd_a = 0;       // mpf_tune("ovl_xcd_a", 0..7): 0 = both roles interleaved on every XCD (Bresenham), n = the first n XCDs run Stage A+C only
 
 template <bool HAS_MASK, int NL, int P, bool ACT>
 static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V, const MpfSbfArgs &ac, int S, int H, int W, hipStream_t st, const MpfMergeArgs &mg)
@@ -1900,10 +1927,13 @@ static int launch_overlap(const float *rgba_b, const MpfViewSet &vs, unsigned V,
         per_xcd = pa > pb ? pa : pb;
     }
     dim3 grid(8u * per_xcd), block(256);
-    if (g_ovl_depth == 4)
-        hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa, mg);
-    else
+#ifdef MPF_WITNESS
+    if (g_ovl_depth == 8) {
         hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 8>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa, mg);
+        return mpf_launch_status("k_pair_overlap");
+    }
+#endif
+    hipLaunchKernelGGL((k_pair_overlap<HAS_MASK, NL, P, ACT, 4>), grid, block, 0, st, rgba_b, vs, V, ac, S, H, W, nB, nA, KB, KA, g_ovl_ablate, (unsigned)g_view_shift % tiles, xa, mg);
     return mpf_launch_status("k_pair_overlap");
 }
 
@@ -2105,7 +2135,9 @@ extern "C" int mpf_src_flow(const float *d_sigma_SHW, const float *d_params, int
     return launch_sbf<1, 2>(d_sigma_SHW, nullptr, d_params, S, H, W, flow_clip, nullptr, nullptr, nullptr, d_flows, nullptr, nullptr, nullptr, nullptr, nullptr, st, N, 0);
 }
 
+#ifdef MPF_WITNESS
 void mpf_fwarp_set_path(int v);      // mpf_fwarp.hip
+#endif
 void mpf_fwarp_set_gate(int v);
 void mpf_conv_set_prefetch(int v);   // mpf_conv.hip
 void mpf_fwarp_set_prio(int v);
@@ -2113,20 +2145,35 @@ void mpf_fwarp_set_grid(int v);
 
 extern "C" int mpf_tune(const char *key, int value)
 {
+    // the product's knobs: scheduling only - launch shapes, grid caps, wave priorities, prefetch, the gather / radix gate - every setting gives the same bytes
     if (key && !strcmp(key, "sbf_px")) { g_sbf_px = value; return 0; }
+    if (key && !strcmp(key, "fwarp_gate")) { mpf_fwarp_set_gate(value); return 0; }
+    if (key && !strcmp(key, "conv_pf")) { mpf_conv_set_prefetch(value); return 0; }
+    if (key && !strcmp(key, "chain_grid")) { mpf_fwarp_set_grid(value); return 0; }
+    if (key && !strcmp(key, "chain_prio")) { mpf_fwarp_set_prio(value); return 0; }
+#ifdef MPF_WITNESS
+    // retired kernel variants (bit-identical witnesses) and timing ablations (INVALID results): libmpiflow_hip_witness.so only
     if (key && !strcmp(key, "stage_b")) { g_stage_b_variant = value; return 0; }
     if (key && !strcmp(key, "planar_lds")) { g_planar_lds = (value < 0 || value > 2) ? 1 : value; return 0; }
     if (key && !strcmp(key, "ovl_depth")) { g_ovl_depth = (value == 8) ? 8 : 4; return 0; }
     if (key && !strcmp(key, "ovl_ablate")) { g_ovl_ablate = value; return 0; }
     if (key && !strcmp(key, "view_shift")) { g_view_shift = value < 0 ? 0 : value; return 0; }
     if (key && !strcmp(key, "fwarp_path")) { mpf_fwarp_set_path(value); return 0; }
-    if (key && !strcmp(key, "fwarp_gate")) { mpf_fwarp_set_gate(value); return 0; }
-    if (key && !strcmp(key, "conv_pf")) { mpf_conv_set_prefetch(value); return 0; }
-    if (key && !strcmp(key, "chain_grid")) { mpf_fwarp_set_grid(value); return 0; }
-    if (key && !strcmp(key, "chain_prio")) { mpf_fwarp_set_prio(value); return 0; }
     if (key && !strcmp(key, "ovl_xcd_a")) { g_ovl_xcd_a = (value < 0 || value > 7) ? 0 : value; return 0; }
     mpf_set_error("mpf_tune: unknown key");
+#else
+    mpf_set_error("mpf_tune: unknown key (variant / ablation keys exist in the witness build only: libmpiflow_hip_witness.so)");
+#endif
     return MPF_ERR_BAD_ARGUMENT;
+}
+
+extern "C" int mpf_is_witness_build(void)
+{
+#ifdef MPF_WITNESS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

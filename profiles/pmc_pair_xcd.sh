@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for XA in 0 3; do
-  CMD="python $REPO/bench.py --steps 2 --warmup 1 --pairs-per-step 8 --no-cpu-baseline --no-sub --no-moving-object --tune ovl_xcd_a=$XA"
+  CMD="python $REPO/bench.py --steps 2 --warmup 1 --pairs-per-step 8 --no-cpu-baseline --no-sub --no-moving-object --witness --tune ovl_xcd_a=$XA"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_xa$XA -o b -- $CMD > $OUT/fetch_xa$XA.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_xa$XA -o b -- $CMD > $OUT/write_xa$XA.log 2>&1
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc_xa$XA -o b -- $CMD > $OUT/tcc_xa$XA.log 2>&1

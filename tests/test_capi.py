@@ -53,11 +53,40 @@ def test_bad_arguments_return_error_codes(built):
     assert lib.mpf_merge_ex(None, 4, 4, None) == 10001
     assert lib.mpf_src_flow_hard(one, 10, one, 1, 4, 8, 8, 0.0, one, None) == 10001 and b"plane_stride" in lib.mpf_last_error()
     assert lib.mpf_pbilinear2x(ctypes.c_void_p(260), 1, 2, 2, 4, one, 0, None) == 10001 and b"aligned" in lib.mpf_last_error()
-    # tuning knobs: process-global ints; the bench-only ablation `chain_stop` of round 4 is gone, unknown keys are errors
-    assert lib.mpf_tune(b"fwarp_path", 2) == 0 and lib.mpf_tune(b"fwarp_path", 0) == 0 and lib.mpf_tune(b"planar_lds", 2) == 0 and lib.mpf_tune(b"planar_lds", 1) == 0
-    assert lib.mpf_tune(b"chain_stop", 1) == 10001 and b"unknown key" in lib.mpf_last_error()
+    # tuning knobs of the PRODUCT library: scheduling only.  Every key that selects a retired kernel variant or a timing ablation is refused - it cannot
+    # change a result of this process, whoever calls it - and unknown keys are errors
+    assert lib.mpf_is_witness_build() == 0
+    for key in (b"sbf_px", b"conv_pf", b"chain_grid", b"chain_prio"):
+        assert lib.mpf_tune(key, 0) == 0
+    assert lib.mpf_tune(b"conv_pf", 1) == 0 and lib.mpf_tune(b"fwarp_gate", -1) == 0
+    for key in (b"ovl_ablate", b"stage_b", b"planar_lds", b"fwarp_path", b"ovl_xcd_a", b"view_shift", b"ovl_depth", b"chain_stop"):
+        assert lib.mpf_tune(key, 1) == 10001 and b"unknown key" in lib.mpf_last_error(), key
     with pytest.raises(built.MpiFlowHipError):
         built.check(rc, "probe")
+
+
+def test_witness_build_keeps_the_variants_and_the_product_has_none_of_their_kernels(built):
+    """libmpiflow_hip_witness.so (-DMPF_WITNESS): the same C ABI + the variant / ablation keys; the product's dynamic symbol table holds none of the retired
+    kernels (nm -D), the witness's holds them all."""
+    import subprocess
+    w = built.load_witness()
+    assert w.mpf_is_witness_build() == 1 and w.mpf_version() == built.load().mpf_version()
+    for n in declared_symbols():
+        assert hasattr(w, n), "libmpiflow_hip_witness.so does not export %s" % n
+    for key, v in ((b"stage_b", 20), (b"stage_b", 1), (b"planar_lds", 2), (b"planar_lds", 1), (b"fwarp_path", 2), (b"fwarp_path", 0), (b"ovl_xcd_a", 0),
+                   (b"view_shift", 8), (b"ovl_depth", 4), (b"ovl_ablate", 0)):
+        assert w.mpf_tune(key, v) == 0, key
+    assert w.mpf_tune(b"chain_stop", 1) == 10001
+    retired = ("k_warp_composite_dbg", "k_warp_composite_lds", "k_warp_composite_planar_wave", "k_fw_bucket", "k_fw_keys_hist", "k_mo_project_keys_hist")
+    syms = {p: subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True, check=True).stdout for p in (built.LIB_PATH, built.WITNESS_PATH)}
+    for k in retired:
+        assert k not in syms[built.LIB_PATH], "%s is compiled into the product library" % k
+        assert k in syms[built.WITNESS_PATH], k
+    assert "k_pair_overlap" in syms[built.LIB_PATH] and "k_fw_gather_resolve" in syms[built.LIB_PATH]
+    # the witness is a context, not a mode: calls go back to the product library afterwards
+    with built.witness() as lib:
+        assert lib is w and built.load() is w
+    assert built.load() is not w and built.load().mpf_is_witness_build() == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, built):

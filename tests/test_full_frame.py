@@ -337,10 +337,9 @@ def test_views_launch_bit_identical_to_single_launches(dev, oracle, S, H, W, V, 
                                                       (16, 96, 160, 2, True, True, True), (256, 16, 64, 1, True, False, False),
                                                       (12, 40, 56, 2, True, True, False)])
 def test_lds_staged_variant_bit_identical(dev, S, H, W, V, mask, aux, extreme):
-    """mpf_tune("stage_b", 20): the kernel that stages each tile's source footprint in LDS == the gather kernel, bit for bit.
+    """mpf_tune("stage_b", 20) of the WITNESS build: the kernel that stages each tile's source footprint in LDS == the gather kernel, bit for bit.
     `extreme`: poses whose footprint does not fit the 48x16 LDS tile, so some workgroups take the in-kernel gather fall-back."""
     from mpiflow_amd import _lib, host_math, ops, synth
-    lib = _lib.load()
     inp = synth.make_inputs(S, H, W, seed=S + V + 40, kind="white")
     if (S, H, W) == (12, 40, 56):                             # skewed intrinsics: the dense K^-1 path
         inp["K"][0, 1], inp["K"][1, 0] = 3.5, 0.25
@@ -368,22 +367,24 @@ def test_lds_staged_variant_bit_identical(dev, S, H, W, V, mask, aux, extreme):
         _, H_st = host_math.homographies(G, k_inv, inp["K"], d)
         dp = ops.upload_params(ops.warp_params(H_st, k_inv, G, d), dev)
         views.append(dict(dparams=dp, quads=quads[v % 2] if mask else None, out=outs()))
-    try:
-        _lib.check(lib.mpf_tune(b"stage_b", 1))
-        for v in views:
-            want.append({k: t.clone() for k, t in ops.warp_composite(a["rgba"], v["quads"], dparams=v["dparams"], out=outs(), interleaved=2).items() if t is not None})
-        _lib.check(lib.mpf_tune(b"stage_b", 20))
-        ops.warp_composite_views(a["rgba"], views, interleaved=2)
-        torch.cuda.synchronize()
-        for v in range(V):
-            for k, t in views[v]["out"].items():
-                assert bits_equal(N(t), N(want[v][k])) == 0, ("views", v, k)
-        single = ops.warp_composite(a["rgba"], views[0]["quads"], dparams=views[0]["dparams"], out=outs(), interleaved=2)
-        for k, t in single.items():
-            if t is not None:
-                assert bits_equal(N(t), N(want[0][k])) == 0, ("single", k)
-    finally:
-        _lib.check(lib.mpf_tune(b"stage_b", 1))
+    # the shipped gather kernel (product library) ...
+    for v in views:
+        want.append({k: t.clone() for k, t in ops.warp_composite(a["rgba"], v["quads"], dparams=v["dparams"], out=outs(), interleaved=2).items() if t is not None})
+    # ... against the LDS-staged variant, which exists in the witness build only
+    with _lib.witness() as lib:
+        try:
+            _lib.check(lib.mpf_tune(b"stage_b", 20))
+            ops.warp_composite_views(a["rgba"], views, interleaved=2)
+            torch.cuda.synchronize()
+            for v in range(V):
+                for k, t in views[v]["out"].items():
+                    assert bits_equal(N(t), N(want[v][k])) == 0, ("views", v, k)
+            single = ops.warp_composite(a["rgba"], views[0]["quads"], dparams=views[0]["dparams"], out=outs(), interleaved=2)
+            for k, t in single.items():
+                if t is not None:
+                    assert bits_equal(N(t), N(want[0][k])) == 0, ("single", k)
+        finally:
+            _lib.check(lib.mpf_tune(b"stage_b", 1))
 
 
 @pytest.mark.parametrize("S,H,W,R", [(8, 32, 48, 3), (16, 40, 72, 9)])

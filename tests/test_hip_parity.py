@@ -6,6 +6,8 @@ actually asserted is much tighter, because the kernels reproduce the reference's
   * vs goldens recorded from the reference: <= 2e-6 on O(1) quantities (the residual is torch.exp = MKL, see
     oracle/oracle_math.c), 5e-5 on flow (pixels, values up to 200), masks exact outside the recorded margin pixels.
 """
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -316,15 +318,17 @@ def test_forward_warp_random_vs_oracle(dev, oracle, h, w, spread):
     assert bits_equal(N(got), want) == 0
     # the general multi-pass radix path (what images above 2^24 pixels take) and round 2's one-pass sort + per-bucket workgroups (fwarp_path 2)
     # give the same bytes as the default gather path
+    # (the path switch exists in the witness build only; the product reaches the radix path through the gate below and for images above 2^24 pixels)
     from mpiflow_amd import _lib
+    with _lib.witness() as wlib:
+        for path in (1, 2):
+            try:
+                _lib.check(wlib.mpf_tune(b"fwarp_path", path))
+                got2 = ops.forward_warp(T(src, dev), T(idx, dev), T(idy, dev), T(z, dev), h, w)
+            finally:
+                _lib.check(wlib.mpf_tune(b"fwarp_path", 0))
+            assert bits_equal(N(got2), want) == 0, path
     lib = _lib.load()
-    for path in (1, 2):
-        try:
-            _lib.check(lib.mpf_tune(b"fwarp_path", path))
-            got2 = ops.forward_warp(T(src, dev), T(idx, dev), T(idy, dev), T(z, dev), h, w)
-        finally:
-            _lib.check(lib.mpf_tune(b"fwarp_path", 0))
-        assert bits_equal(N(got2), want) == 0, path
     # caller-supplied targets choose between gather and radix ON THE DEVICE (the bucket visits pass 1 counts against a threshold): both sides of that gate
     for gate in (0, 2 ** 31 - 1):                          # 0: the radix launches behind the gate do the work; huge: the gather always does
         try:
@@ -359,11 +363,12 @@ def test_forward_warp_scattered_targets_stay_linear(dev, oracle):
         return out, time.perf_counter() - t0
     got, t_default = timed()
     assert bits_equal(N(got), oracle.forward_warping(src, idx, idy, z, h, w)) == 0
-    try:
-        _lib.check(lib.mpf_tune(b"fwarp_path", 1))
-        got1, t_radix = timed()
-    finally:
-        _lib.check(lib.mpf_tune(b"fwarp_path", 0))
+    with _lib.witness() as wlib:                               # the radix path on its own: the witness build's path switch
+        try:
+            _lib.check(wlib.mpf_tune(b"fwarp_path", 1))
+            got1, t_radix = timed()
+        finally:
+            _lib.check(wlib.mpf_tune(b"fwarp_path", 0))
     assert torch.equal(got, got1)
     assert t_default < 4 * t_radix + 2e-3, (t_default, t_radix)        # (the ungated gather: seconds)
 
@@ -677,16 +682,20 @@ def test_equal_adjacent_plane_disparities_give_dist_zero_not_nan(dev, kernel_exp
     G_cam, G_dyn = _poses(o, S + 3 * H)
     ref = o.render_pair(inp["image"], inp["obj_mask"], inp["mpi"], disp, inp["K"], G_cam, G_dyn)
     assert np.isfinite(ref["flow_mix"]).all() and np.isfinite(ref["view_cam"]["rgb"]).all()
-    for variant in (1, 20):
-        _lib.check(_lib.load().mpf_tune(b"stage_b", variant))
-        try:
-            out = pipeline.render_pair(T(inp["image"], dev), T(inp["obj_mask"], dev), T(inp["mpi"], dev), disp, inp["K"], G_cam, G_dyn)
-            for k in ("flow_mix", "frame_mix", "fill_mask"):
-                assert bits_equal(N(out[k]), ref[k]) == 0, (k, variant)
-            for v in ("view_cam", "view_dyn"):
-                assert bits_equal(N(out[v]["rgb"]), ref[v]["rgb"]) == 0 and bits_equal(N(out[v]["objmask"]), ref[v]["objmask"]) == 0, (v, variant)
-        finally:
-            _lib.check(_lib.load().mpf_tune(b"stage_b", 1))
+    for variant in (1, 20):                                     # the shipped kernel (product library), the LDS-staged witness (witness build)
+        import contextlib
+        with (_lib.witness() if variant == 20 else contextlib.nullcontext()):
+            if variant == 20:
+                _lib.check(_lib.load().mpf_tune(b"stage_b", variant))
+            try:
+                out = pipeline.render_pair(T(inp["image"], dev), T(inp["obj_mask"], dev), T(inp["mpi"], dev), disp, inp["K"], G_cam, G_dyn)
+                for k in ("flow_mix", "frame_mix", "fill_mask"):
+                    assert bits_equal(N(out[k]), ref[k]) == 0, (k, variant)
+                for v in ("view_cam", "view_dyn"):
+                    assert bits_equal(N(out[v]["rgb"]), ref[v]["rgb"]) == 0 and bits_equal(N(out[v]["objmask"]), ref[v]["objmask"]) == 0, (v, variant)
+            finally:
+                if variant == 20:
+                    _lib.check(_lib.load().mpf_tune(b"stage_b", 1))
     # the reference-signature (planar, v1 kernel) path and the generic volume renderer use the library sqrt: same answer
     d = o.plane_depths(disp)
     k_inv = o.k_inverse(inp["K"])
@@ -869,9 +878,12 @@ def test_overlapped_launch_equals_separate_launches(dev, kernel_exp, S, H, W):
             w_q = [torch.empty((H, W, 4), device=dev) for _ in range(2)]
             ops.src_blend_flow(mk(b["mpi"]), mk(b["image"]), out_rgba=w_rgba, out_flows=w_fl, dparams=dp, P=P, src_u8=w_u8, obj_mask=mk(b["obj_mask"]),
                                quads=w_q[0], quads_complement=w_q[1], cum_mask=cm)
-            for depth, xcd_a in ((8, 0), (4, 0), (4, 3), (4, 1), (4, 7)):          # xcd_a: the roles partitioned by XCD instead of interleaved
-                _lib.check(_lib.load().mpf_tune(b"ovl_depth", depth))
-                _lib.check(_lib.load().mpf_tune(b"ovl_xcd_a", xcd_a))
+            # the shipped launch (product library: depth 4, roles interleaved on every XCD), then the witness build's variants - xcd_a: the roles partitioned by XCD
+            for depth, xcd_a in ((None, None), (8, 0), (4, 0), (4, 3), (4, 1), (4, 7)):
+              with (contextlib.nullcontext() if depth is None else _lib.witness()):
+                if depth is not None:
+                    _lib.check(_lib.load().mpf_tune(b"ovl_depth", depth))
+                    _lib.check(_lib.load().mpf_tune(b"ovl_xcd_a", xcd_a))
                 g_rgba = ops.alloc_rgba_stack(S, H, W, dev)
                 g_fl = torch.full((P, 2, H, W), float("nan"), device=dev) if P else None
                 g_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
@@ -887,8 +899,9 @@ def test_overlapped_launch_equals_separate_launches(dev, kernel_exp, S, H, W):
                 assert torch.equal(g_u8, w_u8) and all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(g_q, w_q)), tag
                 if P:
                     assert torch.equal(g_fl.view(torch.int32), w_fl.view(torch.int32)), tag
-    _lib.check(_lib.load().mpf_tune(b"ovl_depth", 4))
-    _lib.check(_lib.load().mpf_tune(b"ovl_xcd_a", 0))
+                if depth is not None:
+                    _lib.check(_lib.load().mpf_tune(b"ovl_depth", 4))
+                    _lib.check(_lib.load().mpf_tune(b"ovl_xcd_a", 0))
 
 
 @pytest.mark.parametrize("S,H,W,n", [(8, 32, 48, 5), (20, 23, 37, 3), (16, 64, 96, 1)])
@@ -1051,8 +1064,11 @@ def test_planar_and_split_stage_b_equal_the_interleaved_kernel(dev, kernel_exp, 
         q = ops.mask_quads(T(inp["obj_mask"], dev), complement=comp)
         from mpiflow_amd import _lib
         try:
-            for planar_lds in (1, 0, 2):       # LDS-staged footprints of the tile (the default) / 8-byte tap-pair gathers / wave-private footprints, no barrier
-                _lib.check(_lib.load().mpf_tune(b"planar_lds", planar_lds))
+            # None: the product library (LDS-staged footprints of the tile); then the witness build's switch: the same / 8-byte tap-pair gathers / wave-private footprints
+            for planar_lds in (None, 1, 0, 2):
+              with (contextlib.nullcontext() if planar_lds is None else _lib.witness()):
+                if planar_lds is not None:
+                    _lib.check(_lib.load().mpf_tune(b"planar_lds", planar_lds))
                 for quads in (q, None):
                     a = ops.warp_composite(stack, quads, Hst, k_inv, G, d, interleaved=False)
                     b = ops.warp_composite_split(rgb3, sig1, quads, Hst, k_inv, G, d)
@@ -1062,7 +1078,7 @@ def test_planar_and_split_stage_b_equal_the_interleaved_kernel(dev, kernel_exp, 
                 lean = ops.warp_composite_split(rgb3, sig1, q, Hst, k_inv, G, d, want_depth=False, want_tgt_mask=False)
                 assert bits_equal(N(lean["rgb"]), want["rgb"]) == 0 and bits_equal(N(lean["objmask"]), want["objmask"]) == 0
         finally:
-            _lib.check(_lib.load().mpf_tune(b"planar_lds", 1))
+            _lib.load_witness().mpf_tune(b"planar_lds", 1)
     ref = o.src_blend_flow(inp["mpi"], inp["image"], k_inv, d, np.stack([Hts_c, Hts_d]))
     assert bits_equal(N(ops.src_flow(sig1, k_inv, d, np.stack([Hts_c, Hts_d]))), ref["flows"]) == 0
     assert bits_equal(N(ops.src_flow(sig1.reshape(S, H, W), k_inv, d, Hts_d[None]))[0], ref["flows"][1]) == 0

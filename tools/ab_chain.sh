@@ -6,7 +6,7 @@ B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sub"
 J='import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(sys.argv[1], "value %.1f pairs/s, pair launch %.1f us" % (d["value"], d["roofline"]["avg_launch_ms"] * 1e3))'
 for i in 1 2; do
   $B 2>/dev/null | python -c "$J" "gather"
-  $B --tune fwarp_path=2 2>/dev/null | python -c "$J" "sort  "
+  $B --witness --tune fwarp_path=2 2>/dev/null | python -c "$J" "sort  "
   $B --no-moving-object 2>/dev/null | python -c "$J" "none  "
 done
 mkdir -p gpurun_out/chain_r5

@@ -14,7 +14,7 @@ from mpiflow_amd import _lib, synth                              # noqa: E402
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (640, 960)
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 dev = torch.device("cuda:0")
-lib = _lib.load()
+lib = _lib.select_witness()          # the variant keys this tool switches exist in the witness build only (libmpiflow_hip_witness.so)
 chain, disp = bench.make_moving_object_chain(H, W, synth.intrinsics(H, W), dev, 0)
 inst = torch.from_numpy(synth.soft_box_mask(H, W)).to(dev)
 img = torch.rand((3, H, W), device=dev)

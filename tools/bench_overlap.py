@@ -32,7 +32,7 @@ ap.add_argument("--pmc", action="store_true", help="counter runs: serial single 
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 S, H, W, B = a.planes, a.height, a.width, a.images
-lib = _lib.load()
+lib = _lib.select_witness()          # the variant keys this tool switches exist in the witness build only (libmpiflow_hip_witness.so)
 if os.environ.get("MPF_VIEW_SHIFT"):                      # experiment: odd views walk the tile sequence this many positions ahead (tools/bench_view_shift.py)
     _lib.check(lib.mpf_tune(b"view_shift", int(os.environ["MPF_VIEW_SHIFT"])))
 

@@ -22,7 +22,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--launches", type=int, default=20)
 p.add_argument("--rounds", type=int, default=5)
 a = p.parse_args()
-lib = _lib.load()
+lib = _lib.select_witness()          # the variant keys this tool switches exist in the witness build only (libmpiflow_hip_witness.so)
 dev = torch.device("cuda:0")
 S, H, W = 64, 640, 960
 g = torch.Generator(device=dev).manual_seed(0)

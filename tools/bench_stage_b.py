@@ -31,7 +31,7 @@ p.add_argument("--layout", type=int, default=1, help="1 = interleaved, 2 = inter
 p.add_argument("--planar-lds", type=int, default=-1, help="layouts 0 / 3: 1 = LDS-staged footprints (k_warp_composite_planar_lds), 0 = gathers (k_warp_composite_planar), -1 = library default")
 a = p.parse_args()
 
-lib = _lib.load()
+lib = _lib.select_witness()          # the variant keys this tool switches exist in the witness build only (libmpiflow_hip_witness.so)
 if a.planar_lds >= 0:
     _lib.check(lib.mpf_tune(b"planar_lds", a.planar_lds))
 dev = torch.device("cuda:0")

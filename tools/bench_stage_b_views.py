@@ -27,7 +27,7 @@ p.add_argument("--images", type=int, default=3)
 p.add_argument("--variants", type=str, default="1,20", help="mpf_tune stage_b variants (1 = gather kernel, 20 = LDS-staged kernel)")
 a = p.parse_args()
 
-lib = _lib.load()
+lib = _lib.select_witness()          # the variant keys this tool switches exist in the witness build only (libmpiflow_hip_witness.so)
 if os.environ.get("MPF_VIEW_SHIFT"):
     _lib.check(lib.mpf_tune(b"view_shift", int(os.environ["MPF_VIEW_SHIFT"])))
 dev = torch.device("cuda:0")

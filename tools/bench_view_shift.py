@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from mpiflow_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.select_witness()          # the variant keys this tool switches exist in the witness build only (libmpiflow_hip_witness.so)
 dev = torch.device("cuda:0")
 S, H, W, B = 64, 640, 960, 8
 w = bench.Workload(S, H, W, B, dev, True, seed0=0)

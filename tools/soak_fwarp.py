@@ -14,7 +14,7 @@ from mpiflow_amd import _lib, ops       # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
-lib = _lib.load()
+lib = _lib.select_witness()          # the variant keys this tool switches exist in the witness build only (libmpiflow_hip_witness.so)
 try:
     from oracle import mpi_oracle as orc
 except Exception:                        # noqa: BLE001

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpiflow_amd import _lib, host_math, ops, synth
 
 dev = torch.device("cuda:0")
-lib = _lib.load()
+lib = _lib.select_witness()          # the variant keys this tool switches exist in the witness build only (libmpiflow_hip_witness.so)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 bad = 0

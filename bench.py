@@ -512,7 +512,7 @@ def overlap_record(S, H, W, dev, n_streams=2, images=4, steps=8):
             "streams": n_streams, "pairs_per_s": n / dt, "us_per_pair": dt / n * 1e6, "pairs_timed": n}
 
 
-def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64, model_dtype="auto"):
+def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64, model_dtype="auto", cpus=None, writers=None):
     """The data generator end to end (gen_3dphoto_dynamic.py, the reference's entry point gen_3dphoto_dynamic_v2.py:20-122): PNG decode,
     input stage, AdaMPI network (random weights of the reference's architecture: no checkpoint offline) on the HIP engine, blend once per
     image, `repeat` pairs per image, hole filling (cv2.inpaint's NS restated, on the writer threads), PNG + .flo files - on a synthetic
@@ -542,14 +542,19 @@ def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64, model_d
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         cmd = [sys.executable, os.path.join(ROOT, "gen_3dphoto_dynamic.py"), "--base", base, "--out", os.path.join(tmp, "out"), "--repeat", str(repeat),
                "--mpi-from", "model", "--ckpt_path", "random:0", "--model-engine", "hip", "--model-dtype", model_dtype, "--inpaint", "builtin"]
+        if writers:
+            cmd += ["--writers", str(writers)]
+        # cpus: the process (decode / writer / submitting threads alike) is confined to that many logical CPUs - one rank's share of a node's host
+        pre = (lambda: os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:cpus]))) if cpus else None
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, preexec_fn=pre)
         dt = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": (r.stderr or r.stdout)[-400:]}
         steady = [l for l in r.stdout.splitlines() if l.startswith("steady state")]
         startup = [l for l in r.stdout.splitlines() if l.startswith("start-up:")]
         summary = [l for l in r.stdout.splitlines() if l.startswith("pairs ")]
+        wline = [l for l in r.stdout.splitlines() if l.startswith("writers:")]
         n_files = len(os.listdir(os.path.join(tmp, "out", "flows")))
         rec = {"workload": "gen_3dphoto_dynamic.py end to end: %d synthetic 375x1242 images -> 64 planes x 384 x 1280, repeat %d, AdaMPI (random weights) on the HIP "
                            "engine, NS hole filling on the writer threads, PNG + .flo written" % (n_images, repeat),
@@ -559,6 +564,8 @@ def generator_record(n_images=320, repeat=5, timeout=900, n_distinct=64, model_d
                                      "(torch fp16 autocast: 1.2e-2); --model-engine hip --model-dtype fp32 runs the parity-grade engine (roofline_n1.precise)",
                "model_dtype": model_dtype, "n_images": n_images, "n_distinct": min(n_images, n_distinct), "repeat": repeat, "pairs": n_images * repeat, "flo_files_written": n_files, "process_seconds": dt,
                "pairs_per_s_whole_process": n_images * repeat / dt, "summary_line": summary[-1] if summary else None}
+        if wline:
+            rec["writer_stages"] = wline[-1]
         if startup:
             rec["startup_line"] = startup[-1]
             rec["startup_seconds"] = float(startup[-1].split(":")[1].split("s")[0])
@@ -864,6 +871,22 @@ def main():
                 out["generator"] = generator_record()
             except Exception as e:                                   # noqa: BLE001 - a side record must never cost the headline line
                 out["generator"] = {"error": repr(e)}
+            try:
+                # VERDICT r5 item 5 - what ONE GPU can show of an 8-rank node: the same generator confined to 1/8 of this host's logical CPUs with the writer
+                # count an 8-rank run gives each rank (cores / (4 x 8)).  Steady state within 5 % of the unrestricted record = a rank keeps its rate on its share
+                # of the host; else `writer_stages` names the stage that falls behind and its per-call time IS the 8-GPU generator ceiling
+                ncpu = len(os.sched_getaffinity(0))
+                share, w8 = max(2, ncpu // 8), max(2, min(32, ncpu // 32))
+                hs = generator_record(n_images=160, n_distinct=64, cpus=share, writers=w8)
+                hs["host_share"] = {"cpus_of_the_process": share, "cpus_of_the_box": ncpu, "writers": w8,
+                                    "note": "decode, submitting and writer threads of the rank all confined to %d of %d logical CPUs (sched_setaffinity); "
+                                            "--writers %d = the CLI's default for 8 ranks on this node" % (share, ncpu, w8)}
+                g = out.get("generator", {})
+                if isinstance(hs.get("pairs_per_s_steady_state"), float) and isinstance(g.get("pairs_per_s_steady_state"), float):
+                    hs["steady_state_vs_unrestricted"] = hs["pairs_per_s_steady_state"] / g["pairs_per_s_steady_state"]
+                out["generator_host_share_1of8"] = hs
+            except Exception as e:                                   # noqa: BLE001
+                out["generator_host_share_1of8"] = {"error": repr(e)}
             try:                                                     # the same generator with the PARITY-GRADE producer (every convolution in fp32 on mpf_pconv): a short run
                 out["generator_precise"] = generator_record(n_images=24, n_distinct=24, model_dtype="fp32")
                 out["generator_precise"]["producer_precision"] = ("parity-grade engine (--model-dtype fp32): fp32 tensors, products from bf16 pieces on the matrix cores, fp32 blocks of "
@@ -899,6 +922,8 @@ def main():
         c["generator_pairs_per_s_steady"] = _get(out, "generator", "pairs_per_s_steady_state")
         c["generator_pairs_per_s_whole_process"] = _get(out, "generator", "pairs_per_s_whole_process")
         c["generator_precise_pairs_per_s_steady"] = _get(out, "generator_precise", "pairs_per_s_steady_state")
+        c["generator_host_share_1of8_pairs_per_s_steady"] = _get(out, "generator_host_share_1of8", "pairs_per_s_steady_state")
+        c["generator_host_share_1of8_vs_unrestricted"] = _get(out, "generator_host_share_1of8", "steady_state_vs_unrestricted")
         c["hbm_read_GBps"] = _get(out, "hbm_reference", "read_GBps")
         c["hbm_copy_GBps"] = _get(out, "hbm_reference", "copy_GBps")
         c["cpu_baseline_pairs_per_s"] = _get(out, "cpu_baseline", "value")

@@ -354,6 +354,12 @@ def main(argv=None):
     with lap("drain writers"):
         torch.cuda.synchronize()
         ring.close()
+    if rank == 0:
+        # where the writer threads' time went: the number that says whether 1/N of a node's host cores keeps up with one GPU (bench.py: generator_host_share_1of8)
+        rep = ring.stage_report()
+        per = ", ".join("%s %.2f ms x %d" % (k, 1e3 * v[0] / max(1, v[1]), v[1]) for k, v in sorted(rep["stages"].items()))
+        print("writers: %d threads on %d cpu(s), busy %.0f %% of their wall time, submit() waited %.2f s for a free slot; per call: %s" % (
+            rep["threads"], len(os.sched_getaffinity(0)), 100 * rep["busy_share"], rep["backpressure_seconds"], per))
     if lap.on and rank == 0:
         for k, v in prof.items():
             print("  %-40s %8.3f s" % (k, v))

@@ -179,6 +179,27 @@ class OutputRing:
         self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=threads)
         self._futures = []
         self._torch = torch
+        # cumulative seconds the writer threads spent per stage (stage_report()): which host stage would fall behind when the ranks of a node share its cores
+        self.threads, self._stage, self._stage_lock, self._t_open = threads, {}, __import__("threading").Lock(), __import__("time").perf_counter()
+        self.backpressure_seconds = 0.0
+
+    def _lap(self, name, t0):
+        import time
+        t1 = time.perf_counter()
+        with self._stage_lock:
+            c = self._stage.setdefault(name, [0.0, 0])
+            c[0] += t1 - t0
+            c[1] += 1
+        return t1
+
+    def stage_report(self):
+        """-> dict(stage -> (seconds, calls)), threads, busy share of the writer pool since it was opened, seconds submit() spent waiting for a free slot"""
+        import time
+        with self._stage_lock:
+            st = {k: tuple(v) for k, v in self._stage.items()}
+        wall = time.perf_counter() - self._t_open
+        busy = sum(v[0] for k, v in st.items() if k != "wait for the GPU (event)")
+        return dict(stages=st, threads=self.threads, wall_seconds=wall, busy_share=busy / max(1e-9, wall * self.threads), backpressure_seconds=self.backpressure_seconds)
 
     def _new_slot(self):
         torch, H, W = self._torch, self.H, self.W
@@ -204,22 +225,36 @@ class OutputRing:
             grow = self._n_slots < self._max_slots
             if grow:
                 self._n_slots += 1
-        return self._new_slot() if grow else self._free.get()
+        if grow:
+            return self._new_slot()
+        import time
+        t0 = time.perf_counter()
+        slot = self._free.get()                                      # every slot is in flight: the writers are behind (back-pressure on the submitting thread)
+        self.backpressure_seconds += time.perf_counter() - t0
+        return slot
 
     def _finish(self, slot, event, flo_path, png_paths, fill=False):
+        import time
         try:
+            t = time.perf_counter()
             event.synchronize()
+            t = self._lap("wait for the GPU (event)", t)
             if flo_path is not None:
                 write_flo(flo_path, slot["flow"].numpy())
+                t = self._lap(".flo file", t)
             if png_paths:
                 if fill:
                     frame = self._host_fill(slot["frame"].numpy(), slot["hole"].numpy())
+                    t = self._lap("hole fill (NS)", t)
                     scan = filter_up_rgb(np.asarray(frame)[:, :, ::-1])               # cv2.imwrite: BGR array -> RGB file
+                    t = self._lap("PNG Up filter (host)", t)
                 else:
                     scan = slot["scan"].numpy()
                 data = png_from_scanlines(scan, self.level)
+                t = self._lap("PNG deflate", t)
                 for p in png_paths:
                     write_bytes(p, data)
+                t = self._lap("PNG file", t)
         finally:
             self._free.put(slot)
 

@@ -90,7 +90,7 @@ def parse(argv=None):
                         "a bare `python gen_3dphoto_dynamic.py` starts the N ranks itself (torch.distributed.run, RCCL over xGMI); under torchrun it "
                         "must equal the launcher's rank count")
     p.add_argument("--writers", type=int, default=0,
-                   help="writer threads PER RANK (hole fill, PNG encode and file I/O overlap the GPU); 0 = cores / (4 x ranks on this node), "
+                   help="writer threads PER RANK (hole fill, PNG encode and file I/O overlap the GPU); 0 = the rank's share of the node's logical CPUs minus 6 (cores / ranks on this node - 6), "
                         "between 2 and 32 - the ranks of a node share its host cores")
     p.add_argument("--lanes", type=int, default=1,
                    help="images in flight on this GPU, each with its own streams, plane-stack buffer and network graph (same files for any "
@@ -122,8 +122,11 @@ def outputs_exist(out, name, repeat):
 
 
 def default_writers(local_world):
-    """cores / (4 x ranks on this node), clamped to 2..32: every rank of a node draws on the same host cores"""
-    return max(2, min(32, (os.cpu_count() or 8) // (4 * max(1, local_world))))
+    """The rank's share of the node's logical CPUs minus the six its other threads use (submitting thread, four decoders, one spare), clamped to 2..32: every
+    rank of a node draws on the same host cores.  A pair costs a writer ~19 ms of host time (NS fill 7, deflate 9.6, Up filter 1.3, .flo 0.7: bench.py's
+    `generator_host_share_1of8.writer_stages`), i.e. ~53 pairs/s per thread - round 5's cores / (4 x ranks) gave a rank of an 8-rank node 8 writers on its 32
+    CPUs: 94 % busy and 19 % below the GPU's rate."""
+    return max(2, min(32, (os.cpu_count() or 8) // max(1, local_world) - 6))
 
 
 def self_launch(opt, argv):

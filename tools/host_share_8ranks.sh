@@ -25,8 +25,12 @@ for i in range(n):
     Image.fromarray(m).save(os.path.join(base, "masks", "%04d.png" % i))
 PY
 echo "== 8 ranks, gloo, one device (MPIFLOW_FORCE_DEVICE=0), $N images x 5 pairs at 64 x 384 x 1280"
-/usr/bin/time -v env MPIFLOW_DIST_BACKEND=gloo MPIFLOW_FORCE_DEVICE=0 MPIFLOW_PROFILE=0 python gen_3dphoto_dynamic.py --gpus 8 --base $TMP/data --out $TMP/out8 --repeat 5 \
-    --mpi-from model --ckpt_path random:0 --model-engine hip --inpaint builtin 2>&1 | grep -E "writers:|steady state|start-up|pairs |Elapsed|Maximum resident|Percent of CPU"
+T0=$(date +%s.%N)
+env MPIFLOW_DIST_BACKEND=gloo MPIFLOW_FORCE_DEVICE=0 python gen_3dphoto_dynamic.py --gpus 8 --base $TMP/data --out $TMP/out8 --repeat 5 \
+    --mpi-from model --ckpt_path random:0 --model-engine hip --inpaint builtin > $TMP/log8.txt 2>&1
+echo "exit status $? after $(python -c "import time;print('%.1f' % (time.time() - $T0))") s"
+grep -E "writers:|steady state|start-up|pairs |Error|error|Traceback" $TMP/log8.txt | head -20
+tail -5 $TMP/log8.txt
 echo "== 1 rank, same set (for the file comparison)"
 python gen_3dphoto_dynamic.py --base $TMP/data --out $TMP/out1 --repeat 5 --mpi-from model --ckpt_path random:0 --model-engine hip --inpaint builtin 2>&1 | grep -E "writers:|steady state|pairs "
 python - "$TMP" <<'PY'

@@ -755,6 +755,103 @@ int launch_up(const MpfConvArgs &a, hipStream_t st)
     return mpf_launch_status("k_conv3x3_up");
 }
 
+// upconv(0, 1): the phase-decomposed x2-nearest layer WITHOUT a skip source and with a single chunk (CA <= 16 channels) - the whole convolution is two k-steps per pixel
+// group.  A workgroup walks a.pw consecutive planes at its tile position: tap offsets, this wave's phase fragments (kept in registers), biases and epilogue rows are set up
+// once; per plane ONE 16-byte load per thread (the next plane's is issued before this plane's MFMAs and lands during them and the epilogue), one LDS write into the other
+// of two tile buffers, ONE barrier, 8 MFMAs per block and the gated epilogue.  Same arithmetic per output as k_conv3x3_up.
+template <int EPI, int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+void k_conv3x3_up1(const MpfConvArgs a)
+{
+    constexpr int CT = 16, PG = 4, VPP = 2, LWA = 18, LHA = 6, PIXA = pix_stride_bytes(CT, 1), KSA = 2, TPS = 2;
+    constexpr int TILE_BYTES = (LHA * LWA * PIXA + 255) / 256 * 256;
+    constexpr bool EP_GATED = true;
+    constexpr int EPN = EPI == EP_GATED_ELU_PAIRED ? NB * 8 : (NB / 2) * 16;
+    static_assert(EPI == EP_GATED_ELU || EPI == EP_GATED_ELU_PAIRED, "gated epilogues only");
+    static_assert(PIXA == VPP * 16, "the tile is dense: pixel stride = the chunk's bytes");
+    __shared__ __attribute__((aligned(16))) unsigned char tile2[2 * TILE_BYTES];
+    __shared__ float eplds[2 * EPN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int py = wave >> 1, px = wave & 1;
+    const int npw = a.pw > 1 ? a.pw : 1;
+    const int sgrp = (int)blockIdx.z / a.ncg, cg = (int)blockIdx.z - sgrp * a.ncg;
+    int s = sgrp * npw;
+    if (tid < 2 * EPN) {
+        const int row = tid / EPN, c = tid - row * EPN;
+        eplds[tid] = a.ep[(row + 1) * (a.nblk * 16) + cg * (NB * 16) + c];
+    }
+    const int ox0 = (int)blockIdx.x * 32, oy0 = (int)blockIdx.y * 8;
+    const int sv = tid % VPP, sp = tid / VPP;
+    const unsigned va = (unsigned)a.CA >> 3;
+    const bool stg = sp < LHA * LWA && (unsigned)sv < va;      // this thread stages vector sv of tile pixel sp (beyond the source's vectors: zeros, written once below)
+    const int ly = sp / LWA, lx = sp - ly * LWA;
+    const int ya = min(max((oy0 >> 1) - 1 + ly, 0), a.HA - 1), xa = min(max((ox0 >> 1) - 1 + lx, 0), a.WA - 1);
+    const u32x4 *src = (const u32x4 *)a.srcA + ((size_t)((s * a.HA + ya) * a.WA + xa) * va + (unsigned)sv);
+    const size_t dplane = (size_t)a.HA * a.WA * va;
+    if (sp < LHA * LWA && !stg) {                             // padding vectors of both buffers: zero for the whole walk
+        *reinterpret_cast<u32x4 *>(tile2 + sp * PIXA + sv * 16) = zero4();
+        *reinterpret_cast<u32x4 *>(tile2 + TILE_BYTES + sp * PIXA + sv * 16) = zero4();
+    }
+    const int q = lane >> 4, pi = lane & 15;
+    int tapA[KSA];
+#pragma unroll
+    for (int ks = 0; ks < KSA; ++ks) {
+        const int slot = ks * TPS + q / VPP, ty = slot >> 1, tx = slot & 1;
+        tapA[ks] = ((py + ty) * LWA + pi + px + tx) * PIXA + (q % VPP) * 16;
+    }
+    const unsigned wstride = (unsigned)a.nblk * 64u;
+    const u32x4 *wk = (const u32x4 *)a.wpack + (unsigned)(cg * NB) * 64u + (unsigned)lane + (unsigned)(wave * KSA) * wstride;
+    h8 af[KSA][NB];
+    f32x4 init[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks) {
+            u32x4 w = wk[(unsigned)ks * wstride + (unsigned)(b * 64)];
+            af[ks][b] = *reinterpret_cast<h8 *>(&w);
+        }
+        const float *bias = a.ep + (cg * NB + b) * 16 + 4 * q;
+        init[b] = f32x4{bias[0], bias[1], bias[2], bias[3]};
+    }
+    u32x4 cur = zero4();
+    if (stg) cur = *src;
+    const float *eprows = eplds;
+#pragma nounroll
+    for (int pw = 0; pw < npw; ++pw, ++s) {
+        unsigned char *tile = tile2 + (pw & 1) * TILE_BYTES;
+        if (stg) *reinterpret_cast<u32x4 *>(tile + sp * PIXA + sv * 16) = cur;
+        if (stg && pw + 1 < npw) { src += dplane; cur = *src; }
+        __syncthreads();      // this plane's tile is complete; every wave is past the MFMA reads of the plane before the previous one (the buffer the NEXT plane writes)
+        f32x4 acc[PG][NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int g = 0; g < PG; ++g) acc[g][b] = init[b];
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks) {
+#pragma unroll
+            for (int g = 0; g < PG; ++g) {
+                u32x4 bv = *reinterpret_cast<const u32x4 *>(tile + g * LWA * PIXA + tapA[ks]);
+                h8 bf = *reinterpret_cast<h8 *>(&bv);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][b], bf, acc[g][b], 0, 0, 0);
+            }
+        }
+#define MPF_EP_PIXEL(g) const int oy = oy0 + 2 * (g) + py, ox = ox0 + 2 * pi + px;
+#include "mpf_conv_epilogue.inc"
+#undef MPF_EP_PIXEL
+    }
+}
+
+template <int EPI, int NB>
+int launch_up1(const MpfConvArgs &a, hipStream_t st)
+{
+    const int pw = a.pw > 1 ? a.pw : 1;
+    dim3 grid((a.Wout + 31) / 32, (a.Hout + 7) / 8, (a.S / pw) * a.ncg);
+    hipLaunchKernelGGL((k_conv3x3_up1<EPI, NB>), grid, dim3(256), 0, st, a);
+    return mpf_launch_status("k_conv3x3_up1");
+}
+
 int g_conv_pf = 1;                // mpf_tune("conv_pf", 0 | 1): the walking kernels prefetch the next step's fragments / raw tile (scheduling only, same results)
 
 template <int ST, int CT, int LOADER, int EPI, int NB, int TH, int TW, bool WLDS, bool WALK = false>
@@ -966,7 +1063,9 @@ extern "C" int mpf_conv3x3_f16(const MpfConvArgs *args, void *stream)
         MPF_REQUIRE(a.stride == 1 && a.pad_mode == 1 && a.CA > 0 && a.srcA && a.Hin == 2 * a.HA && a.Win == 2 * a.WA, "mpf_conv3x3_f16: the phase-decomposed loader is the x2-nearest, reflection-padded layer");
         MPF_REQUIRE(a.CB == 0 || (a.srcB && a.cm && a.fm && a.CB >= 16), "mpf_conv3x3_f16: the skip source needs its features and both masks");
         MPF_REQUIRE(a.nchunk == (a.CA + a.ct - 1) / a.ct + (a.CB + a.ct - 1) / a.ct, "mpf_conv3x3_f16: chunk count of the phase-decomposed layer (whole chunks per source)");
-        MPF_REQUIRE(a.pw <= 1 && !a.plane_major, "mpf_conv3x3_f16: the phase-decomposed kernel neither walks planes nor reorders the grid");
+        MPF_REQUIRE(!a.plane_major, "mpf_conv3x3_f16: the phase-decomposed kernels do not reorder the grid");
+        if (a.CB == 0 && a.CA <= 16 && a.ct == 16 && a.epi == EP_GATED_ELU && nb == 2) return launch_up1<EP_GATED_ELU, 2>(a, st);      // upconv(0,1): one chunk, walks a.pw planes
+        MPF_REQUIRE(a.pw <= 1, "mpf_conv3x3_f16: only the single-chunk phase-decomposed layer walks planes");
         if (a.epi == EP_GATED_ELU && a.ct == 32 && nb == 4) return launch_up<32, EP_GATED_ELU, 4>(a, st);
         if (a.epi == EP_GATED_ELU && a.ct == 16 && nb == 6) return launch_up<16, EP_GATED_ELU, 6>(a, st);
         if (a.epi == EP_GATED_ELU && a.ct == 16 && nb == 4) return launch_up<16, EP_GATED_ELU, 4>(a, st);

@@ -306,7 +306,8 @@ class ConvLayer:
         a.wlds = int(_wlds(self.name, self.wlds_default))
         a.plane_major = int(self.plane_major)
         a.bprime_table = int(bool(bprime_table))
-        a.pw = 1 if self.loader == LD_NEAREST_PHASE else _pw(self.name, S, self.nblk // self.ncg)
+        # (of the phase-decomposed layers only the single-chunk one without a skip source - upconv(0,1) - has a plane-walking kernel)
+        a.pw = _pw(self.name, S, self.nblk // self.ncg) if (self.loader != LD_NEAREST_PHASE or (self.CB == 0 and self.CA <= 16)) else 1
         self.last_call = dict(S=S, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, HA=a.HA, WA=a.WA)
         if self.loader in (LD_BILINEAR_CAT, LD_BILINEAR_SYNTH):
             a.fparams[0] = (a.HA - 1) / (Hin - 1) if Hin > 1 else 0.0

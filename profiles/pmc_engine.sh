@@ -20,7 +20,7 @@ import csv, glob, collections, re
 rows = collections.OrderedDict()
 for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_conv3x3<[^>]*>|k_plane_masks)", r["Kernel_Name"])
+        m = re.search(r"(k_conv3x3(?:_up1?)?<[^>]*>|k_plane_masks)", r["Kernel_Name"])
         if not m:
             continue
         key = (m.group(1).replace(" ", ""), r.get("Grid_Size", ""))
@@ -39,7 +39,7 @@ import csv, glob, collections, re
 rows = collections.OrderedDict()
 for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_conv3x3<[^>]*>)", r["Kernel_Name"])
+        m = re.search(r"(k_conv3x3(?:_up1?)?<[^>]*>)", r["Kernel_Name"])
         if m:
             rows.setdefault((m.group(1).replace(" ", ""), r.get("Grid_Size", "")), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("\n# MFMA-busy share per conv layer (kernel instance, grid): MFMA busy SIMD-cycles / (kernel cycles x 1024 SIMDs); VALU-active share beside it")

@@ -254,6 +254,8 @@ class ConvLayer:
             # the 8-block kernels hold 128 accumulator + 158 other registers: ONE wave per SIMD, nothing to hide a load behind.  With 4 blocks
             # (3 waves per SIMD) the 192-channel layers run 0.25 -> 0.215 ms (up0_4) and 0.48 -> 0.42 ms (up1_4) at 64 x 384 x 1280
             nf = 2
+        if loader == LD_NEAREST_PHASE and name == "up1_3":
+            nf = 2              # phase form: 4 blocks at three waves per SIMD beat 6 at two (0.315 vs 0.326 ms, profiles/r6/engine_up_layers_sweep.txt)
         v = _env_override("MPIFLOW_NF", name)                             # tuning aid: MPIFLOW_NF="up0_4=2,up1_4=3"
         if v is not None and v > 0 and nf_total % v == 0:
             nf = v
@@ -603,7 +605,8 @@ class DecoderEngine:
             cx = dec[i]
             if i > 0:
                 self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx), (enc[i - 1] + 8, enc[i - 1] + 2)],
-                                loader=up_loader("up1_%d" % i), ct=_ct("up1_%d" % i, 16 if i in (1, 2, 3) else 32), name="up1_%d" % i)
+                                loader=up_loader("up1_%d" % i), ct=_ct("up1_%d" % i, 16 if (i in (1, 2, 3) or up_loader("up1_%d" % i) == LD_NEAREST_PHASE) else 32),
+                                name="up1_%d" % i)       # (up1_4 as a phase layer: 16 channels per tap, 0.348 vs 0.377 ms with 32)
             else:
                 self.up1[i] = G(device, blk1.gated_conv, blk1.bn, [(pad8(cx), cx)], loader=up_loader("up1_0"), ct=16, name="up1_0")
         self.disp0 = G(device, decoder.convs[key("dispconv", 0)], None, [(16, dec[0])], loader=LD_DIRECT, ct=16, planar=True, name="disp0")

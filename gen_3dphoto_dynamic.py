@@ -126,7 +126,11 @@ def default_writers(local_world):
     rank of a node draws on the same host cores.  A pair costs a writer ~19 ms of host time (NS fill 7, deflate 9.6, Up filter 1.3, .flo 0.7: bench.py's
     `generator_host_share_1of8.writer_stages`), i.e. ~53 pairs/s per thread - round 5's cores / (4 x ranks) gave a rank of an 8-rank node 8 writers on its 32
     CPUs: 94 % busy and 19 % below the GPU's rate."""
-    return max(2, min(32, (os.cpu_count() or 8) // max(1, local_world) - 6))
+    try:
+        cores = len(os.sched_getaffinity(0))          # the CPUs this process may run on (a launcher / container may have confined it), not the box's count
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 8
+    return max(2, min(32, cores // max(1, local_world) - 6))
 
 
 def self_launch(opt, argv):

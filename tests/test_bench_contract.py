@@ -33,6 +33,32 @@ def test_single_gpu_line():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    # round 6: a pair's host work (pose draws, homographies, fp64 inverses) is INSIDE the timed region of the default line, the product library is the one measured,
+    # and the scalars the judge reads sit in `config` (the driver's record keeps config values, only the names of the other sub-records)
+    c = d["config"]
+    assert c["host_prep"].startswith("per pair, timed") and c["host_prep_us_per_pair_timed"] > 0 and c["library"] == "libmpiflow_hip.so"
+    assert set(c["host_prep_comparison"]) == {"once", "per-pair", "window"} and all(v["pairs_per_s"] > 0 for v in c["host_prep_comparison"].values())
+    for k in ("pair_alone_pairs_per_s", "value_over_pair_alone", "pairs_per_s_host_prep_once", "pairs_per_s_host_prep_window", "stage_b_2views_frac", "stage_ac_frac",
+              "hbm_read_GBps", "hbm_copy_GBps", "cpu_baseline_pairs_per_s", "batch512_pairs_per_s"):
+        assert isinstance(c[k], float) and c[k] > 0, k
+    for k in ("n1_ms_per_image", "generator_pairs_per_s_steady", "generator_host_share_1of8_vs_unrestricted"):       # --no-generator: present, null
+        assert k in c and c[k] is None, k
+
+
+def test_host_prep_modes_and_the_witness_switch():
+    """--host-prep once (rounds 1-5's form: fixed poses prepared at set-up) still runs and says so; --witness measures on the witness build and says so; a witness-only
+    tune key is refused on the product library."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fast = SMALL + ["--no-sub", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--host-prep", "once"] + fast, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _last_json(r.stdout)["config"]["host_prep"].startswith("once per image")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--witness", "--tune", "view_shift=4"] + fast, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "witness" in _last_json(r.stdout)["config"]["library"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tune", "view_shift=4"] + fast, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "unknown key" in r.stderr
 
 
 def test_two_rank_path_over_gloo():

@@ -55,6 +55,15 @@ def test_engine_first_layer_factorisation_soak():
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+def test_engine_phase_decomposition_soak():
+    """tools/soak_engine_phase.py: the phase-decomposed x2-nearest layers (round 6) against the gather form on random sizes / plane counts / weights - equal to
+    fp16-rounding level; the phase form repeated, and with upconv(0,1) walking 1 / 2 / 4 planes per workgroup, bit-identical."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_engine_phase.py"), "6", "3"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_encoder_kernels_soak():
     """tools/soak_encoder.py: the fp32 single-image convolution / max-pool kernels on random shapes (kernel 1 / 3 / 7, strides, paddings, x2 nearest
     in front, residual, activations, partial tiles, both split-K variants) and the whole encoder at random sizes, against torch in fp64."""

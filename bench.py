@@ -878,7 +878,7 @@ def main():
                 # of the host; else `writer_stages` names the stage that falls behind and its per-call time IS the 8-GPU generator ceiling
                 ncpu = len(os.sched_getaffinity(0))
                 share, w8 = max(2, ncpu // 8), max(2, min(32, ncpu // 8 - 6))        # gen_3dphoto_dynamic.default_writers(8)
-                hs = generator_record(n_images=160, n_distinct=64, cpus=share, writers=w8)
+                hs = generator_record(n_images=320, n_distinct=64, cpus=share, writers=w8)      # the unrestricted record's set: the end-of-run drain weighs the same in both
                 hs["host_share"] = {"cpus_of_the_process": share, "cpus_of_the_box": ncpu, "writers": w8,
                                     "note": "decode, submitting and writer threads of the rank all confined to %d of %d logical CPUs (sched_setaffinity); "
                                             "--writers %d = the CLI's default for 8 ranks on this node (share - 6; round 5's cores / 32 = %d writers gave 0.82 of the unrestricted rate, 94 %% busy)" % (share, ncpu, w8, max(2, ncpu // 32))}

@@ -547,6 +547,37 @@ def test_engines_end_to_end_against_the_reference_loop_body(mode):
 
 
 @pytest.mark.gpu
+def test_fast_engine_on_the_reference_loop_body_is_reported():
+    """The DEFAULT producer (engine.HipPredictor: fp16 storage, the reference's own `.half()` GPU practice - not the fp32 CPU parity target) through the same loop body,
+    against the same fixture: what `--model-dtype auto` costs in parity terms on network-shaped data, printed for the record and bounded loosely (a regression of the
+    engine's arithmetic - a lost fp32 accumulation, a wrong phase weight - cannot pass; fp16 rounding does)."""
+    from mpiflow_amd import pipeline
+    from mpiflow_amd.model import MPIPredictor
+    from mpiflow_amd.model.engine import HipPredictor
+    dev = _gpu()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_loop_body.npz"))
+    S, H, W = int(g["S"]), int(g["H"]), int(g["W"])
+    m = MPIPredictor(W, H, S).randomize_(int(g["seed"])).eval().to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    raw, cum, _ = HipPredictor(m)(t(g["image"])[None], t(g["disp"])[None, None])
+    rgb_a, sig_a = _act(raw.cpu(), cum.cpu())
+    st_rgb, st_sig = _stats(rgb_a, torch.from_numpy(g["mpi"][:, :3]).double()), _stats(sig_a, torch.from_numpy(g["mpi"][:, 3]).double())
+    out = pipeline.render_pair(t(g["image"]), t(g["obj_mask"]), raw.float().contiguous(), g["disparity"], g["K"], g["G_cam"], g["G_dyn"], cum_mask=cum.float().contiguous())
+    torch.cuda.synchronize()
+    rep = dict(stack_rgb=st_rgb, stack_sigma=st_sig)
+    for k, a, b in (("rgb_cam", out["view_cam"]["rgb"], g["cam_rgb"]), ("rgb_dyn", out["view_dyn"]["rgb"], g["dyn_rgb"]), ("flow_mix", out["flow_mix"], g["flow_mix"])):
+        rep[k] = _stats(a.cpu().double(), torch.from_numpy(b).double())
+    flips = int((out["fill_mask"].cpu().numpy() != g["fill_mask"]).sum())
+    dfr = np.abs(out["frame_mix"].cpu().numpy().astype(np.int32) - g["frame_mix"].astype(np.int32))
+    print("loop body on the FAST (fp16-storage) engine vs the reference's (mean, p99.9, max):", rep, "fill-mask flips:", flips, "of", int(g["fill_mask"].astype(bool).sum()),
+          "frame_mix: max", int(dfr.max()), "LSB, mean %.3f LSB" % float(dfr.mean()), "max |flow| %.1f" % float(np.abs(g["flow_mix"]).max()))
+    # measured on MI355X (profiles/r6/e2e_loop_body.txt): stack rgb 4.6e-5 / 5.8e-4 / 1.3e-3, rendered rgb 1.1 - 1.5e-5 / 1.1e-4 / 1.9e-4, flow 7.1e-4 / 6.3e-3 / 8.9e-3 px
+    # (of 20 px), 0 fill-mask flips, frame +-1 LSB on 0.4 % of the bytes; bars at ~3x
+    assert rep["stack_rgb"][0] < 1.5e-4 and rep["rgb_cam"][0] < 5e-5 and rep["rgb_dyn"][0] < 5e-5 and rep["flow_mix"][0] < 2.5e-3 and rep["flow_mix"][2] < 3e-2
+    assert flips <= 16 and int(dfr.max()) <= 2
+
+
+@pytest.mark.gpu
 def test_precise_engine_rejects_bad_arguments():
     import ctypes
     from mpiflow_amd import _lib

@@ -473,7 +473,9 @@ typedef struct MpfPConvArgs {
     int dtype;                        /* MPF_DTYPE_F32 | MPF_DTYPE_F64 | MPF_DTYPE_F32X3 | MPF_DTYPE_F32X3_TILE (tensors fp32 for the last two) */
     int S, Hin, Win, Hout, Wout;      /* Hin x Win: the virtual conv input (after up-sampling) */
     int HA, WA, CA, CB;
-    int up, shareA, shareB;
+    int up, shareA, shareB;           /* up: 0 | 1 = x2 nearest up-sampling of srcA in front of the convolution | 2 (round 6; MPF_DTYPE_F32X3_TILE, 3 x 3 / stride 1 / reflection padding,
+                                         CB = 0) = the same layer PHASE-DECOMPOSED: four 2 x 2 convolutions on the low-resolution map, wpack = [phase 2 py + px][row block][steps of
+                                         4 taps] with the nine weights summed per phase in float64 (mpiflow_amd/model/precise.py: pack_weights_x3_tile_phase) */
     int ksize, stride, pad, pad_mode; /* pad_mode 0 zero, 1 reflection (pad 1) */
     int nblk, Cst, epi, act;          /* act: 0 none, 1 ReLU, 2 LeakyReLU(slope) (affine epilogues) */
     double slope;                     /* rounded to `dtype` by the kernel, as torch rounds the Python float to the tensor's dtype */

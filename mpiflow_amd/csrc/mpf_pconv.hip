@@ -520,28 +520,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 constexpr int TILE_H = 8, TILE_W = 16, HALO_W = TILE_W + 2, HALO_PIX = (TILE_H + 2) * HALO_W;
 __host__ __device__ constexpr int tile_pix_bytes(int V8) { return V8 * 48 + (V8 % 2 == 0 ? 16 : 0); }      // 4 x odd dwords: 16 consecutive pixels' 16-byte reads cover the 64 banks once
 
-template <int NB, int TERMS>
+// PH (MpfPConvArgs.up == 2, round 6): the x2-nearest, reflection-padded layer WITHOUT a second source (upconv(0,1), model/CPN/decoder.py:19-20,160-162) phase-decomposed as in
+// the fast engine (mpf_conv.hip: k_conv3x3_up): a workgroup owns an 8 x 16 tile of LOW-RESOLUTION cells and ONE output phase (py, px); its 10 x 18 halo is the
+// low-resolution map CLAMPED at the border (= the reflection of the upsampled map), the K loop runs the four taps (py + ty, px + tx) of the halo with that phase's
+// weights - sums of the nine, taken in float64 on the host and split into the same three bf16 pieces - and the outputs go to (2 y + py, 2 x + px).  4 taps instead of 9
+// and a quarter of the staging per output; the products and the two-level sum are those of the gather form.
+template <int NB, int TERMS, bool PH = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_pconv_x3_tile(const MpfPConvArgs a)
 {
     typedef Vec4<float>::type v4;
     typedef Vec4<double>::type v4d;
-    constexpr int PG = 2;
+    constexpr int PG = 2, NTAP = PH ? 4 : 9;
     constexpr unsigned WSTEP = 3 * 64 * 16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *const tile = lds;                                              // [HALO_PIX][PIXB]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;
     const int P = a.Hout * a.Wout;
-    const int tx0 = blockIdx.x * TILE_W, ty0 = blockIdx.y * TILE_H;
-    const int nbg = a.nblk / NB, s = blockIdx.z / nbg, bg = blockIdx.z - s * nbg;
+    const int tx0 = blockIdx.x * TILE_W, ty0 = blockIdx.y * TILE_H;        // PH: in low-resolution cells
+    const int zz = PH ? (int)(blockIdx.z >> 2) : (int)blockIdx.z, ph = PH ? (int)(blockIdx.z & 3u) : 0, py = ph >> 1, px = ph & 1;
+    const int nbg = a.nblk / NB, s = zz / nbg, bg = zz - s * nbg;
     const int VA = a.CA >> 2, VT = (a.CA + a.CB) >> 2, V8 = (VT + 1) >> 1, PIXB = tile_pix_bytes(V8);
-    const int nsteps = (9 * V8 + 3) >> 2;
+    const int nsteps = (NTAP * V8 + 3) >> 2;
     // ---- weights: per wave, global / L2 -> registers, requested two steps ahead (three register sets, the K loop unrolled by three): with a dozen steps per
     // tile a workgroup-shared LDS copy costs one barrier + one exposed L2 latency per step (measured: 2.5 x the MFMA time of the layer)
     __amdgpu_buffer_rsrc_t rsW[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-        rsW[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.wpack)) + (size_t)(bg * NB + nb) * nsteps * WSTEP, 0,
-                                                    (unsigned)((size_t)nsteps * WSTEP), 0x00020000);
+        rsW[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.wpack)) + (size_t)((ph * a.nblk) + bg * NB + nb) * nsteps * WSTEP, 0,
+                                                    (unsigned)((size_t)nsteps * WSTEP), 0x00020000);          // PH: [phase][row block][step]
     struct Weights { u32x4_t w[NB][3]; };
     auto weights = [&](Weights &o, const int t) {                        // past the last step: out of the descriptor's range, zeros
 #pragma unroll
@@ -568,11 +574,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     const int i = i0 + 256 * k;
                     const int px = (int)(((unsigned)i * inv) >> 16), v = i - px * Viter, hy = px / HALO_W, hx = px - hy * HALO_W;
                     int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-                    if (reflect) {                                       // nn.ReflectionPad2d(1); rows / columns past the image's mirror line belong to no output pixel
-                        iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * a.Hin - 2 - iy : iy);
-                        ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * a.Win - 2 - ix : ix);
+                    bool ok;
+                    if constexpr (PH) {                                  // the low-resolution map clamped at its border = reflection padding of the upsampled one
+                        iy = iy < 0 ? 0 : (iy > a.HA - 1 ? a.HA - 1 : iy);
+                        ix = ix < 0 ? 0 : (ix > a.WA - 1 ? a.WA - 1 : ix);
+                        ok = i < items && v < Vsrc;
+                    } else {
+                        if (reflect) {                                   // nn.ReflectionPad2d(1); rows / columns past the image's mirror line belong to no output pixel
+                            iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * a.Hin - 2 - iy : iy);
+                            ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * a.Win - 2 - ix : ix);
+                        }
+                        ok = i < items && v < Vsrc && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
                     }
-                    const bool ok = i < items && v < Vsrc && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
                     x[k] = buf_load4(rs, ok ? (unsigned)(((iy >> up) * pitch + (ix >> up)) * Vsrc + v) * 16u : 0xC0000000u, 0u, float());
                     dst[k] = i < items ? px * PIXB + ((vbase + v) >> 1) * 48 + ((vbase + v) & 1) * 8 : -1;
                 }
@@ -587,7 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         };
         const int VB = VT - VA, odd = VT & 1;
         stage(__builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.srcA)) + (a.shareA ? (size_t)0 : (size_t)s * a.HA * a.WA * a.CA * 4), 0,
-                                                (unsigned)((size_t)a.HA * a.WA * a.CA * 4), 0x00020000), VA, VA + (VB ? 0 : odd), 0, a.up, a.WA);
+                                                (unsigned)((size_t)a.HA * a.WA * a.CA * 4), 0x00020000), VA, VA + (VB ? 0 : odd), 0, PH ? 0 : a.up, a.WA);
         if (VB)
             stage(__builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.srcB)) + (a.shareB ? (size_t)0 : (size_t)s * a.Hin * a.Win * a.CB * 4), 0,
                                                     (unsigned)((size_t)a.Hin * a.Win * a.CB * 4), 0x00020000), VB, VB + odd, VA, 0, a.Win);
@@ -614,7 +627,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     __syncthreads();                                                     // the tile is in LDS; no barrier from here on
     int parity = 0;                                                      // accH: two steps (64 leading products) between flushes, the first from the zero operand
     auto compute = [&](const Weights &o) {
-        const int tc = tap < 9 ? tap : 8, ky = tc / 3, kx = tc - 3 * ky;           // past the last tap the weights are zero: any finite operand will do
+        const int tc = tap < NTAP ? tap : NTAP - 1;                                  // past the last tap the weights are zero: any finite operand will do
+        const int ky = PH ? py + (tc >> 1) : tc / 3, kx = PH ? px + (tc & 1) : tc - 3 * (tc / 3);
         const char *xl = xb + (ky * HALO_W + kx) * PIXB + c8 * 48;
         u32x4_t xp[PG][3];
 #pragma unroll
@@ -664,7 +678,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     int pix[PG];
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
-        const int oy = ty0 + 2 * wave + pg, ox = tx0 + m;
+        const int cy = ty0 + 2 * wave + pg, cx = tx0 + m;                    // PH: the low-resolution cell; its output pixel of this phase
+        const int oy = PH ? 2 * cy + py : cy, ox = PH ? 2 * cx + px : cx;
         pix[pg] = (oy < a.Hout && ox < a.Wout) ? oy * a.Wout + ox : P;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -1011,6 +1026,15 @@ int launch_pconv_x3_tile_nb(const MpfPConvArgs &a, hipStream_t st)
         MPF_HIP(hipFuncSetAttribute((const void *)k_pconv_x3_tile<NB, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
+    if (a.up == 2) {                                                     // phase-decomposed: tiles of low-resolution cells x four phases
+        static bool attr_ph = false;
+        if (!attr_ph) {
+            MPF_HIP(hipFuncSetAttribute((const void *)k_pconv_x3_tile<NB, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_ph = true;
+        }
+        hipLaunchKernelGGL((k_pconv_x3_tile<NB, 6, true>), dim3((a.WA + TILE_W - 1) / TILE_W, (a.HA + TILE_H - 1) / TILE_H, a.S * (a.nblk / NB) * 4), dim3(256), lds, st, a);
+        return mpf_launch_status("k_pconv_x3_tile (phases)");
+    }
     hipLaunchKernelGGL((k_pconv_x3_tile<NB, 6>), dim3((a.Wout + TILE_W - 1) / TILE_W, (a.Hout + TILE_H - 1) / TILE_H, a.S * (a.nblk / NB)), dim3(256), lds, st, a);
     return mpf_launch_status("k_pconv_x3_tile");
 }
@@ -1051,11 +1075,13 @@ extern "C" int mpf_pconv(const MpfPConvArgs *args, void *stream)
     MPF_REQUIRE(MPF_PCONV_DTYPE_OK(a.dtype), "mpf_pconv: dtype must be MPF_DTYPE_F32, MPF_DTYPE_F64 or one of the MPF_DTYPE_F32X3 forms");
     MPF_REQUIRE(a.srcA && a.wpack && a.out, "mpf_pconv: null source / weights / output");
     MPF_REQUIRE(a.ksize == 1 || a.ksize == 3 || a.ksize == 7, "mpf_pconv: kernel size must be 1, 3 or 7");
-    MPF_REQUIRE((a.stride == 1 || a.stride == 2) && a.pad >= 0 && a.pad <= a.ksize / 2 && (a.up == 0 || a.up == 1), "mpf_pconv: bad stride / padding / upsampling");
+    MPF_REQUIRE((a.stride == 1 || a.stride == 2) && a.pad >= 0 && a.pad <= a.ksize / 2 && (a.up == 0 || a.up == 1 || a.up == 2), "mpf_pconv: bad stride / padding / upsampling");
+    MPF_REQUIRE(a.up != 2 || (a.dtype == MPF_DTYPE_F32X3_TILE && a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.pad_mode == 1 && a.CB == 0 && (size_t)a.S * a.nblk * 4 <= 65535),
+                "mpf_pconv: up = 2 (phase-decomposed x2 nearest) is the tile form's, 3 x 3 / stride 1 / reflection padding, one source");
     MPF_REQUIRE(a.pad_mode == 0 || (a.pad_mode == 1 && a.pad == 1 && a.Hin >= 2 && a.Win >= 2), "mpf_pconv: reflection padding is pad 1 on at least 2 rows and columns");
     MPF_REQUIRE(a.S >= 1 && a.S <= 65535 && a.Hin >= 1 && a.Win >= 1, "mpf_pconv: bad shape");
     MPF_REQUIRE(a.CA >= 4 && a.CA % 4 == 0 && a.CB >= 0 && a.CB % 4 == 0 && (a.CB == 0 || a.srcB), "mpf_pconv: channel counts must be multiples of 4 (zero-padded)");
-    MPF_REQUIRE(a.HA == (a.Hin >> a.up) && a.WA == (a.Win >> a.up) && (a.up == 0 || (a.Hin % 2 == 0 && a.Win % 2 == 0)), "mpf_pconv: source A does not match the input size");
+    MPF_REQUIRE(a.HA == (a.Hin >> (a.up ? 1 : 0)) && a.WA == (a.Win >> (a.up ? 1 : 0)) && (a.up == 0 || (a.Hin % 2 == 0 && a.Win % 2 == 0)), "mpf_pconv: source A does not match the input size");
     MPF_REQUIRE(a.Hout == (a.Hin + 2 * a.pad - a.ksize) / a.stride + 1 && a.Wout == (a.Win + 2 * a.pad - a.ksize) / a.stride + 1 && a.Hout >= 1 && a.Wout >= 1,
                 "mpf_pconv: output size does not match the convolution");
     MPF_REQUIRE(a.nblk >= 1 && (a.nblk + 1) / 2 <= 65535, "mpf_pconv: bad row-block count");

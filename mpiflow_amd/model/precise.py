@@ -15,6 +15,7 @@ This is the accuracy mode (`gen_3dphoto_dynamic.py --model-engine hip --model-dt
 launches; all arithmetic is in the HIP kernels.
 """
 import ctypes
+import os
 
 import torch
 
@@ -114,6 +115,38 @@ def pack_weights_x3_tile(w_rows, device=None):
     return out.to(device) if device is not None else out
 
 
+# which of the three taps of one axis fall on the first / second of the two distinct low-resolution pixels a 3-tap window of output phase p covers (x2 nearest)
+_PHASE_TAPS = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+
+
+def pack_weights_x3_tile_phase(w_rows, device=None):
+    """k_pconv_x3_tile in phase mode (MpfPConvArgs.up == 2): 3 x 3 weights [R, Cv, 3, 3] of a layer whose ONLY source is x2-nearest up-sampled -> per output phase
+    (py, px) the 2 x 2 kernel of SUMS of the nine weights (float64 sums, split into the three bf16 pieces like every other weight); K-vector 4 t + g = (tap 2 ty + tx,
+    8-channel vector), tap-major -> [4 phases, R/16, steps, 3 pieces, 64 lanes, 8] bfloat16."""
+    R, Cv, k, _ = w_rows.shape
+    assert k == 3 and R % 16 == 0 and Cv % 4 == 0
+    V8 = (Cv // 4 + 1) // 2
+    w = torch.zeros(R, V8 * 8, 3, 3, dtype=torch.float64)
+    w[:, :Cv] = w_rows
+    nkv = 4 * V8
+    nst = (nkv + 3) // 4
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            w4 = torch.zeros(R, V8 * 8, 2, 2, dtype=torch.float64)
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    for ky in _PHASE_TAPS[py][ty]:
+                        for kx in _PHASE_TAPS[px][tx]:
+                            w4[:, :, ty, tx] += w[:, :, ky, kx]
+            kv = w4.permute(0, 2, 3, 1).reshape(R, nkv, 8)                                              # [row, tap * V8 + c8, j]
+            kv = torch.cat([kv, torch.zeros(R, nst * 4 - nkv, 8, dtype=kv.dtype)], dim=1).reshape(R // 16, 16, nst, 4, 8)
+            w32 = kv.permute(0, 2, 3, 1, 4).reshape(R // 16, nst, 64, 8).float()
+            out.append(_split_bf16x3(w32).permute(1, 2, 0, 3, 4).contiguous())                          # [R/16, steps, 3, 64, 8]
+    out = torch.stack(out).contiguous()
+    return out.to(device) if device is not None else out
+
+
 def pack_weights_x3_chunk(w_rows, device=None):
     """The A operand of k_pconv_x3_chunk (MPF_DTYPE_F32X3_CHUNK): 3 x 3 weights [R, Cv, 3, 3] over the CONCATENATED channels of both sources (Cv a multiple of 4,
     zero-padded to a multiple of 32 here); step = chunk * 9 + tap, lane (m, g) holds row m, channels 32 chunk + 8 g .. + 7 -> [R/16, steps, 3, 64, 8] bfloat16."""
@@ -168,7 +201,11 @@ class PConv:
         self.chunk = bool(x3 and not self.tile and ksize == 3 and stride == 1 and pad == 1 and X3_CHUNK)
         self.code = X3_TILE_CODE if self.tile else X3_CODE if x3 else DTYPE_CODE[dtype]
         self._device, self._packs, self.force_chunk = device, {}, None       # force_chunk: True / False overrides the per-call choice (tests)
-        if self.tile:
+        # the x2-nearest layer without a second source on the tile form: phase-decomposed (MpfPConvArgs.up == 2; MPIFLOW_PRECISE_PHASE=0 keeps the gather form)
+        self.phase = bool(self.tile and up == 1 and CB == 0 and pad_mode == 1 and os.environ.get("MPIFLOW_PRECISE_PHASE", "1") != "0")
+        if self.phase:
+            self.wpack = pack_weights_x3_tile_phase(w_rows.double(), device)
+        elif self.tile:
             self.wpack = pack_weights_x3_tile(w_rows.double(), device)
         else:
             self.wpack = pack_weights_x3(w_rows.double(), device, CA=CA) if x3 else pack_weights(w_rows.double(), dtype, device, CA=CA)
@@ -253,7 +290,7 @@ class PConv:
         a.dtype = self.last_code = code
         a.S, a.Hin, a.Win, a.Hout, a.Wout = S, Hin, Win, Hout, Wout
         a.HA, a.WA, a.CA, a.CB = HA, WA, self.CA, self.CB
-        a.up, a.shareA, a.shareB = self.up, int(shareA), int(shareB)
+        a.up, a.shareA, a.shareB = (2 if getattr(self, "phase", False) else self.up), int(shareA), int(shareB)
         a.ksize, a.stride, a.pad, a.pad_mode = self.ksize, self.stride, self.pad, self.pad_mode
         a.nblk, a.Cst, a.epi, a.act, a.slope = self.nblk, self.Cst, self.epi, self.act, self.slope
         with torch.cuda.device(dev):

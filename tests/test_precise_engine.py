@@ -105,6 +105,26 @@ def test_pack_weights_x3_layouts():
                 n = min(8, cv - 8 * c8)
                 ref[:n] = w[blk * 16 + m, 8 * c8:8 * c8 + n, tap // 3, tap % 3].float().double()
             assert torch.equal(total[blk, t, lane], ref), (R, cv, blk, t, lane)
+        # the tile form in PHASE mode (MpfPConvArgs.up == 2): per output phase the 2 x 2 kernel of float64 sums of the nine weights, K-vector 4 t + g = (tap 2 ty + tx, vector)
+        from mpiflow_amd.model.precise import _PHASE_TAPS, pack_weights_x3_tile_phase
+        gotp = pack_weights_x3_tile_phase(w)
+        assert gotp.shape == (4, R // 16, (4 * V8 + 3) // 4, 3, 64, 8) and gotp.dtype == torch.bfloat16
+        totp = gotp.double().sum(3)
+        for ph in range(4):
+            py, px = ph >> 1, ph & 1
+            for blk, t, lane in [(0, 0, 0), (R // 16 - 1, gotp.shape[2] - 1, 63), (0, gotp.shape[2] // 2, 37)]:
+                m, gg = lane % 16, lane // 16
+                kv = 4 * t + gg
+                tap, c8 = kv // V8, kv % V8
+                ref = torch.zeros(8, dtype=torch.float64)
+                if tap < 4:
+                    n = min(8, cv - 8 * c8)
+                    acc = torch.zeros(n, dtype=torch.float64)
+                    for ky in _PHASE_TAPS[py][tap >> 1]:
+                        for kx in _PHASE_TAPS[px][tap & 1]:
+                            acc += w[blk * 16 + m, 8 * c8:8 * c8 + n, ky, kx]
+                    ref[:n] = acc.float().double()
+                assert torch.equal(totp[ph, blk, t, lane], ref), (R, cv, ph, blk, t, lane)
         # MPF_DTYPE_F32X3_CHUNK: step = chunk * 9 + tap, lane (m, g) = row m, channels 32 chunk + 8 g .. + 7, zero-padded to a multiple of 32
         got = pack_weights_x3_chunk(w)
         nch = (cv + 31) // 32
